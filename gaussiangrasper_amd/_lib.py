@@ -1,0 +1,72 @@
+"""ctypes binding of libgg_raster.so (C ABI: include/gg_raster.h).
+
+There is NO CPU fallback: if the library is missing and cannot be built, or an operator is
+handed a non-HIP tensor, the call raises.  (The CPU restatement under oracle/ is test
+infrastructure and is never imported from here.)"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgg_raster.so")
+ABI_VERSION = 1
+
+_P, _I, _F, _I64, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/gg_raster.h declaration by declaration
+SIGNATURES = {
+    "gg_abi_version": (_I, []),
+    "gg_last_error": (C.c_char_p, []),
+    "gg_project_fwd": (_I, [_I, _P, _P, _F, _P, _P, _P, _F, _F, _F, _F, _I, _I, _I, _I, _F,
+                            _P, _P, _P, _P, _P, _P, _P]),
+    "gg_project_bwd": (_I, [_I, _P, _P, _F, _P, _P, _P, _F, _F, _F, _F, _I, _I, _P, _P, _P, _P, _P,
+                            _P, _P, _P, _P]),
+    "gg_sh_fwd": (_I, [_I, _I, _I, _P, _P, _P, _P]),
+    "gg_sh_bwd": (_I, [_I, _I, _I, _P, _P, _P, _P]),
+    "gg_count_workspace": (_SZ, [_I]),
+    "gg_count_intersects": (_I, [_I, _P, _P, _P, _SZ, _P]),
+    "gg_bin_sort_workspace": (_SZ, [_I, _I64]),
+    "gg_bin_sort": (_I, [_I, _I64, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
+    "gg_blend_workspace": (_SZ, [_I]),
+    "gg_blend_fwd": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "gg_blend_bwd": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                          _P, _SZ, _P]),
+    "gg_expf_array": (_I, [_I, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class GGError(RuntimeError):
+    pass
+
+
+def load(build_if_missing: bool = True):
+    """Load (building first if the .so is absent and hipcc is available) and type the library."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if not build_if_missing:
+            raise GGError(f"{LIB_PATH} not found; run `python -m gaussiangrasper_amd.build`")
+        from . import build as _build
+        try:
+            _build.build()
+        except Exception as exc:  # noqa: BLE001 - surface the build failure loudly
+            raise GGError(f"libgg_raster.so is missing and could not be built: {exc}") from exc
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
+        fn.restype, fn.argtypes = res, args
+    ver = lib.gg_abi_version()
+    if ver != ABI_VERSION:
+        raise GGError(f"libgg_raster.so ABI {ver} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().gg_last_error().decode("utf-8", "replace")
+        raise GGError(f"{what} failed ({status}): {msg}")

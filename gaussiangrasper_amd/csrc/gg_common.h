@@ -1,0 +1,93 @@
+// gg_common.h — shared by the gfx950 kernels of libgg_raster.so (not by the oracle).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gg_constants.h"
+#include "../../include/gg_raster.h"
+
+#define GG_WAVE 64
+
+void gg_set_error(const char *fmt, ...);
+
+#define GG_REQUIRE(cond, msg)                      \
+    do {                                           \
+        if (!(cond)) {                             \
+            gg_set_error("%s: %s", __func__, msg); \
+            return GG_ERR_INVALID_ARG;             \
+        }                                          \
+    } while (0)
+
+#define GG_CHECK_LAUNCH()                                                   \
+    do {                                                                    \
+        hipError_t e__ = hipGetLastError();                                 \
+        if (e__ != hipSuccess) {                                            \
+            gg_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+            return GG_ERR_LAUNCH;                                           \
+        }                                                                   \
+    } while (0)
+
+static inline size_t gg_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------
+// gg_expf: the operation sequence documented in gg_constants.h.  Every step is a correctly
+// rounded fp32 instruction (v_mul, v_rndne, v_fma, v_add, integer shift), the file is built
+// with -ffp-contract=off, so the result is bit-identical to oracle/gg_oracle.c:gg_exp.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gg_expf(float x) {
+    float t = x * GG_EXP_LOG2E;
+    float n = __builtin_rintf(t);
+    float r = __builtin_fmaf(n, -GG_EXP_LN2_HI, x);
+    r = __builtin_fmaf(n, -GG_EXP_LN2_LO, r);
+    float p = GG_EXP_P0;
+    p = __builtin_fmaf(p, r, GG_EXP_P1);
+    p = __builtin_fmaf(p, r, GG_EXP_P2);
+    p = __builtin_fmaf(p, r, GG_EXP_P3);
+    p = __builtin_fmaf(p, r, GG_EXP_P4);
+    p = __builtin_fmaf(p, r, GG_EXP_P5);
+    float z = r * r;
+    float y = __builtin_fmaf(p, z, r);
+    y = y + 1.0f;
+    float s = __builtin_bit_cast(float, (uint32_t)((int)n + 127) << 23);
+    float e = y * s;
+    return (x < GG_EXP_LO) ? 0.0f : e;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tile bounding box of a projected Gaussian (same float-domain clamp as the oracle).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int gg_clampi_f(float v, int bound) {
+    return (int)fminf(fmaxf(v, 0.0f), (float)bound);
+}
+__device__ __forceinline__ void gg_tile_bbox(float cx, float cy, float radius, int tiles_x,
+                                             int tiles_y, int &x0, int &y0, int &x1, int &y1) {
+    float tcx = cx / (float)GG_BLOCK, tcy = cy / (float)GG_BLOCK;
+    float tr = radius / (float)GG_BLOCK;
+    x0 = gg_clampi_f(tcx - tr, tiles_x);
+    x1 = gg_clampi_f((tcx + tr) + 1.0f, tiles_x);
+    y0 = gg_clampi_f(tcy - tr, tiles_y);
+    y1 = gg_clampi_f((tcy + tr) + 1.0f, tiles_y);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave64 helpers (DPP; no LDS traffic).
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float gg_dpp_add(float v) {
+    int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK,
+                                            BANK_MASK, true);
+    return v + __builtin_bit_cast(float, moved);
+}
+// Sum over the 64 lanes; the total is valid in lane 63.
+__device__ __forceinline__ float gg_wave_sum_to_lane63(float v) {
+    v = gg_dpp_add<0x111, 0xf, 0xf>(v);  // row_shr:1
+    v = gg_dpp_add<0x112, 0xf, 0xf>(v);  // row_shr:2
+    v = gg_dpp_add<0x114, 0xf, 0xe>(v);  // row_shr:4
+    v = gg_dpp_add<0x118, 0xf, 0xc>(v);  // row_shr:8
+    v = gg_dpp_add<0x142, 0xa, 0xf>(v);  // row_bcast:15
+    v = gg_dpp_add<0x143, 0xc, 0xf>(v);  // row_bcast:31
+    return v;
+}
+__device__ __forceinline__ int gg_lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}

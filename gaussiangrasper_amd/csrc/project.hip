@@ -1,0 +1,500 @@
+// project.hip — per-Gaussian projection, frustum cull, EWA covariance, conic, radius, tile
+// count (forward) and its VJP (backward), plus the SH colour kernels.  O(N) streaming kernels:
+// one lane per Gaussian, HBM-bound.
+//
+// The forward follows oracle/gg_oracle.c:project_fwd operation for operation (fixed association,
+// no contraction: the file is compiled with -ffp-contract=off, div/sqrt are IEEE-correct), so
+// radii, num_tiles_hit, depth bits, xys and conics are bit-identical to the oracle and with
+// them the sort keys and the per-tile lists.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "gg_common.h"
+
+// ---- error plumbing (one thread-local message, SURVEY §8b "gg_last_error") ------------------
+static thread_local char g_err[512] = "";
+void gg_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *gg_last_error(void) { return g_err; }
+extern "C" int gg_abi_version(void) { return 1; }
+
+struct Mat34 {
+    float m[12];
+};
+struct Mat44 {
+    float m[16];
+};
+
+__device__ __forceinline__ void quat_to_R(const float4 q, float *R, float *qn, float &inv) {
+    float nn = ((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w;  // (w,x,y,z) stored in .x.y.z.w
+    inv = 1.0f / sqrtf(nn);
+    float w = q.x * inv, x = q.y * inv, y = q.z * inv, z = q.w * inv;
+    R[0] = 1.0f - 2.0f * (y * y + z * z);
+    R[1] = 2.0f * (x * y - w * z);
+    R[2] = 2.0f * (x * z + w * y);
+    R[3] = 2.0f * (x * y + w * z);
+    R[4] = 1.0f - 2.0f * (x * x + z * z);
+    R[5] = 2.0f * (y * z - w * x);
+    R[6] = 2.0f * (x * z - w * y);
+    R[7] = 2.0f * (y * z + w * x);
+    R[8] = 1.0f - 2.0f * (x * x + y * y);
+    qn[0] = w;
+    qn[1] = x;
+    qn[2] = y;
+    qn[3] = z;
+}
+
+__global__ __launch_bounds__(256) void project_fwd_kernel(
+    int N, const float *__restrict__ means, const float *__restrict__ scales, float glob_scale,
+    const float *__restrict__ quats, const float *__restrict__ viewmat,
+    const float *__restrict__ projmat, float fx, float fy, float cx, float cy, int img_h,
+    int img_w, int tiles_x, int tiles_y, float clip_thresh, float *__restrict__ cov3d,
+    float *__restrict__ xys, float *__restrict__ depths, int32_t *__restrict__ radii,
+    float *__restrict__ conics, int32_t *__restrict__ num_tiles_hit) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float V[12], P[16];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) V[k] = viewmat[k];  // uniform -> scalar loads
+#pragma unroll
+    for (int k = 0; k < 16; ++k) P[k] = projmat[k];
+
+    float o_c3[6] = {0, 0, 0, 0, 0, 0};
+    float o_con[3] = {0, 0, 0};
+    float o_x = 0, o_y = 0, o_d = 0;
+    int o_r = 0, o_n = 0;
+
+    float px = means[3 * i], py = means[3 * i + 1], pz = means[3 * i + 2];
+    float tx = ((V[0] * px + V[1] * py) + V[2] * pz) + V[3];
+    float ty = ((V[4] * px + V[5] * py) + V[6] * pz) + V[7];
+    float tz = ((V[8] * px + V[9] * py) + V[10] * pz) + V[11];
+    if (tz > clip_thresh) {
+        float R[9], qn[4], inv;
+        float4 q = reinterpret_cast<const float4 *>(quats)[i];
+        quat_to_R(q, R, qn, inv);
+        float s0 = glob_scale * scales[3 * i], s1 = glob_scale * scales[3 * i + 1],
+              s2 = glob_scale * scales[3 * i + 2];
+        float M[9] = {R[0] * s0, R[1] * s1, R[2] * s2, R[3] * s0, R[4] * s1,
+                      R[5] * s2, R[6] * s0, R[7] * s1, R[8] * s2};
+        float c3[6];
+        c3[0] = (M[0] * M[0] + M[1] * M[1]) + M[2] * M[2];
+        c3[1] = (M[0] * M[3] + M[1] * M[4]) + M[2] * M[5];
+        c3[2] = (M[0] * M[6] + M[1] * M[7]) + M[2] * M[8];
+        c3[3] = (M[3] * M[3] + M[4] * M[4]) + M[5] * M[5];
+        c3[4] = (M[3] * M[6] + M[4] * M[7]) + M[5] * M[8];
+        c3[5] = (M[6] * M[6] + M[7] * M[7]) + M[8] * M[8];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o_c3[k] = c3[k];
+
+        float tan_fovx = (0.5f * (float)img_w) / fx;
+        float tan_fovy = (0.5f * (float)img_h) / fy;
+        float lim_x = GG_FOV_LIM * tan_fovx, lim_y = GG_FOV_LIM * tan_fovy;
+        float txc = tz * fminf(lim_x, fmaxf(-lim_x, tx / tz));
+        float tyc = tz * fminf(lim_y, fmaxf(-lim_y, ty / tz));
+        float rz = 1.0f / tz;
+        float rz2 = rz * rz;
+        float J00 = fx * rz, J02 = (-(fx * txc)) * rz2;
+        float J11 = fy * rz, J12 = (-(fy * tyc)) * rz2;
+        float T00 = J00 * V[0] + J02 * V[8], T01 = J00 * V[1] + J02 * V[9],
+              T02 = J00 * V[2] + J02 * V[10];
+        float T10 = J11 * V[4] + J12 * V[8], T11 = J11 * V[5] + J12 * V[9],
+              T12 = J11 * V[6] + J12 * V[10];
+        float A00 = (T00 * c3[0] + T01 * c3[1]) + T02 * c3[2];
+        float A01 = (T00 * c3[1] + T01 * c3[3]) + T02 * c3[4];
+        float A02 = (T00 * c3[2] + T01 * c3[4]) + T02 * c3[5];
+        float A10 = (T10 * c3[0] + T11 * c3[1]) + T12 * c3[2];
+        float A11 = (T10 * c3[1] + T11 * c3[3]) + T12 * c3[4];
+        float A12 = (T10 * c3[2] + T11 * c3[4]) + T12 * c3[5];
+        float a = ((A00 * T00 + A01 * T01) + A02 * T02) + GG_BLUR;
+        float b = (A00 * T10 + A01 * T11) + A02 * T12;
+        float c = ((A10 * T10 + A11 * T11) + A12 * T12) + GG_BLUR;
+
+        float det = a * c - b * b;
+        if (det != 0.0f) {
+            float inv_det = 1.0f / det;
+            o_con[0] = c * inv_det;
+            o_con[1] = (-b) * inv_det;
+            o_con[2] = a * inv_det;
+            float bm = 0.5f * (a + c);
+            float sq = sqrtf(fmaxf(GG_EIG_FLOOR, bm * bm - det));
+            float v1 = bm + sq, v2 = bm - sq;
+            float radius = ceilf(GG_RADIUS_SIGMA * sqrtf(fmaxf(v1, v2)));
+
+            float hx = ((P[0] * px + P[1] * py) + P[2] * pz) + P[3];
+            float hy = ((P[4] * px + P[5] * py) + P[6] * pz) + P[7];
+            float hw = ((P[12] * px + P[13] * py) + P[14] * pz) + P[15];
+            float rw = 1.0f / (hw + GG_W_EPS);
+            float ndx = hx * rw, ndy = hy * rw;
+            float ux = ((0.5f * (float)img_w) * ndx + cx) - GG_PIX_OFFSET;
+            float uy = ((0.5f * (float)img_h) * ndy + cy) - GG_PIX_OFFSET;
+            int x0, y0, x1, y1;
+            gg_tile_bbox(ux, uy, radius, tiles_x, tiles_y, x0, y0, x1, y1);
+            int area = (x1 - x0) * (y1 - y0);
+            if (area > 0) {
+                o_n = area;
+                o_d = tz;
+                o_r = (int)radius;
+                o_x = ux;
+                o_y = uy;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cov3d[6 * (size_t)i + k] = o_c3[k];
+    xys[2 * (size_t)i] = o_x;
+    xys[2 * (size_t)i + 1] = o_y;
+    depths[i] = o_d;
+    radii[i] = o_r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) conics[3 * (size_t)i + k] = o_con[k];
+    num_tiles_hit[i] = o_n;
+}
+
+__global__ __launch_bounds__(256) void project_bwd_kernel(
+    int N, const float *__restrict__ means, const float *__restrict__ scales, float glob_scale,
+    const float *__restrict__ quats, const float *__restrict__ viewmat,
+    const float *__restrict__ projmat, float fx, float fy, int img_h, int img_w,
+    const int32_t *__restrict__ radii, const float *__restrict__ conics,
+    const float *__restrict__ v_xy, const float *__restrict__ v_depth,
+    const float *__restrict__ v_conic, float *__restrict__ v_mean3d, float *__restrict__ v_scale,
+    float *__restrict__ v_quat) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float vm[3] = {0, 0, 0}, vs[3] = {0, 0, 0}, vq4[4] = {0, 0, 0, 0};
+    if (radii[i] > 0) {
+        float V[12], P[16];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) V[k] = viewmat[k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) P[k] = projmat[k];
+        float px = means[3 * i], py = means[3 * i + 1], pz = means[3 * i + 2];
+
+        // (1) pixel centre, exact VJP through the homogeneous divide
+        float hx = ((P[0] * px + P[1] * py) + P[2] * pz) + P[3];
+        float hy = ((P[4] * px + P[5] * py) + P[6] * pz) + P[7];
+        float hw = ((P[12] * px + P[13] * py) + P[14] * pz) + P[15];
+        float rw = 1.0f / (hw + GG_W_EPS);
+        float vnx = (0.5f * (float)img_w) * v_xy[2 * i];
+        float vny = (0.5f * (float)img_h) * v_xy[2 * i + 1];
+        float vhx = vnx * rw, vhy = vny * rw;
+        float vhw = -((vnx * hx + vny * hy) * (rw * rw));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) vm[j] += (P[j] * vhx + P[4 + j] * vhy) + P[12 + j] * vhw;
+        // (2) depth
+        float vz = v_depth[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) vm[j] += V[8 + j] * vz;
+        // (3) conic -> cov2d
+        float ca = conics[3 * i], cb = conics[3 * i + 1], cc = conics[3 * i + 2];
+        float ga = v_conic[3 * i], gb = v_conic[3 * i + 1], gc = v_conic[3 * i + 2];
+        float xg00 = ca * ga + cb * gb, xg01 = ca * gb + cb * gc;
+        float xg10 = cb * ga + cc * gb, xg11 = cb * gb + cc * gc;
+        float s00 = -(xg00 * ca + xg01 * cb), s01 = -(xg00 * cb + xg01 * cc);
+        float s10 = -(xg10 * ca + xg11 * cb), s11 = -(xg10 * cb + xg11 * cc);
+        float v_a = s00, v_b = s01 + s10, v_c = s11;
+
+        float tx = ((V[0] * px + V[1] * py) + V[2] * pz) + V[3];
+        float ty = ((V[4] * px + V[5] * py) + V[6] * pz) + V[7];
+        float tz = ((V[8] * px + V[9] * py) + V[10] * pz) + V[11];
+        float R[9], qn[4], inv_norm;
+        float4 q = reinterpret_cast<const float4 *>(quats)[i];
+        quat_to_R(q, R, qn, inv_norm);
+        float s[3] = {glob_scale * scales[3 * i], glob_scale * scales[3 * i + 1],
+                      glob_scale * scales[3 * i + 2]};
+        float M[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) M[3 * r + k] = R[3 * r + k] * s[k];
+        float C3[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                C3[3 * r + k] = (M[3 * r] * M[3 * k] + M[3 * r + 1] * M[3 * k + 1]) +
+                                M[3 * r + 2] * M[3 * k + 2];
+        float tan_fovx = (0.5f * (float)img_w) / fx, tan_fovy = (0.5f * (float)img_h) / fy;
+        float lim_x = GG_FOV_LIM * tan_fovx, lim_y = GG_FOV_LIM * tan_fovy;
+        float rx = tx / tz, ry = ty / tz;
+        float sgx = (rx > lim_x) ? 1.0f : ((rx < -lim_x) ? -1.0f : 0.0f);
+        float sgy = (ry > lim_y) ? 1.0f : ((ry < -lim_y) ? -1.0f : 0.0f);
+        float txc = tz * fminf(lim_x, fmaxf(-lim_x, rx));
+        float tyc = tz * fminf(lim_y, fmaxf(-lim_y, ry));
+        float rz = 1.0f / tz, rz2 = rz * rz, rz3 = rz2 * rz;
+        float J00 = fx * rz, J02 = (-(fx * txc)) * rz2, J11 = fy * rz, J12 = (-(fy * tyc)) * rz2;
+        float Tm[6] = {J00 * V[0] + J02 * V[8], J00 * V[1] + J02 * V[9], J00 * V[2] + J02 * V[10],
+                       J11 * V[4] + J12 * V[8], J11 * V[5] + J12 * V[9], J11 * V[6] + J12 * V[10]};
+        // (4)
+        float g00 = v_a, g01 = 0.5f * v_b, g11 = v_c;
+        float GT[6];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            GT[k] = g00 * Tm[k] + g01 * Tm[3 + k];
+            GT[3 + k] = g01 * Tm[k] + g11 * Tm[3 + k];
+        }
+        float G3[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) G3[3 * r + k] = Tm[r] * GT[k] + Tm[3 + r] * GT[3 + k];
+        float vT[6];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                vT[3 * r + k] = 2.0f * ((GT[3 * r] * C3[k] + GT[3 * r + 1] * C3[3 + k]) +
+                                        GT[3 * r + 2] * C3[6 + k]);
+        // (5)
+        float vJ00 = (vT[0] * V[0] + vT[1] * V[1]) + vT[2] * V[2];
+        float vJ02 = (vT[0] * V[8] + vT[1] * V[9]) + vT[2] * V[10];
+        float vJ11 = (vT[3] * V[4] + vT[4] * V[5]) + vT[5] * V[6];
+        float vJ12 = (vT[3] * V[8] + vT[4] * V[9]) + vT[5] * V[10];
+        float v_txc = (-(fx * rz2)) * vJ02;
+        float v_tyc = (-(fy * rz2)) * vJ12;
+        float v_tz = ((-(fx * rz2)) * vJ00 - (fy * rz2) * vJ11) +
+                     (2.0f * fx * txc * rz3) * vJ02 + (2.0f * fy * tyc * rz3) * vJ12;
+        float v_tx = (sgx != 0.0f) ? 0.0f : v_txc;
+        float v_ty = (sgy != 0.0f) ? 0.0f : v_tyc;
+        v_tz += (sgx * lim_x) * v_txc + (sgy * lim_y) * v_tyc;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) vm[j] += (V[j] * v_tx + V[4 + j] * v_ty) + V[8 + j] * v_tz;
+        // (6)
+        float vM[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                vM[3 * r + k] = 2.0f * ((G3[3 * r] * M[k] + G3[3 * r + 1] * M[3 + k]) +
+                                        G3[3 * r + 2] * M[6 + k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            vs[k] = glob_scale * ((R[k] * vM[k] + R[3 + k] * vM[3 + k]) + R[6 + k] * vM[6 + k]);
+        float G[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) G[3 * r + k] = vM[3 * r + k] * s[k];
+        float w = qn[0], x = qn[1], y = qn[2], z = qn[3];
+        float vq[4];
+        vq[0] = 2.0f * ((x * (G[7] - G[5]) + y * (G[2] - G[6])) + z * (G[3] - G[1]));
+        vq[1] = 2.0f * (((-2.0f * x) * (G[4] + G[8]) + y * (G[1] + G[3])) +
+                        (z * (G[2] + G[6]) + w * (G[7] - G[5])));
+        vq[2] = 2.0f * ((x * (G[1] + G[3]) + (-2.0f * y) * (G[0] + G[8])) +
+                        (z * (G[5] + G[7]) + w * (G[2] - G[6])));
+        vq[3] = 2.0f * ((x * (G[2] + G[6]) + y * (G[5] + G[7])) +
+                        ((-2.0f * z) * (G[0] + G[4]) + w * (G[3] - G[1])));
+        float dotp = ((qn[0] * vq[0] + qn[1] * vq[1]) + qn[2] * vq[2]) + qn[3] * vq[3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vq4[k] = (vq[k] - qn[k] * dotp) * inv_norm;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        v_mean3d[3 * (size_t)i + k] = vm[k];
+        v_scale[3 * (size_t)i + k] = vs[k];
+    }
+    reinterpret_cast<float4 *>(v_quat)[i] = make_float4(vq4[0], vq4[1], vq4[2], vq4[3]);
+}
+
+// ---- spherical harmonics ---------------------------------------------------------------------
+__device__ __forceinline__ void sh_basis(int deg, float dx, float dy, float dz, float *Y) {
+    Y[0] = GG_SH_C0;
+    if (deg < 1) return;
+    float norm = sqrtf((dx * dx + dy * dy) + dz * dz);
+    float x = dx / norm, y = dy / norm, z = dz / norm;
+    Y[1] = GG_SH_C1 * (-y);
+    Y[2] = GG_SH_C1 * z;
+    Y[3] = GG_SH_C1 * (-x);
+    if (deg < 2) return;
+    float xx = x * x, xy = x * y, xz = x * z, yy = y * y, yz = y * z, zz = z * z;
+    Y[4] = GG_SH_C2_0 * xy;
+    Y[5] = GG_SH_C2_1 * yz;
+    Y[6] = GG_SH_C2_2 * ((2.0f * zz - xx) - yy);
+    Y[7] = GG_SH_C2_3 * xz;
+    Y[8] = GG_SH_C2_4 * (xx - yy);
+    if (deg < 3) return;
+    Y[9] = (GG_SH_C3_0 * y) * (3.0f * xx - yy);
+    Y[10] = (GG_SH_C3_1 * xy) * z;
+    Y[11] = (GG_SH_C3_2 * y) * ((4.0f * zz - xx) - yy);
+    Y[12] = (GG_SH_C3_3 * z) * ((2.0f * zz - 3.0f * xx) - 3.0f * yy);
+    Y[13] = (GG_SH_C3_4 * x) * ((4.0f * zz - xx) - yy);
+    Y[14] = (GG_SH_C3_5 * z) * (xx - yy);
+    Y[15] = (GG_SH_C3_6 * x) * (xx - 3.0f * yy);
+    if (deg < 4) return;
+    Y[16] = (GG_SH_C4_0 * xy) * (xx - yy);
+    Y[17] = (GG_SH_C4_1 * yz) * (3.0f * xx - yy);
+    Y[18] = (GG_SH_C4_2 * xy) * (7.0f * zz - 1.0f);
+    Y[19] = (GG_SH_C4_3 * yz) * (7.0f * zz - 3.0f);
+    Y[20] = GG_SH_C4_4 * (zz * (35.0f * zz - 30.0f) + 3.0f);
+    Y[21] = (GG_SH_C4_5 * xz) * (7.0f * zz - 3.0f);
+    Y[22] = (GG_SH_C4_6 * (xx - yy)) * (7.0f * zz - 1.0f);
+    Y[23] = (GG_SH_C4_7 * xz) * (xx - 3.0f * yy);
+    Y[24] = GG_SH_C4_8 * (xx * (xx - 3.0f * yy) - yy * (3.0f * xx - yy));
+}
+__host__ __device__ static inline int sh_nbases(int deg) {
+    return deg >= 4 ? 25 : (deg + 1) * (deg + 1);
+}
+
+// One lane per Gaussian.  The (N,K,3) coefficient rows are 12K bytes apart, so a direct
+// per-lane walk would touch 64 cache lines per load; instead each wave copies its 64 rows
+// (64*3K contiguous floats) through LDS with fully coalesced dword loads and every lane then
+// reads its own row from LDS (row stride 3K words is odd -> bank-conflict free).
+template <int K>
+__global__ __launch_bounds__(256) void sh_fwd_kernel(int N, int deg,
+                                                     const float *__restrict__ viewdirs,
+                                                     const float *__restrict__ coeffs,
+                                                     float *__restrict__ colors) {
+    constexpr int ROW = 3 * K;
+    __shared__ float stage[4][64 * ROW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int base = (blockIdx.x * 4 + wave) * 64;  // first Gaussian of this wave
+    if (base >= N) return;
+    const int nrows = min(64, N - base);
+    const float *src = coeffs + (size_t)base * ROW;
+    float *st = stage[wave];
+    for (int e = lane; e < nrows * ROW; e += 64) st[e] = src[e];
+    __builtin_amdgcn_wave_barrier();
+    const int i = base + lane;
+    if (lane >= nrows) return;
+    float Y[GG_SH_MAX_BASES];
+    sh_basis(deg, viewdirs[3 * i], viewdirs[3 * i + 1], viewdirs[3 * i + 2], Y);
+    const int nb = min(sh_nbases(deg), K);
+    const float *cf = st + lane * ROW;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float acc = Y[0] * cf[c];
+#pragma unroll
+        for (int k = 1; k < K; ++k)
+            if (k < nb) acc = __builtin_fmaf(Y[k], cf[3 * k + c], acc);
+        colors[3 * (size_t)i + c] = acc;
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void sh_bwd_kernel(int N, int deg,
+                                                     const float *__restrict__ viewdirs,
+                                                     const float *__restrict__ v_colors,
+                                                     float *__restrict__ v_coeffs) {
+    constexpr int ROW = 3 * K;
+    __shared__ float stage[4][64 * ROW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int base = (blockIdx.x * 4 + wave) * 64;
+    if (base >= N) return;
+    const int nrows = min(64, N - base);
+    float *st = stage[wave];
+    const int i = base + lane;
+    if (lane < nrows) {
+        float Y[GG_SH_MAX_BASES];
+        sh_basis(deg, viewdirs[3 * i], viewdirs[3 * i + 1], viewdirs[3 * i + 2], Y);
+        const int nb = min(sh_nbases(deg), K);
+        float vc[3] = {v_colors[3 * i], v_colors[3 * i + 1], v_colors[3 * i + 2]};
+        float *row = st + lane * ROW;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) row[3 * k + c] = (k < nb) ? Y[k] * vc[c] : 0.0f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float *dst = v_coeffs + (size_t)base * ROW;
+    for (int e = lane; e < nrows * ROW; e += 64) dst[e] = st[e];
+}
+
+// ---- C ABI -----------------------------------------------------------------------------------
+extern "C" int gg_project_fwd(int N, const float *means3d, const float *scales, float glob_scale,
+                              const float *quats, const float *viewmat, const float *projmat,
+                              float fx, float fy, float cx, float cy, int img_height,
+                              int img_width, int tiles_x, int tiles_y, float clip_thresh,
+                              float *cov3d, float *xys, float *depths, int32_t *radii,
+                              float *conics, int32_t *num_tiles_hit, gg_stream_t stream) {
+    GG_REQUIRE(N >= 0, "num_points < 0");
+    GG_REQUIRE(img_height > 0 && img_width > 0, "empty image");
+    GG_REQUIRE(tiles_x == (img_width + GG_BLOCK - 1) / GG_BLOCK &&
+                   tiles_y == (img_height + GG_BLOCK - 1) / GG_BLOCK,
+               "tile_bounds must be ceil(W/16), ceil(H/16)");
+    if (N == 0) return GG_OK;
+    GG_REQUIRE(means3d && scales && quats && viewmat && projmat && cov3d && xys && depths &&
+                   radii && conics && num_tiles_hit,
+               "null pointer");
+    hipLaunchKernelGGL(project_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, N, means3d, scales, glob_scale, quats, viewmat,
+                       projmat, fx, fy, cx, cy, img_height, img_width, tiles_x, tiles_y,
+                       clip_thresh, cov3d, xys, depths, radii, conics, num_tiles_hit);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+extern "C" int gg_project_bwd(int N, const float *means3d, const float *scales, float glob_scale,
+                              const float *quats, const float *viewmat, const float *projmat,
+                              float fx, float fy, float cx, float cy, int img_height,
+                              int img_width, const int32_t *radii, const float *conics,
+                              const float *v_xy, const float *v_depth, const float *v_conic,
+                              float *v_mean3d, float *v_scale, float *v_quat,
+                              gg_stream_t stream) {
+    (void)cx;
+    (void)cy;
+    GG_REQUIRE(N >= 0, "num_points < 0");
+    if (N == 0) return GG_OK;
+    GG_REQUIRE(means3d && scales && quats && viewmat && projmat && radii && conics && v_xy &&
+                   v_depth && v_conic && v_mean3d && v_scale && v_quat,
+               "null pointer");
+    hipLaunchKernelGGL(project_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, N, means3d, scales, glob_scale, quats, viewmat,
+                       projmat, fx, fy, img_height, img_width, radii, conics, v_xy, v_depth,
+                       v_conic, v_mean3d, v_scale, v_quat);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+template <int K>
+static void launch_sh(bool fwd, int N, int deg, const float *viewdirs, const float *in, float *out,
+                      hipStream_t s) {
+    dim3 grid((N + 255) / 256), block(256);
+    if (fwd)
+        hipLaunchKernelGGL(sh_fwd_kernel<K>, grid, block, 0, s, N, deg, viewdirs, in, out);
+    else
+        hipLaunchKernelGGL(sh_bwd_kernel<K>, grid, block, 0, s, N, deg, viewdirs, in, out);
+}
+
+static int sh_dispatch(bool fwd, int N, int K, int deg, const float *viewdirs, const float *in,
+                       float *out, gg_stream_t stream) {
+    GG_REQUIRE(N >= 0, "num_points < 0");
+    GG_REQUIRE(K == 1 || K == 4 || K == 9 || K == 16 || K == 25, "num_bases must be 1,4,9,16,25");
+    GG_REQUIRE(deg >= 0 && sh_nbases(deg) <= K, "degrees_to_use exceeds stored bases");
+    if (N == 0) return GG_OK;
+    GG_REQUIRE(viewdirs && in && out, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    switch (K) {
+        case 1: launch_sh<1>(fwd, N, deg, viewdirs, in, out, s); break;
+        case 4: launch_sh<4>(fwd, N, deg, viewdirs, in, out, s); break;
+        case 9: launch_sh<9>(fwd, N, deg, viewdirs, in, out, s); break;
+        case 16: launch_sh<16>(fwd, N, deg, viewdirs, in, out, s); break;
+        default: launch_sh<25>(fwd, N, deg, viewdirs, in, out, s); break;
+    }
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+extern "C" int gg_sh_fwd(int N, int K, int deg, const float *viewdirs, const float *coeffs,
+                         float *colors, gg_stream_t stream) {
+    return sh_dispatch(true, N, K, deg, viewdirs, coeffs, colors, stream);
+}
+extern "C" int gg_sh_bwd(int N, int K, int deg, const float *viewdirs, const float *v_colors,
+                         float *v_coeffs, gg_stream_t stream) {
+    return sh_dispatch(false, N, K, deg, viewdirs, v_colors, v_coeffs, stream);
+}
+
+__global__ void expf_kernel(int n, const float *x, float *y) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = gg_expf(x[i]);
+}
+extern "C" int gg_expf_array(int n, const float *x, float *y, gg_stream_t stream) {
+    GG_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return GG_OK;
+    GG_REQUIRE(x && y, "null pointer");
+    hipLaunchKernelGGL(expf_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, x,
+                       y);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}

@@ -1,0 +1,350 @@
+"""Host-side mirror of the gsplat-0.1.0 operator surface the reference model calls
+(nerfstudio/models/gaussian_splatting.py:46-50 imports, :699/:730/:735/:747/:759/:773 calls),
+sitting directly on the C ABI of libgg_raster.so (include/gg_raster.h).
+
+Same class names, positional argument order, return shapes and error behaviour as
+gsplat.project_gaussians.ProjectGaussians, gsplat.sh.SphericalHarmonics,
+gsplat.rasterize.RasterizeGaussians and gsplat.nd_rasterize.NDRasterizeGaussians.
+PyTorch is plumbing here: it owns device memory and the stream; every kernel is ours.
+
+No CPU path: tensors must live on a HIP device ("cuda" in PyTorch-ROCm), otherwise the operators
+raise.  One design difference from the reference, invisible to the caller: the four rasterize
+calls of one view share ONE binning (tile sort), cached on the identity+version of
+(xys, depths, radii, num_tiles_hit) — the reference re-sorts in every call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+from . import _lib
+from .constants import BLOCK, CLIP_THRESH_DEFAULT, deg_from_sh, num_sh_bases  # noqa: F401
+
+
+def _require_hip(*tensors: Tensor) -> torch.device:
+    dev = None
+    for t in tensors:
+        if not isinstance(t, Tensor):
+            raise TypeError(f"expected a torch.Tensor, got {type(t)}")
+        if t.device.type != "cuda":
+            raise RuntimeError(
+                "gaussiangrasper_amd operators run only on a HIP device (PyTorch-ROCm 'cuda'); "
+                f"got a tensor on '{t.device}'. There is no CPU fallback.")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
+
+
+def _f32(t: Tensor) -> Tensor:
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+def _i32(t: Tensor) -> Tensor:
+    return t.contiguous() if t.dtype == torch.int32 else t.int().contiguous()
+
+
+def _ptr(t: Optional[Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream(dev: torch.device):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _workspace(nbytes: int, dev: torch.device) -> Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+
+
+# ------------------------------------------------------------------------------------------------
+# ProjectGaussians
+# ------------------------------------------------------------------------------------------------
+class ProjectGaussians(Function):
+    """gsplat.project_gaussians.ProjectGaussians.  apply(means3d, scales, glob_scale, quats,
+    viewmat, projmat, fx, fy, cx, cy, img_height, img_width, tile_bounds, clip_thresh=0.01)
+    -> (xys, depths, radii, conics, num_tiles_hit, cov3d)   [reference call :699-713]"""
+
+    @staticmethod
+    def forward(ctx, means3d: Tensor, scales: Tensor, glob_scale: float, quats: Tensor,
+                viewmat: Tensor, projmat: Tensor, fx: float, fy: float, cx: float, cy: float,
+                img_height: int, img_width: int, tile_bounds: Tuple[int, int, int],
+                clip_thresh: float = CLIP_THRESH_DEFAULT):
+        if means3d.ndim != 2 or means3d.shape[1] != 3:
+            raise ValueError("means3d must have dimensions (N, 3)")
+        n = means3d.shape[0]
+        if tuple(scales.shape) != (n, 3):
+            raise ValueError("scales must have dimensions (N, 3)")
+        if tuple(quats.shape) != (n, 4):
+            raise ValueError("quats must have dimensions (N, 4)")
+        if viewmat.numel() < 12 or projmat.numel() != 16:
+            raise ValueError("viewmat must hold >= 12 and projmat exactly 16 elements")
+        dev = _require_hip(means3d, scales, quats, viewmat, projmat)
+        means3d, scales, quats = _f32(means3d), _f32(scales), _f32(quats)
+        viewmat, projmat = _f32(viewmat), _f32(projmat)
+        lib = _lib.load()
+        cov3d = torch.empty(n, 6, dtype=torch.float32, device=dev)
+        xys = torch.empty(n, 2, dtype=torch.float32, device=dev)
+        depths = torch.empty(n, dtype=torch.float32, device=dev)
+        radii = torch.empty(n, dtype=torch.int32, device=dev)
+        conics = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        num_tiles_hit = torch.empty(n, dtype=torch.int32, device=dev)
+        _lib.check(lib.gg_project_fwd(
+            n, _ptr(means3d), _ptr(scales), float(glob_scale), _ptr(quats), _ptr(viewmat),
+            _ptr(projmat), float(fx), float(fy), float(cx), float(cy), int(img_height),
+            int(img_width), int(tile_bounds[0]), int(tile_bounds[1]), float(clip_thresh),
+            _ptr(cov3d), _ptr(xys), _ptr(depths), _ptr(radii), _ptr(conics), _ptr(num_tiles_hit),
+            _stream(dev)), "gg_project_fwd")
+        ctx.scalars = (float(glob_scale), float(fx), float(fy), float(cx), float(cy),
+                       int(img_height), int(img_width))
+        ctx.save_for_backward(means3d, scales, quats, viewmat, projmat, radii, conics)
+        ctx.mark_non_differentiable(radii, num_tiles_hit)
+        return xys, depths, radii, conics, num_tiles_hit, cov3d
+
+    @staticmethod
+    def backward(ctx, v_xys, v_depths, v_radii, v_conics, v_num_tiles_hit, v_cov3d):
+        means3d, scales, quats, viewmat, projmat, radii, conics = ctx.saved_tensors
+        glob_scale, fx, fy, cx, cy, img_height, img_width = ctx.scalars
+        dev = means3d.device
+        n = means3d.shape[0]
+        v_xys = torch.zeros(n, 2, device=dev) if v_xys is None else _f32(v_xys)
+        v_depths = torch.zeros(n, device=dev) if v_depths is None else _f32(v_depths)
+        v_conics = torch.zeros(n, 3, device=dev) if v_conics is None else _f32(v_conics)
+        v_mean3d = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        v_scale = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        v_quat = torch.empty(n, 4, dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        _lib.check(lib.gg_project_bwd(
+            n, _ptr(means3d), _ptr(scales), glob_scale, _ptr(quats), _ptr(viewmat), _ptr(projmat),
+            fx, fy, cx, cy, img_height, img_width, _ptr(radii), _ptr(conics), _ptr(v_xys),
+            _ptr(v_depths), _ptr(v_conics), _ptr(v_mean3d), _ptr(v_scale), _ptr(v_quat),
+            _stream(dev)), "gg_project_bwd")
+        return (v_mean3d, v_scale, None, v_quat, None, None, None, None, None, None, None, None,
+                None, None)
+
+
+# ------------------------------------------------------------------------------------------------
+# SphericalHarmonics
+# ------------------------------------------------------------------------------------------------
+class SphericalHarmonics(Function):
+    """gsplat.sh.SphericalHarmonics.  apply(degrees_to_use, viewdirs (N,3), coeffs (N,K,3))
+    -> colors (N,3)   [reference call :730]"""
+
+    @staticmethod
+    def forward(ctx, degrees_to_use: int, viewdirs: Tensor, coeffs: Tensor):
+        n, k = coeffs.shape[0], coeffs.shape[-2]
+        assert k >= num_sh_bases(degrees_to_use), "not enough SH bases for degrees_to_use"
+        deg_from_sh(k)  # raises ValueError on an invalid basis count
+        if coeffs.shape[-1] != 3 or tuple(viewdirs.shape) != (n, 3):
+            raise ValueError("viewdirs must be (N, 3) and coeffs (N, K, 3)")
+        dev = _require_hip(viewdirs, coeffs)
+        viewdirs, coeffs = _f32(viewdirs), _f32(coeffs)
+        colors = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        _lib.check(lib.gg_sh_fwd(n, k, int(degrees_to_use), _ptr(viewdirs), _ptr(coeffs),
+                                 _ptr(colors), _stream(dev)), "gg_sh_fwd")
+        ctx.degrees_to_use, ctx.num_bases = int(degrees_to_use), k
+        ctx.save_for_backward(viewdirs)
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors: Tensor):
+        (viewdirs,) = ctx.saved_tensors
+        dev, n = viewdirs.device, viewdirs.shape[0]
+        v_colors = _f32(v_colors)
+        v_coeffs = torch.empty(n, ctx.num_bases, 3, dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        _lib.check(lib.gg_sh_bwd(n, ctx.num_bases, ctx.degrees_to_use, _ptr(viewdirs),
+                                 _ptr(v_colors), _ptr(v_coeffs), _stream(dev)), "gg_sh_bwd")
+        return None, None, v_coeffs
+
+
+# ------------------------------------------------------------------------------------------------
+# binning shared by the rasterize calls of one view
+# ------------------------------------------------------------------------------------------------
+class Binning:
+    """Result of compute_cumulative_intersects + bin_and_sort_gaussians for one view."""
+    __slots__ = ("num_intersects", "gaussian_ids_sorted", "tile_bins", "key", "keep")
+
+    def __init__(self, num_intersects, gaussian_ids_sorted, tile_bins, key, keep):
+        self.num_intersects = num_intersects
+        self.gaussian_ids_sorted = gaussian_ids_sorted
+        self.tile_bins = tile_bins
+        self.key = key
+        self.keep = keep  # the keyed tensors stay alive so data_ptr cannot be recycled
+
+
+_bin_cache: Optional[Binning] = None
+bin_cache_stats = {"hits": 0, "misses": 0}
+
+
+def _bin_key(xys, depths, radii, num_tiles_hit, img_height, img_width):
+    return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in
+                 (xys, depths, radii, num_tiles_hit)) + (int(img_height), int(img_width))
+
+
+def clear_bin_cache() -> None:
+    global _bin_cache
+    _bin_cache = None
+
+
+def bin_and_sort_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, num_tiles_hit: Tensor,
+                           img_height: int, img_width: int, use_cache: bool = True) -> Binning:
+    """Tile lists of one view: Gaussian ids tile-major / near-to-far, and per-tile [start,end).
+    One host sync (the reference's `.item()` on the cumulative count)."""
+    global _bin_cache
+    dev = _require_hip(xys, depths, radii, num_tiles_hit)
+    key = _bin_key(xys, depths, radii, num_tiles_hit, img_height, img_width)
+    if use_cache and _bin_cache is not None and _bin_cache.key == key:
+        bin_cache_stats["hits"] += 1
+        return _bin_cache
+    bin_cache_stats["misses"] += 1
+    lib = _lib.load()
+    n = xys.shape[0]
+    tiles_x = (img_width + BLOCK - 1) // BLOCK
+    tiles_y = (img_height + BLOCK - 1) // BLOCK
+    xys_c, depths_c = _f32(xys.detach()), _f32(depths.detach())
+    radii_c, nth_c = _i32(radii), _i32(num_tiles_hit)
+    total = torch.empty(1, dtype=torch.int64, device=dev)
+    _lib.check(lib.gg_count_intersects(n, _ptr(nth_c), _ptr(total), None, 0, _stream(dev)),
+               "gg_count_intersects")
+    num_intersects = int(total.item())
+    tile_bins = torch.empty(tiles_x * tiles_y, 2, dtype=torch.int32, device=dev)
+    ids_sorted = torch.empty(max(num_intersects, 1), dtype=torch.int32, device=dev)
+    ws_bytes = lib.gg_bin_sort_workspace(n, num_intersects)
+    ws = _workspace(ws_bytes, dev)
+    _lib.check(lib.gg_bin_sort(n, num_intersects, _ptr(xys_c), _ptr(depths_c), _ptr(radii_c),
+                               _ptr(nth_c), tiles_x, tiles_y, _ptr(ids_sorted), _ptr(tile_bins),
+                               None, _ptr(ws), ws.numel(), _stream(dev)), "gg_bin_sort")
+    out = Binning(num_intersects, ids_sorted[:num_intersects], tile_bins, key,
+                  (xys, depths, radii, num_tiles_hit))
+    if use_cache:
+        _bin_cache = out
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Rasterize
+# ------------------------------------------------------------------------------------------------
+def _rasterize_forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, opacity,
+                       img_height, img_width, background, three_channel_only):
+    if colors.dtype == torch.uint8:
+        colors = colors.float() / 255
+    if background is not None:
+        assert background.shape[0] == colors.shape[-1], \
+            f"incorrect shape of background color tensor, expected shape {colors.shape[-1]}"
+    else:
+        background = torch.ones(colors.shape[-1], dtype=torch.float32, device=colors.device)
+    if xys.ndimension() != 2 or xys.size(1) != 2:
+        raise ValueError("xys must have dimensions (N, 2)")
+    if three_channel_only:
+        if colors.ndimension() != 2 or colors.size(1) != 3:
+            raise ValueError("colors must have dimensions (N, 3)")
+    elif colors.ndimension() != 2:
+        raise ValueError("colors must have dimensions (N, D)")
+    if opacity.ndimension() != 2 or opacity.size(1) != 1:
+        raise ValueError("opacity must have dimensions (N, 1)")
+    dev = _require_hip(xys, depths, radii, conics, num_tiles_hit, colors, opacity, background)
+    n, ch = xys.size(0), colors.size(1)
+    img_height, img_width = int(img_height), int(img_width)
+    xys_c, conics_c = _f32(xys), _f32(conics)
+    colors_c, opacity_c, background = _f32(colors), _f32(opacity), _f32(background)
+
+    bins = bin_and_sort_gaussians(xys, depths, radii, num_tiles_hit, img_height, img_width)
+    ctx.num_intersects = bins.num_intersects
+    ctx.img = (img_height, img_width)
+    ctx.opacity_shape = tuple(opacity.shape)
+    if bins.num_intersects < 1:
+        out_img = torch.ones(img_height, img_width, ch, device=dev) * background
+        ctx.save_for_backward(xys_c, conics_c, colors_c, opacity_c)
+        return out_img
+    lib = _lib.load()
+    out_img = torch.empty(img_height, img_width, ch, dtype=torch.float32, device=dev)
+    final_Ts = torch.empty(img_height, img_width, dtype=torch.float32, device=dev)
+    final_idx = torch.empty(img_height, img_width, dtype=torch.int32, device=dev)
+    ws = _workspace(lib.gg_blend_workspace(n), dev)
+    _lib.check(lib.gg_blend_fwd(ch, n, img_height, img_width, _ptr(bins.gaussian_ids_sorted),
+                                _ptr(bins.tile_bins), _ptr(xys_c), _ptr(conics_c), _ptr(colors_c),
+                                _ptr(opacity_c), _ptr(background), _ptr(out_img), _ptr(final_Ts),
+                                _ptr(final_idx), _ptr(ws), ws.numel(), _stream(dev)),
+               "gg_blend_fwd")
+    ctx.save_for_backward(xys_c, conics_c, colors_c, opacity_c, background,
+                          bins.gaussian_ids_sorted, bins.tile_bins, final_Ts, final_idx)
+    return out_img
+
+
+def _rasterize_backward(ctx, v_out_img):
+    img_height, img_width = ctx.img
+    if ctx.num_intersects < 1:
+        xys, conics, colors, opacity = ctx.saved_tensors
+        v_xy, v_conic = torch.zeros_like(xys), torch.zeros_like(conics)
+        v_colors, v_opacity = torch.zeros_like(colors), torch.zeros_like(opacity)
+    else:
+        (xys, conics, colors, opacity, background, ids_sorted, tile_bins, final_Ts,
+         final_idx) = ctx.saved_tensors
+        dev, n, ch = xys.device, xys.shape[0], colors.shape[1]
+        v_out_img = _f32(v_out_img)
+        v_xy = torch.empty(n, 2, dtype=torch.float32, device=dev)
+        v_conic = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        v_colors = torch.empty(n, ch, dtype=torch.float32, device=dev)
+        v_opacity = torch.empty(n, 1, dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        ws = _workspace(lib.gg_blend_workspace(n), dev)
+        _lib.check(lib.gg_blend_bwd(ch, n, img_height, img_width, _ptr(ids_sorted),
+                                    _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(colors),
+                                    _ptr(opacity), _ptr(background), _ptr(final_Ts),
+                                    _ptr(final_idx), _ptr(v_out_img), _ptr(v_xy), _ptr(v_conic),
+                                    _ptr(v_colors), _ptr(v_opacity), _ptr(ws), ws.numel(),
+                                    _stream(dev)), "gg_blend_bwd")
+    return (v_xy, None, None, v_conic, None, v_colors, v_opacity.reshape(ctx.opacity_shape),
+            None, None, None)
+
+
+class RasterizeGaussians(Function):
+    """gsplat.rasterize.RasterizeGaussians (3 colour channels).  apply(xys, depths, radii, conics,
+    num_tiles_hit, colors (N,3), opacity (N,1), img_height, img_width, background=None)
+    -> out_img (H,W,3)   [reference calls :735-746 rgb, :759-770 depth, :773-784 normal]"""
+
+    @staticmethod
+    def forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height,
+                img_width, background=None):
+        return _rasterize_forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, opacity,
+                                  img_height, img_width, background, True)
+
+    @staticmethod
+    def backward(ctx, v_out_img):
+        return _rasterize_backward(ctx, v_out_img)
+
+
+class NDRasterizeGaussians(Function):
+    """gsplat.nd_rasterize.NDRasterizeGaussians (any channel count).  Same signature with
+    colors (N,D) -> out_img (H,W,D)   [reference call :747-758, D = 32 feature channels]"""
+
+    @staticmethod
+    def forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height,
+                img_width, background=None):
+        return _rasterize_forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, opacity,
+                                  img_height, img_width, background, False)
+
+    @staticmethod
+    def backward(ctx, v_out_img):
+        return _rasterize_backward(ctx, v_out_img)
+
+
+# ------------------------------------------------------------------------------------------------
+# quat_to_rotmat (gsplat._torch_impl; reference gaussian_splatting.py:516,614, scripts/update.py:204,229)
+# ------------------------------------------------------------------------------------------------
+def quat_to_rotmat(quat: Tensor) -> Tensor:
+    """Rotation matrices (...,3,3) of wxyz quaternions (normalised first).  Differentiable torch
+    code in the reference's dependency too, so it stays torch here; works on any device."""
+    assert quat.shape[-1] == 4, quat.shape
+    w, x, y, z = torch.unbind(torch.nn.functional.normalize(quat, dim=-1), dim=-1)
+    mat = torch.stack([
+        1 - 2 * (y ** 2 + z ** 2), 2 * (x * y - w * z), 2 * (x * z + w * y),
+        2 * (x * y + w * z), 1 - 2 * (x ** 2 + z ** 2), 2 * (y * z - w * x),
+        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x ** 2 + y ** 2)], dim=-1)
+    return mat.reshape(quat.shape[:-1] + (3, 3))

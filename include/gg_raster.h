@@ -1,0 +1,128 @@
+/*
+ * gg_raster.h — C ABI of libgg_raster.so, the MI355X (gfx950) Gaussian-splatting rasterizer.
+ *
+ * This is the drop-in boundary for GaussianGrasper's feature-field hot path.  The reference
+ * reaches the same functionality through gsplat==0.1.0's private extension module
+ * (`gsplat.cuda._C`, bound with pybind11/torch types); the four autograd.Functions the
+ * reference model calls — nerfstudio/models/gaussian_splatting.py:699 (ProjectGaussians),
+ * :730 (SphericalHarmonics), :735/:759/:773 (RasterizeGaussians), :747 (NDRasterizeGaussians)
+ * — sit directly on top of it.  Each entry point below names the binding it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / PyTorch caching allocator); the library
+ *     never allocates, frees or keeps caller memory; scratch comes in through (ws, ws_bytes)
+ *     whose size the matching *_workspace() query returns;
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); all work is
+ *     enqueued asynchronously, nothing synchronises the host;
+ *   - layouts are torch's: row-major array-of-structs, fp32, ids int32;
+ *   - return 0 on success; negative on error (GG_ERR_*), message via gg_last_error().
+ *
+ * Arithmetic contract: SURVEY.md §8a rows a3-a12 with the constants of gg_constants.h;
+ * the forward results (radii, tile counts, depth order, tile lists, images, final_T, final_idx)
+ * are bit-identical to the CPU oracle (oracle/gg_oracle.c), gradients agree to fp32 summation
+ * order.
+ */
+#ifndef GG_RASTER_H
+#define GG_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GG_OK 0
+#define GG_ERR_INVALID_ARG (-1)
+#define GG_ERR_LAUNCH (-2)
+#define GG_ERR_WORKSPACE (-3)
+#define GG_ERR_UNSUPPORTED (-4)
+
+typedef void *gg_stream_t; /* hipStream_t */
+
+/* ABI version of this header (bumped on any signature change). */
+int gg_abi_version(void);
+/* Message for the last error returned on the calling thread ("" if none). */
+const char *gg_last_error(void);
+
+/* ---- projection ------------------------------------------------------------------------
+ * Replaces gsplat `_C.project_gaussians_forward` (ProjectGaussians.forward; reference call
+ * gaussian_splatting.py:699-713).  viewmat: >=12 floats row-major (the caller's viewmat[:3,:]);
+ * projmat: 16 floats (projmat @ viewmat).  All six outputs are fully written (zeros for culled
+ * Gaussians as the oracle documents), so they may be uninitialised on entry. */
+int gg_project_fwd(int num_points, const float *means3d, const float *scales, float glob_scale,
+                   const float *quats, const float *viewmat, const float *projmat, float fx,
+                   float fy, float cx, float cy, int img_height, int img_width, int tiles_x,
+                   int tiles_y, float clip_thresh, float *cov3d, float *xys, float *depths,
+                   int32_t *radii, float *conics, int32_t *num_tiles_hit, gg_stream_t stream);
+
+/* Replaces gsplat `_C.project_gaussians_backward` (ProjectGaussians.backward).  v_conic uses
+ * gsplat's symmetric-matrix convention (v_conic[:,1] is half of dL/d conic.y).  Outputs fully
+ * written (zeros where radii<=0). */
+int gg_project_bwd(int num_points, const float *means3d, const float *scales, float glob_scale,
+                   const float *quats, const float *viewmat, const float *projmat, float fx,
+                   float fy, float cx, float cy, int img_height, int img_width,
+                   const int32_t *radii, const float *conics, const float *v_xy,
+                   const float *v_depth, const float *v_conic, float *v_mean3d, float *v_scale,
+                   float *v_quat, gg_stream_t stream);
+
+/* ---- spherical harmonics -----------------------------------------------------------------
+ * Replace gsplat `_C.compute_sh_forward` / `_C.compute_sh_backward` (SphericalHarmonics;
+ * reference call gaussian_splatting.py:730).  coeffs (N, num_bases, 3); num_bases in
+ * {1,4,9,16,25}; degrees_to_use <= degree(num_bases). */
+int gg_sh_fwd(int num_points, int num_bases, int degrees_to_use, const float *viewdirs,
+              const float *coeffs, float *colors, gg_stream_t stream);
+int gg_sh_bwd(int num_points, int num_bases, int degrees_to_use, const float *viewdirs,
+              const float *v_colors, float *v_coeffs, gg_stream_t stream);
+
+/* ---- binning -------------------------------------------------------------------------------
+ * Together replace gsplat `compute_cumulative_intersects` + `bin_and_sort_gaussians`
+ * (`_C.map_gaussian_to_intersects`, torch.sort, `_C.get_tile_bin_edges`) that every
+ * Rasterize*.forward runs (gaussian_splatting.py:735,747,759,773).
+ *
+ * gg_count_intersects: *num_intersects_out (device int64) = sum(num_tiles_hit). */
+size_t gg_count_workspace(int num_points);
+int gg_count_intersects(int num_points, const int32_t *num_tiles_hit,
+                        int64_t *num_intersects_out, void *ws, size_t ws_bytes,
+                        gg_stream_t stream);
+
+/* gg_bin_sort: given I = sum(num_tiles_hit) (read back by the caller), writes
+ *   gaussian_ids_sorted (I,)  — Gaussian ids, tile-major, near-to-far, ties by ascending id:
+ *                               exactly the order of the reference's sorted int64 keys
+ *                               (tile_id << 32 | depth bits);
+ *   tile_bins (tiles_x*tiles_y, 2) — [start,end) of each tile in that list, (0,0) if empty;
+ *   isect_tile_sorted (I,) optional (may be NULL) — the tile id of every sorted entry. */
+size_t gg_bin_sort_workspace(int num_points, int64_t num_intersects);
+int gg_bin_sort(int num_points, int64_t num_intersects, const float *xys, const float *depths,
+                const int32_t *radii, const int32_t *num_tiles_hit, int tiles_x, int tiles_y,
+                int32_t *gaussian_ids_sorted, int32_t *tile_bins, int32_t *isect_tile_sorted,
+                void *ws, size_t ws_bytes, gg_stream_t stream);
+
+/* ---- alpha blending ----------------------------------------------------------------------
+ * gg_blend_fwd replaces gsplat `_C.rasterize_forward` (C=3) and `_C.nd_rasterize_forward`
+ * (any C >= 1).  colors (N,C), opacity (N,) or (N,1), background (C,), out_img (H,W,C),
+ * final_Ts (H,W), final_idx (H,W).  ws: gg_blend_workspace(num_points) bytes. */
+size_t gg_blend_workspace(int num_points);
+int gg_blend_fwd(int channels, int num_points, int img_height, int img_width,
+                 const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+                 const float *conics, const float *colors, const float *opacity,
+                 const float *background, float *out_img, float *final_Ts, int32_t *final_idx,
+                 void *ws, size_t ws_bytes, gg_stream_t stream);
+
+/* gg_blend_bwd replaces gsplat `_C.rasterize_backward` / `_C.nd_rasterize_backward`.
+ * v_xy (N,2), v_conic (N,3), v_colors (N,C), v_opacity (N,) are fully written. */
+int gg_blend_bwd(int channels, int num_points, int img_height, int img_width,
+                 const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+                 const float *conics, const float *colors, const float *opacity,
+                 const float *background, const float *final_Ts, const int32_t *final_idx,
+                 const float *v_out_img, float *v_xy, float *v_conic, float *v_colors,
+                 float *v_opacity, void *ws, size_t ws_bytes, gg_stream_t stream);
+
+/* y[i] = gg_expf(x[i]) on the device — lets the tests pin the GPU exponential bit-for-bit
+ * against the oracle's (gg_constants.h documents the operation sequence). */
+int gg_expf_array(int n, const float *x, float *y, gg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GG_RASTER_H */

@@ -1,0 +1,700 @@
+/*
+ * gg_oracle.c — CPU ORACLE for the Gaussian-splatting hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (gaussiangrasper_amd/, shim/gsplat) never imports, links or
+ * executes anything under oracle/.
+ *
+ * PARITY UNPINNED.  The arithmetic restated here lives in the reference's un-vendored
+ * third-party dependency gsplat==0.1.0 (reference requirements.txt:78); its source is not
+ * under /root/reference and is not installable offline, and the reference holds no golden
+ * vector, known-answer test or fixture for this path.  What IS exact is
+ * the call-site contract: nerfstudio/models/gaussian_splatting.py:699-713 (ProjectGaussians),
+ * :730 (SphericalHarmonics), :735-784 (Rasterize / NDRasterize), :87-105 (projection_matrix).
+ * Each function below names the gsplat-0.1.0 routine it restates (recollection of the public
+ * source) and the reference call site that reaches it.  Every
+ * uncertain constant comes from include/gg_constants.h.
+ *
+ * Numerics: one source, two builds.
+ *   libgg_oracle_f32.so  REAL=float   -ffp-contract=off : the parity oracle.  Every fp32
+ *       operation is written out in a fixed order (explicit fmaf where a fused op is meant),
+ *       so a GPU kernel that follows the same order reproduces radii, tile counts, depth
+ *       bits, sort keys and the forward image bit for bit.
+ *   libgg_oracle_f64.so  REAL=double : same formulas in fp64, used only for
+ *       finite-difference checks of the analytic backward passes.
+ *
+ * Layouts are torch's: row-major, array-of-structs; (N,3) means, (N,4) quats wxyz,
+ * (N,K,3) SH coefficients, (N,C) colours, (H,W,C) images, (T,2) tile bins.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/gg_constants.h"
+
+#ifdef GGO_F64
+typedef double REAL;
+#define R_(x) ((double)(x))
+#define FMA(a, b, c) fma((a), (b), (c))
+#define SQRT(x) sqrt(x)
+#define CEIL(x) ceil(x)
+#define FMIN(a, b) fmin((a), (b))
+#define FMAX(a, b) fmax((a), (b))
+#define NAME(x) ggo64_##x
+#else
+typedef float REAL;
+#define R_(x) (x)
+#define FMA(a, b, c) fmaf((a), (b), (c))
+#define SQRT(x) sqrtf(x)
+#define CEIL(x) ceilf(x)
+#define FMIN(a, b) fminf((a), (b))
+#define FMAX(a, b) fmaxf((a), (b))
+#define NAME(x) ggo_##x
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * gg_expf — stands in for CUDA's __expf(-sigma) in gsplat's rasterize_forward/backward.
+ * Operation sequence fixed in include/gg_constants.h (the HIP kernels follow the same one).
+ * ---------------------------------------------------------------------------------------- */
+static inline REAL gg_exp(REAL x) {
+#ifdef GGO_F64
+    return exp(x);
+#else
+    if (x < GG_EXP_LO) return 0.0f;
+    float t = x * GG_EXP_LOG2E;
+    float n = rintf(t);
+    float r = fmaf(n, -GG_EXP_LN2_HI, x);
+    r = fmaf(n, -GG_EXP_LN2_LO, r);
+    float p = GG_EXP_P0;
+    p = fmaf(p, r, GG_EXP_P1);
+    p = fmaf(p, r, GG_EXP_P2);
+    p = fmaf(p, r, GG_EXP_P3);
+    p = fmaf(p, r, GG_EXP_P4);
+    p = fmaf(p, r, GG_EXP_P5);
+    float z = r * r;
+    float y = fmaf(p, z, r);
+    y = y + 1.0f;
+    union {
+        uint32_t u;
+        float f;
+    } s;
+    s.u = (uint32_t)((int32_t)n + 127) << 23;
+    return y * s.f;
+#endif
+}
+
+/* exported for the tests that pin gg_expf against libm and against the GPU */
+void NAME(expf_array)(int n, const REAL *x, REAL *y) {
+    for (int i = 0; i < n; ++i) y[i] = gg_exp(x[i]);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Tile bounding box — gsplat helpers.cuh get_tile_bbox/get_bbox (†):
+ *   tile_min = clamp((int)(c/16 - r/16), 0, bound), tile_max = clamp((int)(c/16 + r/16 + 1), 0, bound).
+ * The clamp is applied in the float domain before the conversion: identical for every finite
+ * input ((int) truncates toward zero and everything below 0 clamps to 0) and defined for huge
+ * or NaN centres, where the C cast is not.
+ * ---------------------------------------------------------------------------------------- */
+static inline int clampi_f(REAL v, int bound) {
+    REAL c = FMIN(FMAX(v, R_(0.0f)), (REAL)bound);
+    return (int)c;
+}
+static inline void tile_bbox(REAL cx, REAL cy, REAL radius, int tiles_x, int tiles_y, int *x0,
+                             int *y0, int *x1, int *y1) {
+    REAL tcx = cx / (REAL)GG_BLOCK, tcy = cy / (REAL)GG_BLOCK;
+    REAL tr = radius / (REAL)GG_BLOCK;
+    *x0 = clampi_f(tcx - tr, tiles_x);
+    *x1 = clampi_f((tcx + tr) + R_(1.0f), tiles_x);
+    *y0 = clampi_f(tcy - tr, tiles_y);
+    *y1 = clampi_f((tcy + tr) + R_(1.0f), tiles_y);
+}
+
+/* rotation matrix of the NORMALISED quaternion (w,x,y,z), row-major — gsplat helpers.cuh
+ * quat_to_rotmat (†; it normalises with rsqrtf, here 1/sqrt, both IEEE-exact on our side) */
+static inline void quat_to_R(const REAL *q, REAL *R, REAL *qn, REAL *inv_norm) {
+    REAL nn = ((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3];
+    REAL inv = R_(1.0f) / SQRT(nn);
+    REAL w = q[0] * inv, x = q[1] * inv, y = q[2] * inv, z = q[3] * inv;
+    R[0] = R_(1.0f) - R_(2.0f) * (y * y + z * z);
+    R[1] = R_(2.0f) * (x * y - w * z);
+    R[2] = R_(2.0f) * (x * z + w * y);
+    R[3] = R_(2.0f) * (x * y + w * z);
+    R[4] = R_(1.0f) - R_(2.0f) * (x * x + z * z);
+    R[5] = R_(2.0f) * (y * z - w * x);
+    R[6] = R_(2.0f) * (x * z - w * y);
+    R[7] = R_(2.0f) * (y * z + w * x);
+    R[8] = R_(1.0f) - R_(2.0f) * (x * x + y * y);
+    if (qn) {
+        qn[0] = w;
+        qn[1] = x;
+        qn[2] = y;
+        qn[3] = z;
+    }
+    if (inv_norm) *inv_norm = inv;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * project_fwd — restates gsplat forward.cu project_gaussians_forward_kernel (†) as reached by
+ * ProjectGaussians.apply at nerfstudio/models/gaussian_splatting.py:699-713.
+ * viewmat: row-major, first 12 floats used (the caller passes viewmat[:3,:]); projmat: 4x4
+ * (projmat @ viewmat).  Outputs are zero for culled Gaussians except cov3d/conics, which the
+ * kernel writes before the later culls (cov3d after the near-plane test, conics after det!=0).
+ * ---------------------------------------------------------------------------------------- */
+void NAME(project_fwd)(int N, const REAL *means, const REAL *scales, REAL glob_scale,
+                       const REAL *quats, const REAL *viewmat, const REAL *projmat, REAL fx,
+                       REAL fy, REAL cx, REAL cy, int img_h, int img_w, int tiles_x, int tiles_y,
+                       REAL clip_thresh, REAL *cov3d, REAL *xys, REAL *depths, int32_t *radii,
+                       REAL *conics, int32_t *num_tiles_hit) {
+    const REAL *V = viewmat, *P = projmat;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) {
+        radii[i] = 0;
+        num_tiles_hit[i] = 0;
+        depths[i] = 0;
+        xys[2 * i] = xys[2 * i + 1] = 0;
+        conics[3 * i] = conics[3 * i + 1] = conics[3 * i + 2] = 0;
+        for (int k = 0; k < 6; ++k) cov3d[6 * i + k] = 0;
+
+        REAL px = means[3 * i], py = means[3 * i + 1], pz = means[3 * i + 2];
+        /* clip_near_plane / transform_4x3 */
+        REAL tx = ((V[0] * px + V[1] * py) + V[2] * pz) + V[3];
+        REAL ty = ((V[4] * px + V[5] * py) + V[6] * pz) + V[7];
+        REAL tz = ((V[8] * px + V[9] * py) + V[10] * pz) + V[11];
+        if (tz <= clip_thresh) continue;
+
+        /* scale_rot_to_cov3d: M = R * diag(glob*s), cov3d = M M^T (upper triangle) */
+        REAL R[9];
+        quat_to_R(quats + 4 * i, R, 0, 0);
+        REAL s0 = glob_scale * scales[3 * i], s1 = glob_scale * scales[3 * i + 1],
+             s2 = glob_scale * scales[3 * i + 2];
+        REAL M[9] = {R[0] * s0, R[1] * s1, R[2] * s2, R[3] * s0, R[4] * s1,
+                     R[5] * s2, R[6] * s0, R[7] * s1, R[8] * s2};
+        REAL c3[6];
+        c3[0] = (M[0] * M[0] + M[1] * M[1]) + M[2] * M[2];
+        c3[1] = (M[0] * M[3] + M[1] * M[4]) + M[2] * M[5];
+        c3[2] = (M[0] * M[6] + M[1] * M[7]) + M[2] * M[8];
+        c3[3] = (M[3] * M[3] + M[4] * M[4]) + M[5] * M[5];
+        c3[4] = (M[3] * M[6] + M[4] * M[7]) + M[5] * M[8];
+        c3[5] = (M[6] * M[6] + M[7] * M[7]) + M[8] * M[8];
+        for (int k = 0; k < 6; ++k) cov3d[6 * i + k] = c3[k];
+
+        /* project_cov3d_ewa */
+        REAL tan_fovx = (R_(0.5f) * (REAL)img_w) / fx;
+        REAL tan_fovy = (R_(0.5f) * (REAL)img_h) / fy;
+        REAL lim_x = R_(GG_FOV_LIM) * tan_fovx, lim_y = R_(GG_FOV_LIM) * tan_fovy;
+        REAL txc = tz * FMIN(lim_x, FMAX(-lim_x, tx / tz));
+        REAL tyc = tz * FMIN(lim_y, FMAX(-lim_y, ty / tz));
+        REAL rz = R_(1.0f) / tz;
+        REAL rz2 = rz * rz;
+        REAL J00 = fx * rz, J02 = (-(fx * txc)) * rz2;
+        REAL J11 = fy * rz, J12 = (-(fy * tyc)) * rz2;
+        /* T = J * W, W = viewmat[:3,:3] */
+        REAL T00 = J00 * V[0] + J02 * V[8], T01 = J00 * V[1] + J02 * V[9],
+             T02 = J00 * V[2] + J02 * V[10];
+        REAL T10 = J11 * V[4] + J12 * V[8], T11 = J11 * V[5] + J12 * V[9],
+             T12 = J11 * V[6] + J12 * V[10];
+        /* TV = T * cov3d (2x3) */
+        REAL A00 = (T00 * c3[0] + T01 * c3[1]) + T02 * c3[2];
+        REAL A01 = (T00 * c3[1] + T01 * c3[3]) + T02 * c3[4];
+        REAL A02 = (T00 * c3[2] + T01 * c3[4]) + T02 * c3[5];
+        REAL A10 = (T10 * c3[0] + T11 * c3[1]) + T12 * c3[2];
+        REAL A11 = (T10 * c3[1] + T11 * c3[3]) + T12 * c3[4];
+        REAL A12 = (T10 * c3[2] + T11 * c3[4]) + T12 * c3[5];
+        REAL a = ((A00 * T00 + A01 * T01) + A02 * T02) + R_(GG_BLUR);
+        REAL b = (A00 * T10 + A01 * T11) + A02 * T12;
+        REAL c = ((A10 * T10 + A11 * T11) + A12 * T12) + R_(GG_BLUR);
+
+        /* compute_cov2d_bounds */
+        REAL det = a * c - b * b;
+        if (det == R_(0.0f)) continue;
+        REAL inv_det = R_(1.0f) / det;
+        conics[3 * i] = c * inv_det;
+        conics[3 * i + 1] = (-b) * inv_det;
+        conics[3 * i + 2] = a * inv_det;
+        REAL bm = R_(0.5f) * (a + c);
+        REAL sq = SQRT(FMAX(R_(GG_EIG_FLOOR), bm * bm - det));
+        REAL v1 = bm + sq, v2 = bm - sq;
+        REAL radius = CEIL(R_(GG_RADIUS_SIGMA) * SQRT(FMAX(v1, v2)));
+
+        /* project_pix / ndc2pix */
+        REAL hx = ((P[0] * px + P[1] * py) + P[2] * pz) + P[3];
+        REAL hy = ((P[4] * px + P[5] * py) + P[6] * pz) + P[7];
+        REAL hw = ((P[12] * px + P[13] * py) + P[14] * pz) + P[15];
+        REAL rw = R_(1.0f) / (hw + R_(GG_W_EPS));
+        REAL ndx = hx * rw, ndy = hy * rw;
+        REAL ux = ((R_(0.5f) * (REAL)img_w) * ndx + cx) - R_(GG_PIX_OFFSET);
+        REAL uy = ((R_(0.5f) * (REAL)img_h) * ndy + cy) - R_(GG_PIX_OFFSET);
+
+        int x0, y0, x1, y1;
+        tile_bbox(ux, uy, radius, tiles_x, tiles_y, &x0, &y0, &x1, &y1);
+        int area = (x1 - x0) * (y1 - y0);
+        if (area <= 0) continue;
+        num_tiles_hit[i] = area;
+        depths[i] = tz;
+        radii[i] = (int32_t)radius;
+        xys[2 * i] = ux;
+        xys[2 * i + 1] = uy;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * project_bwd — VJP of project_fwd w.r.t. means, scales, quats (autograd of
+ * gaussian_splatting.py:699; gsplat backward.cu project_gaussians_backward_kernel †).
+ * v_conic follows gsplat's convention: it is the gradient of the symmetric 2x2 conic MATRIX,
+ * i.e. v_conic[1] is HALF of dL/d(conic.y) (rasterize_backward emits it that way, a11).
+ * Gaussians with radii<=0 receive zero gradients.  This is the exact VJP of the forward as
+ * written above (including the homogeneous-w path of the pixel projection and the FOV clamp
+ * in the EWA Jacobian); PARITY.md lists where gsplat 0.1.0 is recalled to approximate.
+ * ---------------------------------------------------------------------------------------- */
+void NAME(project_bwd)(int N, const REAL *means, const REAL *scales, REAL glob_scale,
+                       const REAL *quats, const REAL *viewmat, const REAL *projmat, REAL fx,
+                       REAL fy, REAL cx, REAL cy, int img_h, int img_w, const int32_t *radii,
+                       const REAL *conics, const REAL *v_xy, const REAL *v_depth,
+                       const REAL *v_conic, REAL *v_mean3d, REAL *v_scale, REAL *v_quat) {
+    (void)cx;
+    (void)cy;
+    const REAL *V = viewmat, *P = projmat;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) {
+        for (int k = 0; k < 3; ++k) v_mean3d[3 * i + k] = 0, v_scale[3 * i + k] = 0;
+        for (int k = 0; k < 4; ++k) v_quat[4 * i + k] = 0;
+        if (radii[i] <= 0) continue;
+        REAL px = means[3 * i], py = means[3 * i + 1], pz = means[3 * i + 2];
+        REAL vm[3] = {0, 0, 0};
+
+        /* (1) pixel centre */
+        REAL hx = ((P[0] * px + P[1] * py) + P[2] * pz) + P[3];
+        REAL hy = ((P[4] * px + P[5] * py) + P[6] * pz) + P[7];
+        REAL hw = ((P[12] * px + P[13] * py) + P[14] * pz) + P[15];
+        REAL rw = R_(1.0f) / (hw + R_(GG_W_EPS));
+        REAL vnx = (R_(0.5f) * (REAL)img_w) * v_xy[2 * i];
+        REAL vny = (R_(0.5f) * (REAL)img_h) * v_xy[2 * i + 1];
+        REAL vhx = vnx * rw, vhy = vny * rw;
+        REAL vhw = -((vnx * hx + vny * hy) * (rw * rw));
+        for (int j = 0; j < 3; ++j) vm[j] += (P[j] * vhx + P[4 + j] * vhy) + P[12 + j] * vhw;
+
+        /* (2) depth = row 2 of viewmat */
+        REAL vz = v_depth[i];
+        for (int j = 0; j < 3; ++j) vm[j] += V[8 + j] * vz;
+
+        /* (3) conic -> cov2d : v_Sigma = -X G X */
+        REAL ca = conics[3 * i], cb = conics[3 * i + 1], cc = conics[3 * i + 2];
+        REAL ga = v_conic[3 * i], gb = v_conic[3 * i + 1], gc = v_conic[3 * i + 2];
+        /* XG */
+        REAL xg00 = ca * ga + cb * gb, xg01 = ca * gb + cb * gc;
+        REAL xg10 = cb * ga + cc * gb, xg11 = cb * gb + cc * gc;
+        REAL s00 = -(xg00 * ca + xg01 * cb), s01 = -(xg00 * cb + xg01 * cc);
+        REAL s10 = -(xg10 * ca + xg11 * cb), s11 = -(xg10 * cb + xg11 * cc);
+        REAL v_a = s00, v_b = s01 + s10, v_c = s11;
+
+        /* recompute forward intermediates */
+        REAL tx = ((V[0] * px + V[1] * py) + V[2] * pz) + V[3];
+        REAL ty = ((V[4] * px + V[5] * py) + V[6] * pz) + V[7];
+        REAL tz = ((V[8] * px + V[9] * py) + V[10] * pz) + V[11];
+        REAL R[9], qn[4], inv_norm;
+        quat_to_R(quats + 4 * i, R, qn, &inv_norm);
+        REAL s[3] = {glob_scale * scales[3 * i], glob_scale * scales[3 * i + 1],
+                     glob_scale * scales[3 * i + 2]};
+        REAL M[9];
+        for (int r = 0; r < 3; ++r)
+            for (int k = 0; k < 3; ++k) M[3 * r + k] = R[3 * r + k] * s[k];
+        REAL C3[9]; /* full symmetric cov3d */
+        for (int r = 0; r < 3; ++r)
+            for (int k = 0; k < 3; ++k)
+                C3[3 * r + k] = (M[3 * r] * M[3 * k] + M[3 * r + 1] * M[3 * k + 1]) +
+                                M[3 * r + 2] * M[3 * k + 2];
+        REAL tan_fovx = (R_(0.5f) * (REAL)img_w) / fx, tan_fovy = (R_(0.5f) * (REAL)img_h) / fy;
+        REAL lim_x = R_(GG_FOV_LIM) * tan_fovx, lim_y = R_(GG_FOV_LIM) * tan_fovy;
+        REAL rx = tx / tz, ry = ty / tz;
+        int clx = (rx > lim_x) ? 1 : ((rx < -lim_x) ? -1 : 0);
+        int cly = (ry > lim_y) ? 1 : ((ry < -lim_y) ? -1 : 0);
+        REAL txc = tz * FMIN(lim_x, FMAX(-lim_x, rx));
+        REAL tyc = tz * FMIN(lim_y, FMAX(-lim_y, ry));
+        REAL rz = R_(1.0f) / tz, rz2 = rz * rz, rz3 = rz2 * rz;
+        REAL J00 = fx * rz, J02 = (-(fx * txc)) * rz2, J11 = fy * rz, J12 = (-(fy * tyc)) * rz2;
+        REAL Tm[6] = {J00 * V[0] + J02 * V[8], J00 * V[1] + J02 * V[9], J00 * V[2] + J02 * V[10],
+                      J11 * V[4] + J12 * V[8], J11 * V[5] + J12 * V[9], J11 * V[6] + J12 * V[10]};
+
+        /* (4) cov2d = Tm C3 Tm^T ; Gc = [[v_a, v_b/2],[v_b/2, v_c]] */
+        REAL g00 = v_a, g01 = R_(0.5f) * v_b, g11 = v_c;
+        /* GT = Gc * Tm (2x3) */
+        REAL GT[6];
+        for (int k = 0; k < 3; ++k) {
+            GT[k] = g00 * Tm[k] + g01 * Tm[3 + k];
+            GT[3 + k] = g01 * Tm[k] + g11 * Tm[3 + k];
+        }
+        /* entrywise v_C3 = Tm^T Gc Tm (3x3, symmetric) */
+        REAL G3[9];
+        for (int r = 0; r < 3; ++r)
+            for (int k = 0; k < 3; ++k) G3[3 * r + k] = Tm[r] * GT[k] + Tm[3 + r] * GT[3 + k];
+        /* v_Tm = 2 * Gc Tm C3 */
+        REAL vT[6];
+        for (int r = 0; r < 2; ++r)
+            for (int k = 0; k < 3; ++k)
+                vT[3 * r + k] = R_(2.0f) * ((GT[3 * r] * C3[k] + GT[3 * r + 1] * C3[3 + k]) +
+                                            GT[3 * r + 2] * C3[6 + k]);
+        /* (5) v_J = v_Tm W^T ; only J00,J02,J11,J12 are live */
+        REAL vJ00 = (vT[0] * V[0] + vT[1] * V[1]) + vT[2] * V[2];
+        REAL vJ02 = (vT[0] * V[8] + vT[1] * V[9]) + vT[2] * V[10];
+        REAL vJ11 = (vT[3] * V[4] + vT[4] * V[5]) + vT[5] * V[6];
+        REAL vJ12 = (vT[3] * V[8] + vT[4] * V[9]) + vT[5] * V[10];
+        REAL v_txc = (-(fx * rz2)) * vJ02;
+        REAL v_tyc = (-(fy * rz2)) * vJ12;
+        REAL v_tz = ((-(fx * rz2)) * vJ00 - (fy * rz2) * vJ11) +
+                    (R_(2.0f) * fx * txc * rz3) * vJ02 + (R_(2.0f) * fy * tyc * rz3) * vJ12;
+        REAL v_tx, v_ty;
+        if (clx) {
+            v_tz += ((REAL)clx * lim_x) * v_txc;
+            v_tx = 0;
+        } else
+            v_tx = v_txc;
+        if (cly) {
+            v_tz += ((REAL)cly * lim_y) * v_tyc;
+            v_ty = 0;
+        } else
+            v_ty = v_tyc;
+        for (int j = 0; j < 3; ++j) vm[j] += (V[j] * v_tx + V[4 + j] * v_ty) + V[8 + j] * v_tz;
+        for (int j = 0; j < 3; ++j) v_mean3d[3 * i + j] = vm[j];
+
+        /* (6) cov3d = M M^T -> v_M = 2 G3 M ; M = R diag(s) */
+        REAL vM[9];
+        for (int r = 0; r < 3; ++r)
+            for (int k = 0; k < 3; ++k)
+                vM[3 * r + k] = R_(2.0f) * ((G3[3 * r] * M[k] + G3[3 * r + 1] * M[3 + k]) +
+                                            G3[3 * r + 2] * M[6 + k]);
+        for (int k = 0; k < 3; ++k)
+            v_scale[3 * i + k] =
+                glob_scale * ((R[k] * vM[k] + R[3 + k] * vM[3 + k]) + R[6 + k] * vM[6 + k]);
+        REAL G[9];
+        for (int r = 0; r < 3; ++r)
+            for (int k = 0; k < 3; ++k) G[3 * r + k] = vM[3 * r + k] * s[k];
+        REAL w = qn[0], x = qn[1], y = qn[2], z = qn[3];
+        REAL vq[4];
+        vq[0] = R_(2.0f) * ((x * (G[7] - G[5]) + y * (G[2] - G[6])) + z * (G[3] - G[1]));
+        vq[1] = R_(2.0f) * (((R_(-2.0f) * x) * (G[4] + G[8]) + y * (G[1] + G[3])) +
+                            (z * (G[2] + G[6]) + w * (G[7] - G[5])));
+        vq[2] = R_(2.0f) * ((x * (G[1] + G[3]) + (R_(-2.0f) * y) * (G[0] + G[8])) +
+                            (z * (G[5] + G[7]) + w * (G[2] - G[6])));
+        vq[3] = R_(2.0f) * ((x * (G[2] + G[6]) + y * (G[5] + G[7])) +
+                            ((R_(-2.0f) * z) * (G[0] + G[4]) + w * (G[3] - G[1])));
+        /* through q/|q| */
+        REAL dotp = ((qn[0] * vq[0] + qn[1] * vq[1]) + qn[2] * vq[2]) + qn[3] * vq[3];
+        for (int k = 0; k < 4; ++k) v_quat[4 * i + k] = (vq[k] - qn[k] * dotp) * inv_norm;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Spherical harmonics — gsplat sh.cuh sh_coeffs_to_color / compute_sh_forward_kernel (†),
+ * SphericalHarmonics.apply at gaussian_splatting.py:730.  K bases stored per Gaussian
+ * ((N,K,3)); `degrees_to_use` = active degree n (:729).  The kernel re-normalises viewdirs.
+ * ---------------------------------------------------------------------------------------- */
+static inline void sh_basis(int deg, REAL dx, REAL dy, REAL dz, REAL *Y) {
+    Y[0] = R_(GG_SH_C0);
+    if (deg < 1) return;
+    REAL norm = SQRT((dx * dx + dy * dy) + dz * dz);
+    REAL x = dx / norm, y = dy / norm, z = dz / norm;
+    Y[1] = R_(GG_SH_C1) * (-y);
+    Y[2] = R_(GG_SH_C1) * z;
+    Y[3] = R_(GG_SH_C1) * (-x);
+    if (deg < 2) return;
+    REAL xx = x * x, xy = x * y, xz = x * z, yy = y * y, yz = y * z, zz = z * z;
+    Y[4] = R_(GG_SH_C2_0) * xy;
+    Y[5] = R_(GG_SH_C2_1) * yz;
+    Y[6] = R_(GG_SH_C2_2) * ((R_(2.0f) * zz - xx) - yy);
+    Y[7] = R_(GG_SH_C2_3) * xz;
+    Y[8] = R_(GG_SH_C2_4) * (xx - yy);
+    if (deg < 3) return;
+    Y[9] = (R_(GG_SH_C3_0) * y) * (R_(3.0f) * xx - yy);
+    Y[10] = (R_(GG_SH_C3_1) * xy) * z;
+    Y[11] = (R_(GG_SH_C3_2) * y) * ((R_(4.0f) * zz - xx) - yy);
+    Y[12] = (R_(GG_SH_C3_3) * z) * ((R_(2.0f) * zz - R_(3.0f) * xx) - R_(3.0f) * yy);
+    Y[13] = (R_(GG_SH_C3_4) * x) * ((R_(4.0f) * zz - xx) - yy);
+    Y[14] = (R_(GG_SH_C3_5) * z) * (xx - yy);
+    Y[15] = (R_(GG_SH_C3_6) * x) * (xx - R_(3.0f) * yy);
+    if (deg < 4) return;
+    Y[16] = (R_(GG_SH_C4_0) * xy) * (xx - yy);
+    Y[17] = (R_(GG_SH_C4_1) * yz) * (R_(3.0f) * xx - yy);
+    Y[18] = (R_(GG_SH_C4_2) * xy) * (R_(7.0f) * zz - R_(1.0f));
+    Y[19] = (R_(GG_SH_C4_3) * yz) * (R_(7.0f) * zz - R_(3.0f));
+    Y[20] = R_(GG_SH_C4_4) * (zz * (R_(35.0f) * zz - R_(30.0f)) + R_(3.0f));
+    Y[21] = (R_(GG_SH_C4_5) * xz) * (R_(7.0f) * zz - R_(3.0f));
+    Y[22] = (R_(GG_SH_C4_6) * (xx - yy)) * (R_(7.0f) * zz - R_(1.0f));
+    Y[23] = (R_(GG_SH_C4_7) * xz) * (xx - R_(3.0f) * yy);
+    Y[24] = R_(GG_SH_C4_8) * (xx * (xx - R_(3.0f) * yy) - yy * (R_(3.0f) * xx - yy));
+}
+static inline int sh_nbases(int deg) { return deg >= 4 ? 25 : (deg + 1) * (deg + 1); }
+
+void NAME(sh_fwd)(int N, int K, int degrees_to_use, const REAL *viewdirs, const REAL *coeffs,
+                  REAL *colors) {
+    int nb = sh_nbases(degrees_to_use);
+    if (nb > K) nb = K;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) {
+        REAL Y[GG_SH_MAX_BASES];
+        sh_basis(degrees_to_use, viewdirs[3 * i], viewdirs[3 * i + 1], viewdirs[3 * i + 2], Y);
+        const REAL *cf = coeffs + (size_t)i * K * 3;
+        for (int c = 0; c < 3; ++c) {
+            REAL acc = Y[0] * cf[c];
+            for (int k = 1; k < nb; ++k) acc = FMA(Y[k], cf[3 * k + c], acc);
+            colors[3 * i + c] = acc;
+        }
+    }
+}
+/* compute_sh_backward_kernel (†): gradient to coefficients only (viewdirs are detached by the
+ * caller, gaussian_splatting.py:727); inactive bases get zero. */
+void NAME(sh_bwd)(int N, int K, int degrees_to_use, const REAL *viewdirs, const REAL *v_colors,
+                  REAL *v_coeffs) {
+    int nb = sh_nbases(degrees_to_use);
+    if (nb > K) nb = K;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) {
+        REAL Y[GG_SH_MAX_BASES];
+        sh_basis(degrees_to_use, viewdirs[3 * i], viewdirs[3 * i + 1], viewdirs[3 * i + 2], Y);
+        REAL *vc = v_coeffs + (size_t)i * K * 3;
+        for (int k = 0; k < K; ++k)
+            for (int c = 0; c < 3; ++c) vc[3 * k + c] = (k < nb) ? Y[k] * v_colors[3 * i + c] : 0;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Binning — gsplat rasterize.py compute_cumulative_intersects + bin_and_sort_gaussians (†),
+ * forward.cu map_gaussian_to_intersects / get_tile_bin_edges, torch.sort on the int64 keys;
+ * run inside every Rasterize*.forward (gaussian_splatting.py:735,747,759,773).
+ * ---------------------------------------------------------------------------------------- */
+int64_t NAME(cumsum)(int N, const int32_t *num_tiles_hit, int32_t *cum) {
+    int64_t acc = 0;
+    for (int i = 0; i < N; ++i) {
+        acc += num_tiles_hit[i];
+        cum[i] = (int32_t)acc;
+    }
+    return acc;
+}
+
+void NAME(map_intersects)(int N, const REAL *xys, const REAL *depths, const int32_t *radii,
+                          const int32_t *cum, int tiles_x, int tiles_y, int64_t *isect_ids,
+                          int32_t *gaussian_ids) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) {
+        if (radii[i] <= 0) continue;
+        int x0, y0, x1, y1;
+        tile_bbox(xys[2 * i], xys[2 * i + 1], (REAL)radii[i], tiles_x, tiles_y, &x0, &y0, &x1,
+                  &y1);
+        int64_t cur = (i == 0) ? 0 : cum[i - 1];
+        union {
+            float f;
+            int32_t i;
+        } d;
+        d.f = (float)depths[i];
+        int64_t depth_id = (int64_t)(uint32_t)d.i; /* depth > 0: sign bit clear */
+        for (int ty = y0; ty < y1; ++ty)
+            for (int tx = x0; tx < x1; ++tx) {
+                int64_t tile = (int64_t)ty * tiles_x + tx;
+                isect_ids[cur] = (tile << 32) | depth_id;
+                gaussian_ids[cur] = i;
+                ++cur;
+            }
+    }
+}
+
+/* Ascending sort of the keys; ties keep emission order = ascending Gaussian id (the reference's
+ * torch.sort does not promise a tie order; SURVEY a7 fixes this one).  Stable LSD radix. */
+void NAME(sort_intersects)(int64_t I, const int64_t *keys_in, const int32_t *ids_in,
+                           int64_t *keys_out, int32_t *ids_out) {
+    if (I <= 0) return;
+    uint64_t *ka = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)I);
+    uint64_t *kb = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)I);
+    int32_t *va = (int32_t *)malloc(sizeof(int32_t) * (size_t)I);
+    int32_t *vb = (int32_t *)malloc(sizeof(int32_t) * (size_t)I);
+    memcpy(ka, keys_in, sizeof(uint64_t) * (size_t)I);
+    memcpy(va, ids_in, sizeof(int32_t) * (size_t)I);
+    for (int pass = 0; pass < 8; ++pass) {
+        size_t cnt[257];
+        memset(cnt, 0, sizeof(cnt));
+        int sh = pass * 8;
+        for (int64_t i = 0; i < I; ++i) cnt[((ka[i] >> sh) & 255) + 1]++;
+        for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
+        for (int64_t i = 0; i < I; ++i) {
+            size_t dst = cnt[(ka[i] >> sh) & 255]++;
+            kb[dst] = ka[i];
+            vb[dst] = va[i];
+        }
+        uint64_t *tk = ka;
+        ka = kb;
+        kb = tk;
+        int32_t *tv = va;
+        va = vb;
+        vb = tv;
+    }
+    memcpy(keys_out, ka, sizeof(uint64_t) * (size_t)I);
+    memcpy(ids_out, va, sizeof(int32_t) * (size_t)I);
+    free(ka);
+    free(kb);
+    free(va);
+    free(vb);
+}
+
+void NAME(tile_bins)(int64_t I, const int64_t *keys_sorted, int num_tiles, int32_t *tile_bins) {
+    memset(tile_bins, 0, sizeof(int32_t) * 2 * (size_t)num_tiles);
+    for (int64_t i = 0; i < I; ++i) {
+        int32_t cur = (int32_t)(keys_sorted[i] >> 32);
+        if (i == 0) tile_bins[2 * cur] = 0;
+        if (i == I - 1) tile_bins[2 * cur + 1] = (int32_t)I;
+        if (i > 0) {
+            int32_t prev = (int32_t)(keys_sorted[i - 1] >> 32);
+            if (prev != cur) {
+                tile_bins[2 * prev + 1] = (int32_t)i;
+                tile_bins[2 * cur] = (int32_t)i;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * blend_fwd — gsplat forward.cu rasterize_forward (C=3, gaussian_splatting.py:735,759,773) and
+ * nd_rasterize_forward (runtime C, :747) (†).  One image pixel at a time, walking its tile's
+ * depth-sorted list front to back.  Pixel centre = integer (j, i); the -0.5 lives in xys.
+ * final_idx[p] = one past the list position of the last Gaussian blended into p (range start
+ * if none); the backward walks [range start, final_idx) in reverse, i.e. exactly the blended
+ * Gaussians.  (gsplat stores an equivalent cursor; the value never leaves the operator.)
+ * ---------------------------------------------------------------------------------------- */
+void NAME(blend_fwd)(int C, int img_h, int img_w, int tiles_x, int tiles_y,
+                     const int32_t *ids_sorted, const int32_t *tile_bins, const REAL *xys,
+                     const REAL *conics, const REAL *colors, const REAL *opacity,
+                     const REAL *background, REAL *out_img, REAL *final_T, int32_t *final_idx) {
+    int num_tiles = tiles_x * tiles_y;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int tile = 0; tile < num_tiles; ++tile) {
+        int ty = tile / tiles_x, tx = tile % tiles_x;
+        int r0 = tile_bins[2 * tile], r1 = tile_bins[2 * tile + 1];
+        REAL *acc = (REAL *)malloc(sizeof(REAL) * (size_t)C);
+        for (int ly = 0; ly < GG_BLOCK; ++ly)
+            for (int lx = 0; lx < GG_BLOCK; ++lx) {
+                int i = ty * GG_BLOCK + ly, j = tx * GG_BLOCK + lx;
+                if (i >= img_h || j >= img_w) continue;
+                REAL px = (REAL)j, py = (REAL)i;
+                REAL T = R_(1.0f);
+                int last = r0;
+                for (int c = 0; c < C; ++c) acc[c] = 0;
+                for (int idx = r0; idx < r1; ++idx) {
+                    int g = ids_sorted[idx];
+                    REAL dx = xys[2 * g] - px, dy = xys[2 * g + 1] - py;
+                    REAL ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
+                    REAL sigma = FMA(R_(0.5f), FMA(ca * dx, dx, (cc * dy) * dy), (cb * dx) * dy);
+                    if (sigma < R_(0.0f)) continue;
+                    REAL alpha = FMIN(R_(GG_ALPHA_MAX_FWD), opacity[g] * gg_exp(-sigma));
+                    if (alpha < R_(GG_ALPHA_MIN)) continue;
+                    REAL next_T = T * (R_(1.0f) - alpha);
+                    if (next_T <= R_(GG_T_EPS)) break;
+                    REAL vis = alpha * T;
+                    const REAL *col = colors + (size_t)g * C;
+                    for (int c = 0; c < C; ++c) acc[c] = FMA(col[c], vis, acc[c]);
+                    T = next_T;
+                    last = idx + 1;
+                }
+                size_t p = (size_t)i * img_w + j;
+                final_T[p] = T;
+                final_idx[p] = last;
+                for (int c = 0; c < C; ++c) out_img[p * C + c] = FMA(T, background[c], acc[c]);
+            }
+        free(acc);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * blend_bwd — gsplat backward.cu rasterize_backward_kernel / nd_rasterize_backward_kernel (†),
+ * autograd of the four rasterize calls.  Per-pixel terms are computed in REAL exactly as a11
+ * lists them; the sums over pixels (gsplat: atomicAdd) are accumulated in double per
+ * (tile, list entry) in a fixed pixel order and then added per Gaussian in list order, so the
+ * oracle is deterministic and carries no fp32 summation-order noise.
+ * v_conic[.,1] carries gsplat's 0.5 factor (gradient of the symmetric matrix entry).
+ * ---------------------------------------------------------------------------------------- */
+void NAME(blend_bwd)(int C, int N, int img_h, int img_w, int tiles_x, int tiles_y,
+                     const int32_t *ids_sorted, const int32_t *tile_bins, const REAL *xys,
+                     const REAL *conics, const REAL *colors, const REAL *opacity,
+                     const REAL *background, const REAL *final_T, const int32_t *final_idx,
+                     const REAL *v_out, REAL *v_xy, REAL *v_conic, REAL *v_colors,
+                     REAL *v_opacity) {
+    int num_tiles = tiles_x * tiles_y;
+    int64_t I = 0;
+    for (int t = 0; t < num_tiles; ++t)
+        if (tile_bins[2 * t + 1] > I) I = tile_bins[2 * t + 1];
+    const int S = C + 6; /* per-entry partials: C colour, xy(2), conic(3), opacity(1) */
+    double *slab = (double *)calloc((size_t)(I > 0 ? I : 1) * S, sizeof(double));
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int tile = 0; tile < num_tiles; ++tile) {
+        int ty = tile / tiles_x, tx = tile % tiles_x;
+        int r0 = tile_bins[2 * tile];
+        REAL *Sc = (REAL *)malloc(sizeof(REAL) * (size_t)C);
+        for (int ly = 0; ly < GG_BLOCK; ++ly)
+            for (int lx = 0; lx < GG_BLOCK; ++lx) {
+                int i = ty * GG_BLOCK + ly, j = tx * GG_BLOCK + lx;
+                if (i >= img_h || j >= img_w) continue;
+                size_t p = (size_t)i * img_w + j;
+                REAL px = (REAL)j, py = (REAL)i;
+                REAL T_final = final_T[p];
+                REAL T = T_final;
+                const REAL *vo = v_out + p * C;
+                for (int c = 0; c < C; ++c) Sc[c] = 0;
+                for (int idx = final_idx[p] - 1; idx >= r0; --idx) {
+                    int g = ids_sorted[idx];
+                    REAL dx = xys[2 * g] - px, dy = xys[2 * g + 1] - py;
+                    REAL ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
+                    REAL sigma = FMA(R_(0.5f), FMA(ca * dx, dx, (cc * dy) * dy), (cb * dx) * dy);
+                    if (sigma < R_(0.0f)) continue;
+                    REAL opac = opacity[g];
+                    REAL vis = gg_exp(-sigma);
+                    REAL alpha = FMIN(R_(GG_ALPHA_MAX_BWD), opac * vis);
+                    if (alpha < R_(GG_ALPHA_MIN)) continue;
+                    REAL ra = R_(1.0f) / (R_(1.0f) - alpha);
+                    T = T * ra;
+                    REAL fac = alpha * T;
+                    REAL v_alpha = 0;
+                    const REAL *col = colors + (size_t)g * C;
+                    double *sl = slab + (size_t)idx * S;
+                    for (int c = 0; c < C; ++c) {
+                        sl[c] += (double)(fac * vo[c]);
+                        v_alpha = FMA(col[c] * T - Sc[c] * ra, vo[c], v_alpha);
+                        v_alpha = FMA(((-T_final) * ra) * background[c], vo[c], v_alpha);
+                        Sc[c] = FMA(col[c], fac, Sc[c]);
+                    }
+                    REAL v_sigma = ((-opac) * vis) * v_alpha;
+                    sl[C + 0] += (double)(v_sigma * (ca * dx + cb * dy));
+                    sl[C + 1] += (double)(v_sigma * (cb * dx + cc * dy));
+                    sl[C + 2] += (double)(((R_(0.5f) * v_sigma) * dx) * dx);
+                    sl[C + 3] += (double)(((R_(0.5f) * v_sigma) * dx) * dy);
+                    sl[C + 4] += (double)(((R_(0.5f) * v_sigma) * dy) * dy);
+                    sl[C + 5] += (double)(vis * v_alpha);
+                }
+            }
+        free(Sc);
+    }
+    /* per-Gaussian reduction, list order */
+    double *acc = (double *)calloc((size_t)(N > 0 ? N : 1) * S, sizeof(double));
+    for (int64_t idx = 0; idx < I; ++idx) {
+        int g = ids_sorted[idx];
+        for (int k = 0; k < S; ++k) acc[(size_t)g * S + k] += slab[(size_t)idx * S + k];
+    }
+    for (int g = 0; g < N; ++g) {
+        const double *a = acc + (size_t)g * S;
+        for (int c = 0; c < C; ++c) v_colors[(size_t)g * C + c] = (REAL)a[c];
+        v_xy[2 * g] = (REAL)a[C];
+        v_xy[2 * g + 1] = (REAL)a[C + 1];
+        v_conic[3 * g] = (REAL)a[C + 2];
+        v_conic[3 * g + 1] = (REAL)a[C + 3];
+        v_conic[3 * g + 2] = (REAL)a[C + 4];
+        v_opacity[g] = (REAL)a[C + 5];
+    }
+    free(acc);
+    free(slab);
+}
+
+/* Number of host threads the parallel loops above will use (bench.py cpu_baseline.cores). */
+#ifdef _OPENMP
+#include <omp.h>
+int NAME(num_threads)(void) { return omp_get_max_threads(); }
+void NAME(set_num_threads)(int n) { omp_set_num_threads(n); }
+#else
+int NAME(num_threads)(void) { return 1; }
+void NAME(set_num_threads)(int n) { (void)n; }
+#endif

@@ -1,0 +1,224 @@
+"""numpy front end of the CPU oracle (oracle/gg_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module
+(see the header of gg_oracle.c).  PARITY UNPINNED: the reference holds no fixture for this
+path and its implementation (gsplat==0.1.0) is not available offline; the oracle restates
+SURVEY.md §8a and is pinned only by the analytic / finite-difference tests in tests/.
+
+Every function takes and returns numpy arrays in torch's layouts.  `dtype=np.float32` uses the
+bit-exact parity build, `dtype=np.float64` the finite-difference build.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+
+def build(force: bool = False) -> None:
+    """Compile both oracle libraries with the committed Makefile."""
+    if force:
+        subprocess.check_call(["make", "-C", _HERE, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+
+
+def _lib(dtype):
+    key = "f64" if np.dtype(dtype) == np.float64 else "f32"
+    if key not in _LIBS:
+        path = os.path.join(_HERE, f"libgg_oracle_{key}.so")
+        if not os.path.exists(path):
+            build()
+        _LIBS[key] = C.CDLL(path)
+    return _LIBS[key], ("ggo64_" if key == "f64" else "ggo_"), (C.c_double if key == "f64" else C.c_float)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def num_threads() -> int:
+    lib, pre, _ = _lib(np.float32)
+    return int(getattr(lib, pre + "num_threads")())
+
+
+def set_num_threads(n: int) -> None:
+    for dt in (np.float32, np.float64):
+        lib, pre, _ = _lib(dt)
+        getattr(lib, pre + "set_num_threads")(C.c_int(n))
+
+
+def expf(x, dtype=np.float32):
+    lib, pre, _ = _lib(dtype)
+    x = _c(x, dtype)
+    y = np.empty_like(x)
+    getattr(lib, pre + "expf_array")(C.c_int(x.size), _p(x), _p(y))
+    return y
+
+
+def project_fwd(means, scales, glob_scale, quats, viewmat, projmat, fx, fy, cx, cy, img_h, img_w,
+                tile_bounds, clip_thresh=0.01, dtype=np.float32):
+    """-> (xys, depths, radii, conics, num_tiles_hit, cov3d), the order ProjectGaussians.apply
+    returns them (nerfstudio/models/gaussian_splatting.py:699)."""
+    lib, pre, RT = _lib(dtype)
+    means, scales, quats = _c(means, dtype), _c(scales, dtype), _c(quats, dtype)
+    viewmat, projmat = _c(viewmat, dtype).reshape(-1), _c(projmat, dtype).reshape(-1)
+    assert viewmat.size >= 12 and projmat.size == 16
+    n = means.shape[0]
+    cov3d = np.zeros((n, 6), dtype)
+    xys = np.zeros((n, 2), dtype)
+    depths = np.zeros((n,), dtype)
+    radii = np.zeros((n,), np.int32)
+    conics = np.zeros((n, 3), dtype)
+    nth = np.zeros((n,), np.int32)
+    getattr(lib, pre + "project_fwd")(
+        C.c_int(n), _p(means), _p(scales), RT(glob_scale), _p(quats), _p(viewmat), _p(projmat),
+        RT(fx), RT(fy), RT(cx), RT(cy), C.c_int(img_h), C.c_int(img_w), C.c_int(tile_bounds[0]),
+        C.c_int(tile_bounds[1]), RT(clip_thresh), _p(cov3d), _p(xys), _p(depths), _p(radii),
+        _p(conics), _p(nth))
+    return xys, depths, radii, conics, nth, cov3d
+
+
+def project_bwd(means, scales, glob_scale, quats, viewmat, projmat, fx, fy, cx, cy, img_h, img_w,
+                radii, conics, v_xy, v_depth, v_conic, dtype=np.float32):
+    """-> (v_mean3d, v_scale, v_quat)"""
+    lib, pre, RT = _lib(dtype)
+    means, scales, quats = _c(means, dtype), _c(scales, dtype), _c(quats, dtype)
+    viewmat, projmat = _c(viewmat, dtype).reshape(-1), _c(projmat, dtype).reshape(-1)
+    radii = _c(radii, np.int32)
+    conics, v_xy, v_depth, v_conic = (_c(conics, dtype), _c(v_xy, dtype), _c(v_depth, dtype),
+                                      _c(v_conic, dtype))
+    n = means.shape[0]
+    vm, vs, vq = np.zeros((n, 3), dtype), np.zeros((n, 3), dtype), np.zeros((n, 4), dtype)
+    getattr(lib, pre + "project_bwd")(
+        C.c_int(n), _p(means), _p(scales), RT(glob_scale), _p(quats), _p(viewmat), _p(projmat),
+        RT(fx), RT(fy), RT(cx), RT(cy), C.c_int(img_h), C.c_int(img_w), _p(radii), _p(conics),
+        _p(v_xy), _p(v_depth), _p(v_conic), _p(vm), _p(vs), _p(vq))
+    return vm, vs, vq
+
+
+def sh_fwd(degrees_to_use, viewdirs, coeffs, dtype=np.float32):
+    lib, pre, _ = _lib(dtype)
+    viewdirs, coeffs = _c(viewdirs, dtype), _c(coeffs, dtype)
+    n, k = coeffs.shape[0], coeffs.shape[1]
+    out = np.zeros((n, 3), dtype)
+    getattr(lib, pre + "sh_fwd")(C.c_int(n), C.c_int(k), C.c_int(degrees_to_use), _p(viewdirs),
+                                 _p(coeffs), _p(out))
+    return out
+
+
+def sh_bwd(degrees_to_use, num_bases, viewdirs, v_colors, dtype=np.float32):
+    lib, pre, _ = _lib(dtype)
+    viewdirs, v_colors = _c(viewdirs, dtype), _c(v_colors, dtype)
+    n = viewdirs.shape[0]
+    out = np.zeros((n, num_bases, 3), dtype)
+    getattr(lib, pre + "sh_bwd")(C.c_int(n), C.c_int(num_bases), C.c_int(degrees_to_use),
+                                 _p(viewdirs), _p(v_colors), _p(out))
+    return out
+
+
+def bin_and_sort(xys, depths, radii, num_tiles_hit, tile_bounds, dtype=np.float32):
+    """compute_cumulative_intersects + bin_and_sort_gaussians.
+    -> dict(num_intersects, cum_tiles_hit, isect_ids, gaussian_ids, isect_ids_sorted,
+            gaussian_ids_sorted, tile_bins)"""
+    lib, pre, _ = _lib(dtype)
+    xys, depths = _c(xys, dtype), _c(depths, dtype)
+    radii, nth = _c(radii, np.int32), _c(num_tiles_hit, np.int32)
+    n = xys.shape[0]
+    cum = np.zeros((n,), np.int32)
+    fn = getattr(lib, pre + "cumsum")
+    fn.restype = C.c_int64
+    total = int(fn(C.c_int(n), _p(nth), _p(cum)))
+    tiles_x, tiles_y = int(tile_bounds[0]), int(tile_bounds[1])
+    keys = np.zeros((total,), np.int64)
+    ids = np.zeros((total,), np.int32)
+    keys_s = np.zeros((total,), np.int64)
+    ids_s = np.zeros((total,), np.int32)
+    bins = np.zeros((tiles_x * tiles_y, 2), np.int32)
+    if total > 0:
+        getattr(lib, pre + "map_intersects")(C.c_int(n), _p(xys), _p(depths), _p(radii), _p(cum),
+                                             C.c_int(tiles_x), C.c_int(tiles_y), _p(keys), _p(ids))
+        getattr(lib, pre + "sort_intersects")(C.c_int64(total), _p(keys), _p(ids), _p(keys_s),
+                                              _p(ids_s))
+        getattr(lib, pre + "tile_bins")(C.c_int64(total), _p(keys_s), C.c_int(tiles_x * tiles_y),
+                                        _p(bins))
+    return dict(num_intersects=total, cum_tiles_hit=cum, isect_ids=keys, gaussian_ids=ids,
+                isect_ids_sorted=keys_s, gaussian_ids_sorted=ids_s, tile_bins=bins)
+
+
+def blend_fwd(ids_sorted, tile_bins, xys, conics, colors, opacity, img_h, img_w, background,
+              dtype=np.float32) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """-> (out_img (H,W,C), final_Ts (H,W), final_idx (H,W))"""
+    lib, pre, _ = _lib(dtype)
+    ids_sorted, tile_bins = _c(ids_sorted, np.int32), _c(tile_bins, np.int32)
+    xys, conics, colors = _c(xys, dtype), _c(conics, dtype), _c(colors, dtype)
+    opacity, background = _c(opacity, dtype).reshape(-1), _c(background, dtype).reshape(-1)
+    ch = colors.shape[1]
+    assert background.size == ch and opacity.size == xys.shape[0]
+    tiles_x, tiles_y = (img_w + 15) // 16, (img_h + 15) // 16
+    assert tile_bins.shape[0] == tiles_x * tiles_y
+    out = np.zeros((img_h, img_w, ch), dtype)
+    ft = np.zeros((img_h, img_w), dtype)
+    fi = np.zeros((img_h, img_w), np.int32)
+    getattr(lib, pre + "blend_fwd")(
+        C.c_int(ch), C.c_int(img_h), C.c_int(img_w), C.c_int(tiles_x), C.c_int(tiles_y),
+        _p(ids_sorted), _p(tile_bins), _p(xys), _p(conics), _p(colors), _p(opacity),
+        _p(background), _p(out), _p(ft), _p(fi))
+    return out, ft, fi
+
+
+def blend_bwd(ids_sorted, tile_bins, xys, conics, colors, opacity, img_h, img_w, background,
+              final_Ts, final_idx, v_out, dtype=np.float32):
+    """-> (v_xy, v_conic, v_colors, v_opacity (N,1))"""
+    lib, pre, _ = _lib(dtype)
+    ids_sorted, tile_bins = _c(ids_sorted, np.int32), _c(tile_bins, np.int32)
+    xys, conics, colors = _c(xys, dtype), _c(conics, dtype), _c(colors, dtype)
+    opacity, background = _c(opacity, dtype).reshape(-1), _c(background, dtype).reshape(-1)
+    final_Ts, final_idx, v_out = _c(final_Ts, dtype), _c(final_idx, np.int32), _c(v_out, dtype)
+    n, ch = colors.shape
+    tiles_x, tiles_y = (img_w + 15) // 16, (img_h + 15) // 16
+    v_xy, v_conic = np.zeros((n, 2), dtype), np.zeros((n, 3), dtype)
+    v_colors, v_opacity = np.zeros((n, ch), dtype), np.zeros((n, 1), dtype)
+    getattr(lib, pre + "blend_bwd")(
+        C.c_int(ch), C.c_int(n), C.c_int(img_h), C.c_int(img_w), C.c_int(tiles_x),
+        C.c_int(tiles_y), _p(ids_sorted), _p(tile_bins), _p(xys), _p(conics), _p(colors),
+        _p(opacity), _p(background), _p(final_Ts), _p(final_idx), _p(v_out), _p(v_xy),
+        _p(v_conic), _p(v_colors), _p(v_opacity))
+    return v_xy, v_conic, v_colors, v_opacity
+
+
+def rasterize_fwd(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_h, img_w,
+                  background, dtype=np.float32):
+    """Whole Rasterize*.forward: bin + sort + blend.  -> (out_img, saved dict)"""
+    tb = ((img_w + 15) // 16, (img_h + 15) // 16, 1)
+    b = bin_and_sort(xys, depths, radii, num_tiles_hit, tb, dtype)
+    ch = np.asarray(colors).shape[1]
+    if b["num_intersects"] < 1:
+        bg = np.asarray(background, dtype).reshape(1, 1, ch)
+        out = np.ones((img_h, img_w, ch), dtype) * bg
+        return out, dict(bins=b, final_Ts=None, final_idx=None)
+    out, ft, fi = blend_fwd(b["gaussian_ids_sorted"], b["tile_bins"], xys, conics, colors, opacity,
+                            img_h, img_w, background, dtype)
+    return out, dict(bins=b, final_Ts=ft, final_idx=fi)
+
+
+def quat_to_rotmat(quats):
+    """gsplat._torch_impl.quat_to_rotmat (reference call sites gaussian_splatting.py:516,614;
+    scripts/update.py:204,229): normalise wxyz, standard rotation matrix, (...,3,3)."""
+    q = np.asarray(quats, np.float64)
+    q = q / np.linalg.norm(q, axis=-1, keepdims=True)
+    w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    m = np.stack([
+        1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+        2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], axis=-1)
+    return m.reshape(q.shape[:-1] + (3, 3))

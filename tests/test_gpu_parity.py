@@ -1,0 +1,411 @@
+"""GPU parity tests (run on a real MI355X with `-m gpu`): every entry point of the C ABI
+(include/gg_raster.h, reached through gaussiangrasper_amd.ops / ctypes) against the CPU oracle on
+the same seeded inputs.
+
+Bars (BASELINE.json north_star): integer/index results bit-exact — radii, tile counts, per-tile
+Gaussian index lists, tile ranges, final_idx; forward floating-point results are required to be
+BIT-EXACT as well (the oracle and the kernels share one fp32 operation sequence), which is
+stricter than the 1e-5 max-abs bar; gradients (fp32 atomics, different summation order) must agree
+within the tolerances written in each test.  PARITY UNPINNED vs the real gsplat 0.1.0.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gaussiangrasper_amd import ops as P
+from gaussiangrasper_amd.camera import ring_cameras
+from gaussiangrasper_amd.pipeline import backward_view, render_view, seeded_cotangents
+from gaussiangrasper_amd.scene import make_scene
+
+DEV = "cuda:0"
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _scene_view(n, h, w, cfg=1, view_idx=0, nviews=3, feature_dim=32):
+    sc = make_scene(n, feature_dim=feature_dim, config_index=cfg)
+    v = ring_cameras(nviews, h, w)[view_idx]
+    return sc, v
+
+
+def _project_oracle(O, sc, v):
+    return O.project_fwd(_np(sc.means), _np(sc.scales.exp()), 1.0, _np(sc.quats),
+                         _np(v.viewmat[:3]), _np(v.projmat), v.fx, v.fy, v.cx, v.cy, v.height,
+                         v.width, v.tile_bounds)
+
+
+def _project_gpu(sc, v):
+    g = sc.to(DEV)
+    return P.ProjectGaussians.apply(g.means, g.scales.exp(), 1, g.quats, v.viewmat[:3].to(DEV),
+                                    v.projmat.to(DEV), v.fx, v.fy, v.cx, v.cy, v.height, v.width,
+                                    v.tile_bounds)
+
+
+def assert_bitexact(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    same = (a.view(np.uint32) == b.view(np.uint32)) if a.dtype == np.float32 else (a == b)
+    if not same.all():
+        bad = np.argwhere(~same)
+        d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+        raise AssertionError(f"{what}: {len(bad)} of {a.size} elements differ; max abs diff "
+                             f"{np.nanmax(d):.3e}; first at {bad[0]}: {a[tuple(bad[0])]} vs {b[tuple(bad[0])]}")
+
+
+def assert_close(a, b, what, rtol, atol_frac):
+    """|a-b| <= atol_frac*max|b| + rtol*|b|"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    scale = np.abs(b).max() if b.size else 0.0
+    err = np.abs(a - b) - rtol * np.abs(b)
+    worst = err.max() if err.size else 0.0
+    assert worst <= atol_frac * scale + 1e-30, \
+        f"{what}: max excess err {worst:.3e} vs allowed {atol_frac * scale:.3e} (scale {scale:.3e})"
+
+
+def test_library_loaded_is_the_hip_one():
+    from gaussiangrasper_amd import _lib
+    lib = _lib.load(build_if_missing=False)
+    assert lib.gg_abi_version() == _lib.ABI_VERSION
+    assert torch.cuda.is_available()
+
+
+def test_expf_bitexact(oracle):
+    x = np.concatenate([np.linspace(-90, 0, 200001), -np.logspace(-8, 1.9, 5000),
+                        [0.0, -0.0, -80.0, -80.00001, -79.99999]]).astype(np.float32)
+    xt = torch.from_numpy(x).to(DEV)
+    yt = torch.empty_like(xt)
+    from gaussiangrasper_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.gg_expf_array(x.size, P._ptr(xt), P._ptr(yt), P._stream(xt.device)), "expf")
+    assert_bitexact(_np(yt), oracle.expf(x), "gg_expf")
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 16, 16), (7, 45, 70), (1000, 48, 64), (50000, 300, 400),
+                                   (200000, 600, 800)])
+def test_project_fwd_bitexact(oracle, n, h, w):
+    sc, v = _scene_view(n, h, w)
+    ref = _project_oracle(oracle, sc, v)
+    got = _project_gpu(sc, v)
+    for name, r, g in zip(("xys", "depths", "radii", "conics", "num_tiles_hit", "cov3d"), ref, got):
+        assert_bitexact(_np(g), r, f"project_fwd.{name}")
+
+
+def test_project_fwd_culls_and_clamps(oracle):
+    """behind camera, z<=clip, off-screen, border clamp, huge Gaussian covering every tile"""
+    v = ring_cameras(1, 64, 96)[0]
+    cam = v.cam_pos.numpy()
+    fwd = -cam / np.linalg.norm(cam)
+    means = np.stack([cam - 1.0 * fwd, cam + 0.005 * fwd, cam + 0.0100001 * fwd, cam + 2.5 * fwd,
+                      cam + 2.5 * fwd + np.array([0, 5.0, 0]), cam + 2.5 * fwd + np.array([0, 0.9, 0]),
+                      cam + 2.5 * fwd]).astype(np.float32)
+    scales = np.full((7, 3), 0.01, np.float32)
+    scales[6] = 3.0
+    quats = np.tile(np.array([[1, 0, 0, 0]], np.float32), (7, 1))
+    ref = oracle.project_fwd(means, scales, 1.0, quats, _np(v.viewmat[:3]), _np(v.projmat), v.fx,
+                             v.fy, v.cx, v.cy, v.height, v.width, v.tile_bounds)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    got = P.ProjectGaussians.apply(t(means), t(scales), 1, t(quats), v.viewmat[:3].to(DEV),
+                                   v.projmat.to(DEV), v.fx, v.fy, v.cx, v.cy, v.height, v.width,
+                                   v.tile_bounds)
+    for name, r, g in zip(("xys", "depths", "radii", "conics", "num_tiles_hit", "cov3d"), ref, got):
+        assert_bitexact(_np(g), r, f"project_fwd.{name}")
+    radii = ref[2]
+    assert radii[0] == 0 and radii[1] == 0 and radii[3] > 0 and radii[4] == 0
+    assert ref[4][6] == v.tile_bounds[0] * v.tile_bounds[1]  # huge one hits every tile
+
+
+@pytest.mark.parametrize("k,deg", [(1, 0), (4, 1), (9, 2), (16, 3), (25, 4), (25, 2), (25, 0)])
+def test_sh_fwd_bwd(oracle, k, deg):
+    n = 5000 + 37
+    g = torch.Generator().manual_seed(k * 10 + deg)
+    vd = torch.randn(n, 3, generator=g)
+    cf = torch.randn(n, k, 3, generator=g)
+    vc = torch.randn(n, 3, generator=g)
+    cfd = cf.to(DEV).requires_grad_(True)
+    out = P.SphericalHarmonics.apply(deg, vd.to(DEV), cfd)
+    assert_bitexact(_np(out), oracle.sh_fwd(deg, _np(vd), _np(cf)), "sh_fwd")
+    out.backward(vc.to(DEV))
+    assert_bitexact(_np(cfd.grad), oracle.sh_bwd(deg, k, _np(vd), _np(vc)), "sh_bwd")
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 16, 16), (7, 45, 70), (1000, 48, 64), (50000, 300, 400),
+                                   (300000, 600, 800)])
+def test_binning_bitexact(oracle, n, h, w):
+    sc, v = _scene_view(n, h, w)
+    xys, depths, radii, conics, nth, _ = _project_oracle(oracle, sc, v)
+    ref = oracle.bin_and_sort(xys, depths, radii, nth, v.tile_bounds)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    b = P.bin_and_sort_gaussians(t(xys), t(depths), t(radii), t(nth), h, w, use_cache=False)
+    assert b.num_intersects == ref["num_intersects"]
+    assert_bitexact(_np(b.tile_bins), ref["tile_bins"], "tile_bins")
+    assert_bitexact(_np(b.gaussian_ids_sorted), ref["gaussian_ids_sorted"], "gaussian_ids_sorted")
+
+
+def test_binning_ties_and_duplicates(oracle):
+    """many Gaussians with IDENTICAL depth: ties must come out in ascending Gaussian id"""
+    n, h, w = 5000, 64, 64
+    rng = np.random.default_rng(5)
+    xys = rng.uniform(0, 64, (n, 2)).astype(np.float32)
+    depths = rng.choice(np.array([1.0, 1.5, 2.0, 2.0000002], np.float32), n)
+    radii = rng.integers(0, 20, n).astype(np.int32)
+    nth = np.zeros(n, np.int32)
+    for i in range(n):
+        if radii[i] > 0:
+            x0, x1 = int(np.clip(xys[i, 0] / 16 - radii[i] / 16, 0, 4)), int(np.clip(xys[i, 0] / 16 + radii[i] / 16 + 1, 0, 4))
+            y0, y1 = int(np.clip(xys[i, 1] / 16 - radii[i] / 16, 0, 4)), int(np.clip(xys[i, 1] / 16 + radii[i] / 16 + 1, 0, 4))
+            nth[i] = (x1 - x0) * (y1 - y0)
+            if nth[i] == 0:
+                radii[i] = 0
+    ref = oracle.bin_and_sort(xys, depths, radii, nth, (4, 4, 1))
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    b = P.bin_and_sort_gaussians(t(xys), t(depths), t(radii), t(nth), h, w, use_cache=False)
+    assert b.num_intersects == ref["num_intersects"] == int(nth.sum())
+    assert_bitexact(_np(b.tile_bins), ref["tile_bins"], "tile_bins")
+    assert_bitexact(_np(b.gaussian_ids_sorted), ref["gaussian_ids_sorted"], "gaussian_ids_sorted")
+
+
+def _blend_inputs(oracle, n, h, w, ch, seed=0, cfg=1):
+    sc, v = _scene_view(n, h, w, cfg=cfg)
+    xys, depths, radii, conics, nth, _ = _project_oracle(oracle, sc, v)
+    rng = np.random.default_rng(seed)
+    colors = rng.uniform(-1, 1, (n, ch)).astype(np.float32)
+    opac = torch.sigmoid(sc.opacities).numpy()
+    bg = rng.uniform(0, 1, ch).astype(np.float32)
+    return xys, depths, radii, conics, nth, colors, opac, bg
+
+
+@pytest.mark.parametrize("n,h,w,ch", [(1, 16, 16, 3), (7, 45, 70, 3), (2000, 48, 64, 1),
+                                      (2000, 48, 64, 5), (50000, 300, 400, 3),
+                                      (50000, 300, 400, 32), (20000, 150, 200, 39),
+                                      (5000, 100, 120, 128), (300000, 600, 800, 32)])
+def test_blend_fwd_bitexact(oracle, n, h, w, ch):
+    xys, depths, radii, conics, nth, colors, opac, bg = _blend_inputs(oracle, n, h, w, ch)
+    ref_out, saved = oracle.rasterize_fwd(xys, depths, radii, conics, nth, colors, opac, h, w, bg)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    op = P.RasterizeGaussians if ch == 3 else P.NDRasterizeGaussians
+    P.clear_bin_cache()
+
+    class Ctx:  # run the forward body directly to look at the saved final_Ts / final_idx
+        def save_for_backward(self, *a):
+            self.saved = a
+    ctx = Ctx()
+    out = P._rasterize_forward(ctx, t(xys), t(depths), t(radii), t(conics), t(nth), t(colors),
+                               t(opac), h, w, t(bg), ch == 3)
+    assert_bitexact(_np(out), ref_out, "out_img")
+    if saved["final_Ts"] is not None:
+        assert_bitexact(_np(ctx.saved[7]), saved["final_Ts"], "final_Ts")
+        assert_bitexact(_np(ctx.saved[8]), saved["final_idx"], "final_idx")
+    out2 = op.apply(t(xys), t(depths), t(radii), t(conics), t(nth), t(colors), t(opac), h, w, t(bg))
+    assert_bitexact(_np(out2), ref_out, "out_img(apply)")
+
+
+@pytest.mark.parametrize("n,h,w,ch", [(1, 16, 16, 3), (7, 45, 70, 3), (2000, 48, 64, 1),
+                                      (2000, 48, 64, 5), (50000, 300, 400, 3),
+                                      (50000, 300, 400, 32), (20000, 150, 200, 39)])
+def test_blend_bwd(oracle, n, h, w, ch):
+    """tolerance: |gpu-oracle| <= 2e-5*max|grad| + 1e-3*|grad| (fp32 atomics vs fp64-summed oracle;
+    the kernel uses the algebraically-equal scalar-W form of v_alpha, see blend.hip header)"""
+    xys, depths, radii, conics, nth, colors, opac, bg = _blend_inputs(oracle, n, h, w, ch, seed=3)
+    ref_out, saved = oracle.rasterize_fwd(xys, depths, radii, conics, nth, colors, opac, h, w, bg)
+    v_out = np.random.default_rng(11).standard_normal(ref_out.shape).astype(np.float32)
+    b = saved["bins"]
+    if b["num_intersects"] < 1:
+        pytest.skip("no intersections")
+    ref = oracle.blend_bwd(b["gaussian_ids_sorted"], b["tile_bins"], xys, conics, colors, opac, h, w,
+                           bg, saved["final_Ts"], saved["final_idx"], v_out)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    xt, ct, colt, ot = (t(xys).requires_grad_(True), t(conics).requires_grad_(True),
+                        t(colors).requires_grad_(True), t(opac).requires_grad_(True))
+    op = P.RasterizeGaussians if ch == 3 else P.NDRasterizeGaussians
+    P.clear_bin_cache()
+    out = op.apply(xt, t(depths), t(radii), ct, t(nth), colt, ot, h, w, t(bg))
+    out.backward(t(v_out))
+    for name, g, r in zip(("v_xy", "v_conic", "v_colors", "v_opacity"),
+                          (xt.grad, ct.grad, colt.grad, ot.grad), ref):
+        assert_close(_np(g), r, f"blend_bwd.{name}", rtol=1e-3, atol_frac=2e-5)
+
+
+@pytest.mark.parametrize("n,h,w", [(7, 45, 70), (1000, 48, 64), (50000, 300, 400)])
+def test_project_bwd(oracle, n, h, w):
+    """tolerance: 1e-5*max|grad| + 1e-4*|grad| (same formulas, fp32, per-Gaussian, no reduction)"""
+    sc, v = _scene_view(n, h, w)
+    ref_fwd = _project_oracle(oracle, sc, v)
+    rng = np.random.default_rng(2)
+    v_xy = rng.standard_normal((n, 2)).astype(np.float32)
+    v_depth = rng.standard_normal(n).astype(np.float32)
+    v_conic = rng.standard_normal((n, 3)).astype(np.float32)
+    ref = oracle.project_bwd(_np(sc.means), _np(sc.scales.exp()), 1.0, _np(sc.quats),
+                             _np(v.viewmat[:3]), _np(v.projmat), v.fx, v.fy, v.cx, v.cy, h, w,
+                             ref_fwd[2], ref_fwd[3], v_xy, v_depth, v_conic)
+    g = sc.to(DEV)
+    m, s, q = (g.means.requires_grad_(True), g.scales.exp().detach().requires_grad_(True),
+               g.quats.requires_grad_(True))
+    outs = P.ProjectGaussians.apply(m, s, 1, q, v.viewmat[:3].to(DEV), v.projmat.to(DEV), v.fx, v.fy,
+                                    v.cx, v.cy, h, w, v.tile_bounds)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    torch.autograd.backward([outs[0], outs[1], outs[3]], [t(v_xy), t(v_depth), t(v_conic)])
+    for name, got, r in zip(("v_mean3d", "v_scale", "v_quat"), (m.grad, s.grad, q.grad), ref):
+        assert_close(_np(got), r, f"project_bwd.{name}", rtol=1e-4, atol_frac=1e-5)
+
+
+@pytest.mark.parametrize("n,h,w,d", [(3000, 96, 128, 32), (50000, 300, 400, 32)])
+def test_reference_call_sequence_vs_oracle(oracle, n, h, w, d):
+    """The whole get_outputs sequence (project, SH, 4 rasterize calls) + one backward with dense
+    seeded cotangents, HIP operators vs oracle-backed operators: images bit-exact, parameter
+    gradients within 3e-5*max|grad| + 2e-3*|grad|; xys.grad is populated."""
+    import oracle_ops
+    sc, v = _scene_view(n, h, w, feature_dim=d)
+    # oracle side (CPU)
+    sc_c = sc.to("cpu")
+    for p in sc_c.params():
+        p.requires_grad_(True)
+    out_c = render_view(sc_c, v, oracle_ops)
+    cot = seeded_cotangents(out_c, seed=7)
+    backward_view(out_c, cot)
+    # HIP side
+    P.clear_bin_cache()
+    sc_g = sc.to(DEV)
+    for p in sc_g.params():
+        p.requires_grad_(True)
+    vg = ring_cameras(3, h, w, device=DEV)[0]
+    out_g = render_view(sc_g, vg, P)
+    backward_view(out_g, {k: t.to(DEV) for k, t in cot.items()})
+    for k in ("rgb", "feature", "depth", "normal"):
+        assert_bitexact(_np(out_g[k]), _np(out_c[k]), f"image.{k}")
+    assert_bitexact(_np(out_g["radii"]), _np(out_c["radii"]), "radii")
+    assert out_g["xys"].grad is not None and out_g["xys"].grad.abs().sum() > 0
+    assert_close(_np(out_g["xys"].grad), _np(out_c["xys"].grad), "xys.grad", rtol=2e-3, atol_frac=3e-5)
+    for name, pg, pc in zip(("means", "scales", "quats", "opacities", "colors_all", "feature"),
+                            sc_g.params(), sc_c.params()):
+        assert_close(_np(pg.grad), _np(pc.grad), f"grad.{name}", rtol=2e-3, atol_frac=3e-5)
+    assert P.bin_cache_stats["hits"] >= 3  # one sort shared by the four rasterize calls
+
+
+def test_no_intersections_returns_background():
+    """I < 1: gsplat returns ones*background and zero grads (SURVEY §8b error conventions)"""
+    n, h, w = 10, 32, 48
+    xys = torch.zeros(n, 2, device=DEV, requires_grad=True)
+    z = torch.zeros(n, device=DEV)
+    zi = torch.zeros(n, dtype=torch.int32, device=DEV)
+    conics = torch.ones(n, 3, device=DEV)
+    colors = torch.rand(n, 3, device=DEV, requires_grad=True)
+    opac = torch.rand(n, 1, device=DEV)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=DEV)
+    P.clear_bin_cache()
+    out = P.RasterizeGaussians.apply(xys, z, zi, conics, zi, colors, opac, h, w, bg)
+    assert out.shape == (h, w, 3)
+    assert torch.equal(out, torch.ones(h, w, 3, device=DEV) * bg)
+    out.sum().backward()
+    assert xys.grad.abs().sum() == 0 and colors.grad.abs().sum() == 0
+
+
+def test_error_behaviour():
+    n = 4
+    f = lambda *s: torch.zeros(*s, device=DEV)
+    zi = torch.zeros(n, dtype=torch.int32, device=DEV)
+    with pytest.raises(ValueError):
+        P.RasterizeGaussians.apply(f(n, 2), f(n), zi, f(n, 3), zi, f(n, 4), f(n, 1), 16, 16, f(4))
+    with pytest.raises(ValueError):
+        P.RasterizeGaussians.apply(f(n, 2), f(n), zi, f(n, 3), zi, f(n, 3), f(n), 16, 16, f(3))
+    with pytest.raises(ValueError):
+        P.NDRasterizeGaussians.apply(f(n, 3), f(n), zi, f(n, 3), zi, f(n, 8), f(n, 1), 16, 16, f(8))
+    with pytest.raises(AssertionError):
+        P.NDRasterizeGaussians.apply(f(n, 2), f(n), zi, f(n, 3), zi, f(n, 8), f(n, 1), 16, 16, f(3))
+    with pytest.raises(RuntimeError):  # CPU tensors: no fallback
+        P.RasterizeGaussians.apply(torch.zeros(n, 2), torch.zeros(n), zi.cpu(), torch.zeros(n, 3),
+                                   zi.cpu(), torch.zeros(n, 3), torch.zeros(n, 1), 16, 16,
+                                   torch.zeros(3))
+    # uint8 colours are converted to float/255
+    xys, depths = torch.full((1, 2), 8.0, device=DEV), torch.ones(1, device=DEV)
+    radii, nth = torch.full((1,), 3, dtype=torch.int32, device=DEV), torch.ones(1, dtype=torch.int32, device=DEV)
+    conics = torch.tensor([[0.5, 0.0, 0.5]], device=DEV)
+    P.clear_bin_cache()
+    a = P.RasterizeGaussians.apply(xys, depths, radii, conics, nth,
+                                   torch.tensor([[255, 0, 51]], dtype=torch.uint8, device=DEV),
+                                   torch.ones(1, 1, device=DEV) * 0.9, 16, 16, f(3))
+    P.clear_bin_cache()
+    b = P.RasterizeGaussians.apply(xys, depths, radii, conics, nth,
+                                   torch.tensor([[1.0, 0.0, 0.2]], device=DEV),
+                                   torch.ones(1, 1, device=DEV) * 0.9, 16, 16, f(3))
+    assert torch.equal(a, b)
+
+
+def test_golden_fixtures_on_gpu():
+    """committed golden vectors (made by tests/golden/make_golden.py from the oracle) vs the HIP path"""
+    import glob
+    import os
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+    assert files, "no golden fixtures"
+    for f in files:
+        z = np.load(f)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+        h, w = int(z["hw"][0]), int(z["hw"][1])
+        tb = ((w + 15) // 16, (h + 15) // 16, 1)
+        got = P.ProjectGaussians.apply(t(z["means"]), t(z["scales"]), 1, t(z["quats"]), t(z["viewmat"]),
+                                       t(z["projmat"]), float(z["intr"][0]), float(z["intr"][1]),
+                                       float(z["intr"][2]), float(z["intr"][3]), h, w, tb)
+        for name, g in zip(("xys", "depths", "radii", "conics", "num_tiles_hit", "cov3d"), got):
+            assert_bitexact(_np(g), z[name], f"{os.path.basename(f)}:{name}")
+        P.clear_bin_cache()
+        b = P.bin_and_sort_gaussians(got[0], got[1], got[2], got[4], h, w, use_cache=False)
+        assert_bitexact(_np(b.gaussian_ids_sorted), z["gaussian_ids_sorted"], "gaussian_ids_sorted")
+        assert_bitexact(_np(b.tile_bins), z["tile_bins"], "tile_bins")
+        op = P.RasterizeGaussians if z["colors"].shape[1] == 3 else P.NDRasterizeGaussians
+        col, opa = t(z["colors"]).requires_grad_(True), t(z["opacity"]).requires_grad_(True)
+        xy, con = got[0].detach().requires_grad_(True), got[3].detach().requires_grad_(True)
+        out = op.apply(xy, got[1], got[2], con, got[4], col, opa, h, w, t(z["background"]))
+        assert_bitexact(_np(out), z["out_img"], f"{os.path.basename(f)}:out_img")
+        out.backward(t(z["v_out"]))
+        for name, g in zip(("v_xy", "v_conic", "v_colors", "v_opacity"),
+                           (xy.grad, con.grad, col.grad, opa.grad)):
+            assert_close(_np(g), z[name], f"{os.path.basename(f)}:{name}", rtol=1e-3, atol_frac=2e-5)
+
+
+def test_full_size_properties():
+    """BASELINE sizes (1 M Gaussians, 1600x1200, 32-ch feature): size-independent properties —
+    tile lists are a partition ordered by (depth, id); blending ones gives 1 - final_T; the op is
+    linear in the colours; a C=35 call agrees bit-for-bit, channel-wise, with C=3 and C=32 calls."""
+    n, h, w = 1_000_000, 1200, 1600
+    sc, _ = _scene_view(n, h, w, cfg=3)
+    v = ring_cameras(8, h, w, device=DEV)[1]
+    g = sc.to(DEV)
+    xys, depths, radii, conics, nth, _ = P.ProjectGaussians.apply(
+        g.means, g.scales.exp(), 1, g.quats, v.viewmat[:3], v.projmat, v.fx, v.fy, v.cx, v.cy, h, w,
+        v.tile_bounds)
+    b = P.bin_and_sort_gaussians(xys, depths, radii, nth, h, w, use_cache=False)
+    ids, bins = b.gaussian_ids_sorted.long(), b.tile_bins.long()
+    assert b.num_intersects == int(nth.long().sum())
+    lens = bins[:, 1] - bins[:, 0]
+    assert int(lens.sum()) == b.num_intersects and int(lens.min()) >= 0
+    nz = bins[lens > 0]
+    assert torch.equal(nz[1:, 0], nz[:-1, 1]) and int(nz[0, 0]) == 0  # contiguous partition
+    tile_of = torch.repeat_interleave(torch.arange(bins.shape[0], device=DEV), lens)
+    d = depths[ids]
+    key = tile_of.double() * 1e6 + d.double()
+    assert bool((key[1:] >= key[:-1]).all()), "lists must be tile-major, near-to-far"
+    tie = (key[1:] == key[:-1])
+    assert bool((ids[1:][tie] > ids[:-1][tie]).all()), "ties must be in ascending Gaussian id"
+    counts = torch.bincount(ids, minlength=n)
+    assert torch.equal(counts.int(), nth), "every Gaussian appears num_tiles_hit times"
+
+    opac = torch.sigmoid(g.opacities)
+    feat = g.feature
+    zeros = lambda c: torch.zeros(c, device=DEV)
+    ones_img = P.NDRasterizeGaussians.apply(xys, depths, radii, conics, nth, torch.ones(n, 1, device=DEV),
+                                            opac, h, w, zeros(1))
+    # transmittance conservation: sum_i alpha_i T_i = 1 - T_final ; T_final via background=1 trick
+    t_img = P.NDRasterizeGaussians.apply(xys, depths, radii, conics, nth, torch.zeros(n, 1, device=DEV),
+                                         opac, h, w, torch.ones(1, device=DEV))
+    assert float((ones_img + t_img - 1).abs().max()) < 2e-5
+    f_img = P.NDRasterizeGaussians.apply(xys, depths, radii, conics, nth, feat, opac, h, w, zeros(32))
+    rgb = torch.rand(n, 3, device=DEV)
+    r_img = P.RasterizeGaussians.apply(xys, depths, radii, conics, nth, rgb, opac, h, w, zeros(3))
+    both = P.NDRasterizeGaussians.apply(xys, depths, radii, conics, nth, torch.cat([rgb, feat], 1),
+                                        opac, h, w, zeros(35))
+    assert torch.equal(both[..., :3], r_img) and torch.equal(both[..., 3:], f_img)
+    lin = P.NDRasterizeGaussians.apply(xys, depths, radii, conics, nth, 2 * feat, opac, h, w, zeros(32))
+    assert torch.equal(lin, 2 * f_img)  # scaling by 2 is exact in binary fp

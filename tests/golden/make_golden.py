@@ -24,7 +24,7 @@ CASES = [  # name, N, H, W, C, scale multiplier (bigger splats at tiny resolutio
     ("g1_n300_48x64_c3", 300, 48, 64, 3, 14.0, 1),
     ("g2_n200_32x48_c8", 200, 32, 48, 8, 5.0, 2),
     ("g3_n150_16x32_c32", 150, 16, 32, 32, 12.0, 0),
-    ("g4_dense_n400_32x32_c3", 400, 32, 32, 3, 20.0, 1),   # clustered + opaque: hits the T<=1e-4 stop
+    ("g4_dense_n400_32x32_c3", 400, 32, 32, 3, 60.0, 1),   # clustered + opaque: hits the T<=1e-4 stop
 ]
 
 
@@ -35,7 +35,7 @@ def main():
         v = ring_cameras(3, h, w)[vi]
         scales = (sc.scales.exp() * smul).numpy()
         if "dense" in name:
-            sc.means.mul_(0.15)
+            sc.means.mul_(0.5)
             sc.opacities.add_(6.0)
         viewmat = v.viewmat[:3].contiguous().numpy()
         projmat = v.projmat.numpy()

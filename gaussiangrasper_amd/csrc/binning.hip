@@ -407,6 +407,7 @@ extern "C" int gg_bin_sort(int N, int64_t I, const float *xys, const float *dept
         gg_set_error("gg_bin_sort: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
         return GG_ERR_WORKSPACE;
     }
+    gg_prof_begin(GG_K_BIN_SORT, s);
     // 1. depth order of the Gaussians
     hipLaunchKernelGGL(depth_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, depths, radii,
                        w.dkeyA, w.dvalA);
@@ -443,6 +444,7 @@ extern "C" int gg_bin_sort(int N, int64_t I, const float *xys, const float *dept
     // 5. tile ranges
     hipLaunchKernelGGL(tile_bins_kernel, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, s, I, kcur,
                        tile_bins, isect_tile_sorted);
+    gg_prof_end(GG_K_BIN_SORT, s);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }

@@ -390,10 +390,12 @@ static void launch_fwd(int C, int off, int n, int img_h, int img_w, int tiles_x,
                        const int32_t *ids, const int32_t *tile_bins, const GRec *rec,
                        const float *colors, const float *background, float *out_img,
                        float *final_Ts, int32_t *final_idx, int write_final, hipStream_t s) {
+    gg_prof_begin(GG_K_BLEND_FWD + gg_width_index(CH), s);
     if (n == CH)
         hipLaunchKernelGGL((blend_fwd_kernel<CH, true>), dim3(ntiles), dim3(256), 0, s, FWD_ARGS);
     else
         hipLaunchKernelGGL((blend_fwd_kernel<CH, false>), dim3(ntiles), dim3(256), 0, s, FWD_ARGS);
+    gg_prof_end(GG_K_BLEND_FWD + gg_width_index(CH), s);
 }
 
 extern "C" int gg_blend_fwd(int C, int N, int img_h, int img_w, const int32_t *ids,
@@ -441,6 +443,7 @@ static void launch_bwd(int C, int off, int n, int img_h, int img_w, int tiles_x,
                        const float *colors, const float *background, const float *final_Ts,
                        const int32_t *final_idx, const float *v_out, float *v_xy, float *v_conic,
                        float *v_colors, float *v_opacity, hipStream_t s) {
+    gg_prof_begin(GG_K_BLEND_BWD + gg_width_index(CH), s);
     if (n == CH)
         hipLaunchKernelGGL((blend_bwd_kernel<CH, true>), dim3(ntiles), dim3(256), 0, s, C, off, n,
                            img_h, img_w, tiles_x, ntiles, ids, (const int2 *)tile_bins, rec, colors,
@@ -449,6 +452,7 @@ static void launch_bwd(int C, int off, int n, int img_h, int img_w, int tiles_x,
         hipLaunchKernelGGL((blend_bwd_kernel<CH, false>), dim3(ntiles), dim3(256), 0, s, C, off, n,
                            img_h, img_w, tiles_x, ntiles, ids, (const int2 *)tile_bins, rec, colors,
                            background, final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity);
+    gg_prof_end(GG_K_BLEND_BWD + gg_width_index(CH), s);
 }
 
 extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *ids,

@@ -418,10 +418,12 @@ extern "C" int gg_project_fwd(int N, const float *means3d, const float *scales, 
     GG_REQUIRE(means3d && scales && quats && viewmat && projmat && cov3d && xys && depths &&
                    radii && conics && num_tiles_hit,
                "null pointer");
+    gg_prof_begin(GG_K_PROJECT_FWD, (hipStream_t)stream);
     hipLaunchKernelGGL(project_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, N, means3d, scales, glob_scale, quats, viewmat,
                        projmat, fx, fy, cx, cy, img_height, img_width, tiles_x, tiles_y,
                        clip_thresh, cov3d, xys, depths, radii, conics, num_tiles_hit);
+    gg_prof_end(GG_K_PROJECT_FWD, (hipStream_t)stream);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
@@ -440,10 +442,12 @@ extern "C" int gg_project_bwd(int N, const float *means3d, const float *scales, 
     GG_REQUIRE(means3d && scales && quats && viewmat && projmat && radii && conics && v_xy &&
                    v_depth && v_conic && v_mean3d && v_scale && v_quat,
                "null pointer");
+    gg_prof_begin(GG_K_PROJECT_BWD, (hipStream_t)stream);
     hipLaunchKernelGGL(project_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, N, means3d, scales, glob_scale, quats, viewmat,
                        projmat, fx, fy, img_height, img_width, radii, conics, v_xy, v_depth,
                        v_conic, v_mean3d, v_scale, v_quat);
+    gg_prof_end(GG_K_PROJECT_BWD, (hipStream_t)stream);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
@@ -466,6 +470,7 @@ static int sh_dispatch(bool fwd, int N, int K, int deg, const float *viewdirs, c
     if (N == 0) return GG_OK;
     GG_REQUIRE(viewdirs && in && out, "null pointer");
     hipStream_t s = (hipStream_t)stream;
+    gg_prof_begin(fwd ? GG_K_SH_FWD : GG_K_SH_BWD, s);
     switch (K) {
         case 1: launch_sh<1>(fwd, N, deg, viewdirs, in, out, s); break;
         case 4: launch_sh<4>(fwd, N, deg, viewdirs, in, out, s); break;
@@ -473,6 +478,7 @@ static int sh_dispatch(bool fwd, int N, int K, int deg, const float *viewdirs, c
         case 16: launch_sh<16>(fwd, N, deg, viewdirs, in, out, s); break;
         default: launch_sh<25>(fwd, N, deg, viewdirs, in, out, s); break;
     }
+    gg_prof_end(fwd ? GG_K_SH_FWD : GG_K_SH_BWD, s);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }

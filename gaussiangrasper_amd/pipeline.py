@@ -2,15 +2,23 @@
 (nerfstudio/models/gaussian_splatting.py:699-784): project -> SH -> rasterize rgb (3 ch),
 feature (D ch, ND op), depth (3 replicated ch, background 10, channel 0 kept), normal (3 ch).
 Used by bench.py, the multi-GPU harness and the tests; `ops` is any namespace that exposes the
-four gsplat-style autograd.Functions + quat_to_rotmat (the product: gaussiangrasper_amd.ops)."""
+four gsplat-style autograd.Functions + quat_to_rotmat (the product: gaussiangrasper_amd.ops).
+
+Two stages so that tests can feed bit-identical activated inputs to two operator stacks:
+  activate()            the caller-side torch elementwise work: exp(scales),
+                        q/|q|, sigmoid(opacities) (recomputed per rasterize call, as the reference
+                        does), view directions, smallest-axis normals;
+  rasterize_activated() the operator calls themselves, argument for argument as the reference."""
 from __future__ import annotations
 
-from typing import Dict
+from typing import Callable, Dict, Union
 
 import torch
 
 from .camera import ViewParams
 from .scene import Scene
+
+CHANNELS = ("rgb", "feature", "depth", "normal")
 
 
 def smallest_axis_normals(quats: torch.Tensor, log_scales: torch.Tensor, quat_to_rotmat) -> torch.Tensor:
@@ -20,41 +28,57 @@ def smallest_axis_normals(quats: torch.Tensor, log_scales: torch.Tensor, quat_to
     return rot.gather(2, idx).squeeze(dim=2)
 
 
-def render_view(scene: Scene, view: ViewParams, ops, sh_degree_to_use: int = 4,
-                channels=("rgb", "feature", "depth", "normal")) -> Dict[str, torch.Tensor]:
-    dev = scene.means.device
+def activate(scene: Scene, view: ViewParams, quat_to_rotmat) -> Dict[str, Union[torch.Tensor, Callable]]:
+    viewdirs = scene.means.detach() - view.cam_pos.to(scene.means.device)
+    viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
+    return {
+        "means": scene.means,
+        "scales": torch.exp(scene.scales),
+        "quats": scene.quats / scene.quats.norm(dim=-1, keepdim=True),
+        "opac": lambda: torch.sigmoid(scene.opacities),     # :742,:754,:766,:780 — one per call
+        "viewdirs": viewdirs,
+        "sh": scene.colors_all,
+        "feature": scene.feature,
+        "normals": smallest_axis_normals(scene.quats, scene.scales, quat_to_rotmat),
+    }
+
+
+def rasterize_activated(act: Dict, view: ViewParams, ops, sh_degree_to_use: int = 4,
+                        channels=CHANNELS) -> Dict[str, torch.Tensor]:
+    dev = act["means"].device
     h, w = view.height, view.width
+    opac = (lambda: act["opac"]()) if callable(act["opac"]) else (lambda: act["opac"])
     xys, depths, radii, conics, num_tiles_hit, cov3d = ops.ProjectGaussians.apply(
-        scene.means, torch.exp(scene.scales), 1,
-        scene.quats / scene.quats.norm(dim=-1, keepdim=True),
-        view.viewmat[:3, :], view.projmat, view.fx, view.fy, view.cx, view.cy, h, w,
-        view.tile_bounds)
+        act["means"], act["scales"], 1, act["quats"], view.viewmat[:3, :].to(dev),
+        view.projmat.to(dev), view.fx, view.fy, view.cx, view.cy, h, w, view.tile_bounds)
     out: Dict[str, torch.Tensor] = {"xys": xys, "radii": radii, "depths": depths, "conics": conics,
                                     "num_tiles_hit": num_tiles_hit}
     if xys.requires_grad:
         xys.retain_grad()           # densification statistics read xys.grad (:724-725, :376-393)
     if "rgb" in channels:
-        viewdirs = scene.means.detach() - view.cam_pos
-        viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
-        rgbs = ops.SphericalHarmonics.apply(sh_degree_to_use, viewdirs, scene.colors_all)
+        rgbs = ops.SphericalHarmonics.apply(sh_degree_to_use, act["viewdirs"], act["sh"])
         rgbs = torch.clamp(rgbs + 0.5, 0.0, 1.0)
         out["rgb"] = ops.RasterizeGaussians.apply(
-            xys, depths, radii, conics, num_tiles_hit, rgbs, torch.sigmoid(scene.opacities), h, w,
-            torch.zeros(3, device=dev))
+            xys, depths, radii, conics, num_tiles_hit, rgbs, opac(), h, w, torch.zeros(3, device=dev))
     if "feature" in channels:
         out["feature"] = ops.NDRasterizeGaussians.apply(
-            xys, depths, radii, conics, num_tiles_hit, scene.feature,
-            torch.sigmoid(scene.opacities), h, w, torch.zeros(scene.feature.shape[1], device=dev))
+            xys, depths, radii, conics, num_tiles_hit, act["feature"], opac(), h, w,
+            torch.zeros(act["feature"].shape[1], device=dev))
     if "depth" in channels:
         out["depth"] = ops.RasterizeGaussians.apply(
-            xys, depths, radii, conics, num_tiles_hit, depths[:, None].repeat(1, 3),
-            torch.sigmoid(scene.opacities), h, w, torch.ones(3, device=dev) * 10)[..., 0:1]
+            xys, depths, radii, conics, num_tiles_hit, depths[:, None].repeat(1, 3), opac(), h, w,
+            torch.ones(3, device=dev) * 10)[..., 0:1]
     if "normal" in channels:
-        normals = smallest_axis_normals(scene.quats, scene.scales, ops.quat_to_rotmat)
         out["normal"] = ops.RasterizeGaussians.apply(
-            xys, depths, radii, conics, num_tiles_hit, normals, torch.sigmoid(scene.opacities),
-            h, w, torch.zeros(3, device=dev))
+            xys, depths, radii, conics, num_tiles_hit, act["normals"], opac(), h, w,
+            torch.zeros(3, device=dev))
     return out
+
+
+def render_view(scene: Scene, view: ViewParams, ops, sh_degree_to_use: int = 4,
+                channels=CHANNELS) -> Dict[str, torch.Tensor]:
+    return rasterize_activated(activate(scene, view, ops.quat_to_rotmat), view, ops,
+                               sh_degree_to_use, channels)
 
 
 def seeded_cotangents(outputs: Dict[str, torch.Tensor], seed: int = 0) -> Dict[str, torch.Tensor]:
@@ -62,7 +86,7 @@ def seeded_cotangents(outputs: Dict[str, torch.Tensor], seed: int = 0) -> Dict[s
     and GPU runs see the same numbers."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     cot = {}
-    for name in ("rgb", "feature", "depth", "normal"):
+    for name in CHANNELS:
         if name in outputs:
             t = outputs[name]
             cot[name] = torch.randn(t.shape, generator=g, dtype=torch.float32).to(t.device)

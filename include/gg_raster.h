@@ -118,6 +118,25 @@ int gg_blend_bwd(int channels, int num_points, int img_height, int img_width,
                  const float *v_out_img, float *v_xy, float *v_conic, float *v_colors,
                  float *v_opacity, void *ws, size_t ws_bytes, gg_stream_t stream);
 
+/* ---- in-library kernel timing (measurement only; off by default) --------------------------------
+ * When enabled, every launch of the kernels below is bracketed by a hipEvent pair recorded on the
+ * launch stream, so bench.py can report the average duration of exactly that kernel over its
+ * timed region (the number a rocprofv3 --kernel-trace --stats run must agree with).
+ * gg_prof_get synchronises on the recorded events.  Kernel ids: */
+#define GG_K_PROJECT_FWD 0
+#define GG_K_PROJECT_BWD 1
+#define GG_K_SH_FWD 2
+#define GG_K_SH_BWD 3
+#define GG_K_BIN_SORT 4   /* the whole gg_bin_sort launch sequence */
+#define GG_K_BLEND_PREP 5
+#define GG_K_BLEND_FWD 10 /* + width index: template widths {1,3,4,8,16,32} -> 0..5 */
+#define GG_K_BLEND_BWD 20 /* + width index */
+#define GG_PROF_NUM_KERNELS 32
+int gg_prof_enable(int on);
+int gg_prof_reset(void);
+int gg_prof_get(int kernel_id, int *launches, double *total_ms);
+const char *gg_prof_name(int kernel_id);
+
 /* y[i] = gg_expf(x[i]) on the device — lets the tests pin the GPU exponential bit-for-bit
  * against the oracle's (gg_constants.h documents the operation sequence). */
 int gg_expf_array(int n, const float *x, float *y, gg_stream_t stream);

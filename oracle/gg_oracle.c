@@ -32,6 +32,9 @@
 #include <string.h>
 
 #include "../include/gg_constants.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #ifdef GGO_F64
 typedef double REAL;
@@ -671,9 +674,20 @@ void NAME(blend_bwd)(int C, int N, int img_h, int img_w, int tiles_x, int tiles_
     }
     /* per-Gaussian reduction, list order */
     double *acc = (double *)calloc((size_t)(N > 0 ? N : 1) * S, sizeof(double));
-    for (int64_t idx = 0; idx < I; ++idx) {
-        int g = ids_sorted[idx];
-        for (int k = 0; k < S; ++k) acc[(size_t)g * S + k] += slab[(size_t)idx * S + k];
+    /* every thread scans the whole list and adds the entries of "its" Gaussians (g mod nthreads):
+     * each Gaussian's partials are still added in list order, whatever the thread count */
+#pragma omp parallel
+    {
+        int nt = 1, tid = 0;
+#ifdef _OPENMP
+        nt = omp_get_num_threads();
+        tid = omp_get_thread_num();
+#endif
+        for (int64_t idx = 0; idx < I; ++idx) {
+            int g = ids_sorted[idx];
+            if (g % nt != tid) continue;
+            for (int k = 0; k < S; ++k) acc[(size_t)g * S + k] += slab[(size_t)idx * S + k];
+        }
     }
     for (int g = 0; g < N; ++g) {
         const double *a = acc + (size_t)g * S;
@@ -691,7 +705,6 @@ void NAME(blend_bwd)(int C, int N, int img_h, int img_w, int tiles_x, int tiles_
 
 /* Number of host threads the parallel loops above will use (bench.py cpu_baseline.cores). */
 #ifdef _OPENMP
-#include <omp.h>
 int NAME(num_threads)(void) { return omp_get_max_threads(); }
 void NAME(set_num_threads)(int n) { omp_set_num_threads(n); }
 #else

@@ -40,7 +40,8 @@ def _project_oracle(O, sc, v):
 
 def _project_gpu(sc, v):
     g = sc.to(DEV)
-    return P.ProjectGaussians.apply(g.means, g.scales.exp(), 1, g.quats, v.viewmat[:3].to(DEV),
+    # exp() on the CPU: torch's CPU and GPU exp differ in the last bit, the inputs must be identical
+    return P.ProjectGaussians.apply(g.means, sc.scales.exp().to(DEV), 1, g.quats, v.viewmat[:3].to(DEV),
                                     v.projmat.to(DEV), v.fx, v.fy, v.cx, v.cy, v.height, v.width,
                                     v.tile_bounds)
 
@@ -242,7 +243,7 @@ def test_project_bwd(oracle, n, h, w):
                              _np(v.viewmat[:3]), _np(v.projmat), v.fx, v.fy, v.cx, v.cy, h, w,
                              ref_fwd[2], ref_fwd[3], v_xy, v_depth, v_conic)
     g = sc.to(DEV)
-    m, s, q = (g.means.requires_grad_(True), g.scales.exp().detach().requires_grad_(True),
+    m, s, q = (g.means.requires_grad_(True), sc.scales.exp().to(DEV).requires_grad_(True),
                g.quats.requires_grad_(True))
     outs = P.ProjectGaussians.apply(m, s, 1, q, v.viewmat[:3].to(DEV), v.projmat.to(DEV), v.fx, v.fy,
                                     v.cx, v.cy, h, w, v.tile_bounds)
@@ -252,37 +253,70 @@ def test_project_bwd(oracle, n, h, w):
         assert_close(_np(got), r, f"project_bwd.{name}", rtol=1e-4, atol_frac=1e-5)
 
 
+def _activated_leaves(act, dev):
+    out = {}
+    for k, v in act.items():
+        v = v() if callable(v) else v
+        out[k] = v.detach().to(dev).requires_grad_(k not in ("viewdirs",))
+    return out
+
+
 @pytest.mark.parametrize("n,h,w,d", [(3000, 96, 128, 32), (50000, 300, 400, 32)])
-def test_reference_call_sequence_vs_oracle(oracle, n, h, w, d):
-    """The whole get_outputs sequence (project, SH, 4 rasterize calls) + one backward with dense
-    seeded cotangents, HIP operators vs oracle-backed operators: images bit-exact, parameter
-    gradients within 3e-5*max|grad| + 2e-3*|grad|; xys.grad is populated."""
+def test_operator_sequence_bitexact_vs_oracle(oracle, n, h, w, d):
+    """The reference's operator sequence (project, SH, 4 rasterize calls) on IDENTICAL activated
+    inputs (activations computed once on the CPU), HIP operators vs oracle-backed operators:
+    all four images bit-exact; gradients w.r.t. every operator input within
+    3e-5*max|grad| + 2e-3*|grad|; xys.grad populated; one sort for four calls."""
     import oracle_ops
+    from gaussiangrasper_amd.pipeline import activate, rasterize_activated
     sc, v = _scene_view(n, h, w, feature_dim=d)
-    # oracle side (CPU)
-    sc_c = sc.to("cpu")
-    for p in sc_c.params():
-        p.requires_grad_(True)
-    out_c = render_view(sc_c, v, oracle_ops)
+    act = activate(sc, v, oracle_ops.quat_to_rotmat)
+    a_c, a_g = _activated_leaves(act, "cpu"), _activated_leaves(act, DEV)
+    out_c = rasterize_activated(a_c, v, oracle_ops)
     cot = seeded_cotangents(out_c, seed=7)
     backward_view(out_c, cot)
-    # HIP side
     P.clear_bin_cache()
-    sc_g = sc.to(DEV)
-    for p in sc_g.params():
-        p.requires_grad_(True)
-    vg = ring_cameras(3, h, w, device=DEV)[0]
-    out_g = render_view(sc_g, vg, P)
+    hits0 = P.bin_cache_stats["hits"]
+    out_g = rasterize_activated(a_g, v, P)
     backward_view(out_g, {k: t.to(DEV) for k, t in cot.items()})
     for k in ("rgb", "feature", "depth", "normal"):
         assert_bitexact(_np(out_g[k]), _np(out_c[k]), f"image.{k}")
     assert_bitexact(_np(out_g["radii"]), _np(out_c["radii"]), "radii")
     assert out_g["xys"].grad is not None and out_g["xys"].grad.abs().sum() > 0
     assert_close(_np(out_g["xys"].grad), _np(out_c["xys"].grad), "xys.grad", rtol=2e-3, atol_frac=3e-5)
+    for name in ("means", "scales", "quats", "opac", "sh", "feature", "normals"):
+        assert_close(_np(a_g[name].grad), _np(a_c[name].grad), f"grad.{name}", rtol=2e-3, atol_frac=3e-5)
+    assert P.bin_cache_stats["hits"] - hits0 == 3  # one sort shared by the four rasterize calls
+
+
+def test_full_host_path_vs_oracle(oracle):
+    """render_view() end to end from raw parameters on both sides.  The caller-side activations
+    (exp, sigmoid, normalise) run in torch on each device and differ in the last bit, so this
+    test uses tolerances: radii identical, >= 99.99 % of image values within 1e-5 (BASELINE bar),
+    none off by more than 2e-2 (an alpha-threshold flip), parameter gradients within
+    1e-4*max|grad| + 5e-3*|grad|."""
+    import oracle_ops
+    n, h, w = 20000, 192, 256
+    sc, v = _scene_view(n, h, w)
+    sc_c = sc.to("cpu")
+    for p in sc_c.params():
+        p.requires_grad_(True)
+    out_c = render_view(sc_c, v, oracle_ops)
+    cot = seeded_cotangents(out_c, seed=7)
+    backward_view(out_c, cot)
+    P.clear_bin_cache()
+    sc_g = sc.to(DEV)
+    for p in sc_g.params():
+        p.requires_grad_(True)
+    out_g = render_view(sc_g, v, P)
+    backward_view(out_g, {k: t.to(DEV) for k, t in cot.items()})
+    assert_bitexact(_np(out_g["radii"]), _np(out_c["radii"]), "radii")
+    for k in ("rgb", "feature", "depth", "normal"):
+        d = np.abs(_np(out_g[k]).astype(np.float64) - _np(out_c[k]))
+        assert (d > 1e-5).mean() < 1e-4 and d.max() < 2e-2, (k, (d > 1e-5).mean(), d.max())
     for name, pg, pc in zip(("means", "scales", "quats", "opacities", "colors_all", "feature"),
                             sc_g.params(), sc_c.params()):
-        assert_close(_np(pg.grad), _np(pc.grad), f"grad.{name}", rtol=2e-3, atol_frac=3e-5)
-    assert P.bin_cache_stats["hits"] >= 3  # one sort shared by the four rasterize calls
+        assert_close(_np(pg.grad), _np(pc.grad), f"grad.{name}", rtol=5e-3, atol_frac=1e-4)
 
 
 def test_no_intersections_returns_background():

@@ -1,0 +1,482 @@
+// blend2.hip — second-generation blend kernels (same results as blend.hip's, ~2-3x fewer stalls).
+//
+// What the first generation measured (profiles/r01_v1_*, PMC passes): only ~28 % of wave-cycles
+// issue an instruction; SALU instruction count is ~70 % of VALU; the rest is s_waitcnt and
+// dependency stalls of a branchy one-Gaussian-at-a-time loop (s_ff1 / 8x v_readlane / ballots /
+// scalar colour loads waited on inside every iteration).  The engine here keeps the exact
+// per-(pixel, Gaussian) arithmetic and restructures everything around it:
+//
+//   * chunk staging (64 list entries, one per lane) + exact ellipse-vs-quadrant cull as before,
+//     but the survivors are COMPACTED INTO LDS in depth order (mbcnt prefix of the ballot), so the
+//     walk is a plain counted loop and the per-Gaussian record reaches every lane through
+//     wave-uniform ds_read_b128 broadcasts — no readlane, no mask juggling;
+//   * the walk handles FOUR survivors per iteration: sigma / gg_expf / alpha of the four are
+//     independent instruction streams (ILP hides the VALU latency a single chain exposes), only the
+//     T recurrence is sequential, and it is branch-free (selects), so there is ONE scalar branch per
+//     four Gaussians instead of ~6 per Gaussian;
+//   * narrow calls (<= 3 channels: rgb / depth / normal) carry the colours inside the LDS record;
+//   * 32-channel chunks accumulate on the matrix pipe: out[p][c] += vis[p][g]*colour[g][c] is
+//     v_mfma_f32_32x32x2_f32 with the two Gaussians of a pair as the k index — an exact fp32 fma
+//     chain in list order, i.e. bit-identical to the oracle's sequential fmaf, at no VALU cost.
+//     The A operand (vis of 2 Gaussians x 64 pixels) is one v_permlane32_swap; the B operand is one
+//     coalesced 2x128-byte colour load per pair.
+//
+// Bit-exactness: blended contributions are `acc = fma(colour, vis, acc)` with vis = 0 for pixels
+// that skip the Gaussian; fma(c, 0, acc) == acc for finite c, so the unconditional form equals
+// the oracle's conditional one (colours must be finite, as everywhere).
+#include "blend_common.h"
+
+#define GRP 4          // survivors per loop iteration
+#define LIST_CAP 72    // 4 leading pads + 64 + 4 trailing pads
+
+struct WaveList {
+    float4 a[LIST_CAP];  // x, y, opacity, (unused)
+    float4 b[LIST_CAP];  // conic a, b, c, (unused)
+    float4 c[LIST_CAP];  // narrow: colours 0..2 ; wide: .x = Gaussian id (int bits). .w = list position + 1
+};
+
+__device__ __forceinline__ int lane_prefix(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// Stage one chunk: returns the survivor count; list[OFF + k] = k-th survivor in list order,
+// GRP null records (opacity 0 -> never pass) on both sides.
+template <int CH, bool WIDE>
+__device__ __forceinline__ int stage_chunk(WaveList &L, int lane, int e, bool valid,
+                                           const int32_t *__restrict__ ids,
+                                           const GRec *__restrict__ rec,
+                                           const float *__restrict__ colors, int C, int ch_off, int nch,
+                                           float xlo, float xhi, float ylo, float yhi) {
+    const int g = valid ? ids[e] : 0;
+    const float4 ra = reinterpret_cast<const float4 *>(rec + g)[0];
+    const float4 rb = reinterpret_cast<const float4 *>(rec + g)[1];
+    const bool hit = valid && rec_hits_rect(ra, rb, xlo, xhi, ylo, yhi);
+    const uint64_t m = __ballot(hit);
+    const int cnt = __builtin_popcountll(m);
+    const int pos = GRP + lane_prefix(m);
+    if (hit) {
+        float4 cc = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, e + 1));
+        if (WIDE) {
+            cc.x = __builtin_bit_cast(float, g);
+        } else {
+            const float *col = colors + (size_t)g * C + ch_off;
+            cc.x = col[0];
+            if (CH > 1 && nch > 1) cc.y = col[1];
+            if (CH > 2 && nch > 2) cc.z = col[2];
+        }
+        L.a[pos] = ra;
+        L.b[pos] = rb;
+        L.c[pos] = cc;
+    }
+    if (lane < 2 * GRP) {  // null pads: opacity 0, conic 0 -> alpha = 0 < 1/255
+        const int q = (lane < GRP) ? lane : (cnt + lane);
+        L.a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        L.b[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        L.c[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return cnt;
+}
+
+// =============================================================================================
+// forward
+// =============================================================================================
+template <int CH, bool WIDE, bool FULL>
+__global__ __launch_bounds__(256) void blend2_fwd_kernel(
+    int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
+    const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
+    const float *__restrict__ colors, const float *__restrict__ background,
+    float *__restrict__ out_img, float *__restrict__ final_T, int32_t *__restrict__ final_idx,
+    int write_final) {
+    __shared__ WaveList lists[4];
+    const int tile = xcd_tile(blockIdx.x, ntiles);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    WaveList &L = lists[wave];
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int qx0 = tx * GG_BLOCK + (wave & 1) * 8, qy0 = ty * GG_BLOCK + (wave >> 1) * 8;
+    const int j = qx0 + (lane & 7), i = qy0 + (lane >> 3);
+    const bool inside = (i < img_h) && (j < img_w);
+    const float px = (float)j, py = (float)i;
+    const float xlo = (float)qx0, xhi = (float)(qx0 + 7), ylo = (float)qy0, yhi = (float)(qy0 + 7);
+    const int2 range = bins[tile];
+
+    float T = 1.0f;
+    int last = range.x;
+    bool done = !inside;
+    float acc[WIDE ? 1 : CH];
+    f32x16 acc0, acc1;  // WIDE: pixels 0-31 / 32-63 of the quadrant x 32 channels
+#pragma unroll
+    for (int c = 0; c < (WIDE ? 1 : CH); ++c) acc[c] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+    const int wch = lane & 31, half = lane >> 5;
+    const bool wch_ok = FULL || wch < nch;
+
+    for (int base = range.x; base < range.y; base += 64) {
+        if (__ballot(!done) == 0ull) break;
+        const int e = base + lane;
+        const int cnt = stage_chunk<CH, WIDE>(L, lane, e, e < range.y, ids, rec, colors, C, ch_off,
+                                              nch, xlo, xhi, ylo, yhi);
+        for (int k = 0; k < cnt; k += GRP) {
+            if (k > 0 && __ballot(!done) == 0ull) break;
+            float4 A[GRP], B[GRP], Cc[GRP];
+#pragma unroll
+            for (int q = 0; q < GRP; ++q) {
+                A[q] = L.a[GRP + k + q];
+                B[q] = L.b[GRP + k + q];
+                Cc[q] = L.c[GRP + k + q];
+            }
+            float colB[GRP / 2];
+            if (WIDE) {
+#pragma unroll
+                for (int pr = 0; pr < GRP / 2; ++pr) {
+                    // lanes 0-31 fetch the colour row of the even Gaussian, 32-63 of the odd one
+                    const int gid = __builtin_bit_cast(int, L.c[GRP + k + 2 * pr + half].x);
+                    colB[pr] = wch_ok ? colors[(size_t)gid * C + ch_off + wch] : 0.0f;
+                }
+            }
+            float alpha[GRP];
+            bool pass[GRP];
+#pragma unroll
+            for (int q = 0; q < GRP; ++q) {
+                const float dx = A[q].x - px, dy = A[q].y - py;
+                const float sigma = __builtin_fmaf(
+                    0.5f, __builtin_fmaf(B[q].x * dx, dx, (B[q].z * dy) * dy), (B[q].y * dx) * dy);
+                alpha[q] = fminf(GG_ALPHA_MAX_FWD, A[q].z * gg_expf(-sigma));
+                pass[q] = sigma >= 0.0f && !(alpha[q] < GG_ALPHA_MIN);
+            }
+            float vis[GRP];
+#pragma unroll
+            for (int q = 0; q < GRP; ++q) {
+                const float next_T = T * (1.0f - alpha[q]);
+                const bool live = pass[q] && !done;
+                const bool stop = live && (next_T <= GG_T_EPS);
+                const bool blend = live && !stop;
+                vis[q] = blend ? alpha[q] * T : 0.0f;
+                T = blend ? next_T : T;
+                last = blend ? __builtin_bit_cast(int, Cc[q].w) : last;
+                done = done || stop;
+                if (!WIDE) {
+                    acc[0] = __builtin_fmaf(Cc[q].x, vis[q], acc[0]);
+                    if (CH > 1) acc[CH > 1 ? 1 : 0] = __builtin_fmaf(Cc[q].y, vis[q], acc[CH > 1 ? 1 : 0]);
+                    if (CH > 2) acc[CH > 2 ? 2 : 0] = __builtin_fmaf(Cc[q].z, vis[q], acc[CH > 2 ? 2 : 0]);
+                }
+            }
+            if (WIDE) {
+#pragma unroll
+                for (int pr = 0; pr < GRP / 2; ++pr) {
+                    auto r = __builtin_amdgcn_permlane32_swap(
+                        __builtin_bit_cast(unsigned, vis[2 * pr]),
+                        __builtin_bit_cast(unsigned, vis[2 * pr + 1]), false, false);
+                    // r[0]: pixels 0-31 x {even, odd} Gaussian ; r[1]: pixels 32-63 x {even, odd}
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, (unsigned)r[0]),
+                                                                colB[pr], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, (unsigned)r[1]),
+                                                                colB[pr], acc1, 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // list is rewritten by the next chunk
+    }
+    if (inside && write_final) {
+        const size_t p = (size_t)i * img_w + j;
+        final_T[p] = T;
+        final_idx[p] = last;
+    }
+    if (!WIDE) {
+        if (inside) {
+            float *o = out_img + ((size_t)i * img_w + j) * C + ch_off;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                if (c < nch) o[c] = __builtin_fmaf(T, background[ch_off + c], acc[c]);
+        }
+    } else {
+        const float bgc = wch_ok ? background[ch_off + wch] : 0.0f;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pq = 32 * blk + (r & 3) + 8 * (r >> 2) + 4 * half;  // pixel of this value
+                const float Tp = __shfl(T, pq, 64);
+                const int pj = qx0 + (pq & 7), pi = qy0 + (pq >> 3);
+                if (pi < img_h && pj < img_w && wch_ok)
+                    out_img[((size_t)pi * img_w + pj) * C + ch_off + wch] =
+                        __builtin_fmaf(Tp, bgc, blk ? acc1[r] : acc0[r]);
+            }
+    }
+}
+
+// =============================================================================================
+// backward
+// =============================================================================================
+#define B2_SLOTS 32
+#define B2_FSTRIDE 65
+
+// NARROW: CH <= 3, colours in the record, all CH+6 partials of the four Gaussians of a group go
+//         through ONE register butterfly (Red<4*(CH+6)>).
+// WIDE  : CH = 32 chunk; colours by wave-uniform scalar loads for D = <colour, v_out>, colour
+//         gradients through LDS-parked fac + v_mfma_f32_32x32x2_f32 (see blend.hip v1 wide kernel),
+//         the 4*6 geometry partials through one butterfly.
+template <int CH, bool WIDE, bool FULL>
+__global__ __launch_bounds__(256) void blend2_bwd_kernel(
+    int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
+    const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
+    const float *__restrict__ colors, const float *__restrict__ background,
+    const float *__restrict__ final_T, const int32_t *__restrict__ final_idx,
+    const float *__restrict__ v_out, float *__restrict__ v_xy, float *__restrict__ v_conic,
+    float *__restrict__ v_colors, float *__restrict__ v_opacity) {
+    constexpr int KC = WIDE ? 0 : CH;   // colour partials that go through the butterfly
+    constexpr int KG = KC + 6;          // per-Gaussian values in the butterfly
+    constexpr int KB = GRP * KG;        // butterfly width
+    constexpr int K = CH + 6;           // slab row: CH colours, xy(2), conic(3), opacity(1)
+    constexpr int KP = (K + 3) & ~3;
+    using R = Red<KB>;
+    __shared__ WaveList lists[4];
+    __shared__ float slab[BW_BATCH][KP];
+    __shared__ float s_fac[WIDE ? 4 : 1][WIDE ? B2_SLOTS * B2_FSTRIDE : 1];
+    __shared__ int s_slotrow[4][B2_SLOTS];
+    __shared__ int s_gid[BW_BATCH];
+    __shared__ int s_flag[BW_BATCH];
+    __shared__ int s_hi[4];
+
+    const int tile = xcd_tile(blockIdx.x, ntiles);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    WaveList &L = lists[wave];
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int qx0 = tx * GG_BLOCK + (wave & 1) * 8, qy0 = ty * GG_BLOCK + (wave >> 1) * 8;
+    const int j = qx0 + (lane & 7), i = qy0 + (lane >> 3);
+    const bool inside = (i < img_h) && (j < img_w);
+    const float px = (float)j, py = (float)i;
+    const float xlo = (float)qx0, xhi = (float)(qx0 + 7), ylo = (float)qy0, yhi = (float)(qy0 + 7);
+    const int2 range = bins[tile];
+    const size_t p = inside ? ((size_t)i * img_w + j) : 0;
+    float *fac_w = s_fac[WIDE ? wave : 0];
+    int *slotrow_w = s_slotrow[wave];
+
+    const float T_final = inside ? final_T[p] : 1.0f;
+    const int fin = inside ? final_idx[p] : range.x;
+    float T = T_final;
+    float vo[CH];
+    float W;
+    {
+        float Bsum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            vo[c] = (inside && (FULL || c < nch)) ? v_out[p * C + ch_off + c] : 0.0f;
+            if (FULL || c < nch) Bsum = __builtin_fmaf(background[ch_off + c], vo[c], Bsum);
+        }
+        W = T_final * Bsum;
+    }
+    float vob[WIDE ? 32 : 1];
+    if (WIDE) {
+        const int cch = lane & 31, hf = lane >> 5;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int pq = 2 * s + hf;
+            const int pj = qx0 + (pq & 7), pi = qy0 + (pq >> 3);
+            const bool ok = (pi < img_h) && (pj < img_w) && (FULL || cch < nch);
+            vob[s] = ok ? v_out[((size_t)pi * img_w + pj) * C + ch_off + cch] : 0.0f;
+        }
+    }
+    int hi = fin;
+    for (int off = 32; off > 0; off >>= 1) hi = max(hi, __shfl_xor(hi, off, 64));
+    if (lane == 0) s_hi[wave] = hi;
+    for (int t = threadIdx.x; t < BW_BATCH * KP; t += 256) (&slab[0][0])[t] = 0.0f;
+    if (threadIdx.x < BW_BATCH) s_flag[threadIdx.x] = 0;
+    __syncthreads();
+    const int block_hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+
+    // butterfly result map: which (group member, value) does this lane own?
+    const int b4 = (lane >> 4) & 1, b5 = lane >> 5, r16 = lane & 15;
+    bool owner = false;
+    int myvar = 0;
+    if (r16 < R::H2) myvar = R::var(r16, b4, b5, owner);
+    owner = owner && (r16 < R::H2);
+    const int my_q = myvar / KG, my_k = myvar - my_q * KG;
+    // slab column of my value: colours first (narrow), then the 6 geometry values after CH colours
+    const int my_col = (my_k < KC) ? my_k : (CH + (my_k - KC));
+
+    int nslots = 0;
+    auto flush_slots = [&]() {
+        if (WIDE) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const float *arow = fac_w + (lane & 31) * B2_FSTRIDE + (lane >> 5);
+#pragma unroll
+            for (int s = 0; s < 32; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * s], vob[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int slot = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (slot < nslots) atomicAdd(&slab[slotrow_w[slot]][lane & 31], acc[r]);
+            }
+        }
+        nslots = 0;
+    };
+
+    for (int top = block_hi; top > range.x; top -= BW_BATCH) {
+        const int e = top - BW_BATCH + lane;
+        const bool valid = (e >= range.x) && (e < hi);
+        if (wave == 0) s_gid[lane] = (e >= range.x) ? ids[e] : 0;
+        const int cnt = stage_chunk<CH, WIDE>(L, lane, e, valid, ids, rec, colors, C, ch_off, nch,
+                                              xlo, xhi, ylo, yhi);
+        // survivors sit at L[GRP .. GRP+cnt); walk them back to front, four at a time;
+        // member q of a group is list slot (kk - q): q = 0 is the farthest of the four.
+        for (int kk = GRP + cnt - 1; kk >= GRP; kk -= GRP) {
+            float4 A[GRP], B[GRP], Cc[GRP];
+#pragma unroll
+            for (int q = 0; q < GRP; ++q) {
+                A[q] = L.a[kk - q];
+                B[q] = L.b[kk - q];
+                Cc[q] = L.c[kk - q];
+            }
+            float vis[GRP], alpha[GRP], dxs[GRP], dys[GRP];
+            bool pass[GRP];
+            int srcs[GRP];
+#pragma unroll
+            for (int q = 0; q < GRP; ++q) {
+                const float dx = A[q].x - px, dy = A[q].y - py;
+                dxs[q] = dx;
+                dys[q] = dy;
+                const float sigma = __builtin_fmaf(
+                    0.5f, __builtin_fmaf(B[q].x * dx, dx, (B[q].z * dy) * dy), (B[q].y * dx) * dy);
+                vis[q] = gg_expf(-sigma);
+                alpha[q] = fminf(GG_ALPHA_MAX_BWD, A[q].z * vis[q]);
+                const int idx = __builtin_bit_cast(int, Cc[q].w) - 1;  // -1 for null pads
+                srcs[q] = idx - (top - BW_BATCH);
+                pass[q] = (idx >= 0) && (idx < fin) && sigma >= 0.0f && !(alpha[q] < GG_ALPHA_MIN);
+            }
+            if (__ballot(pass[0] || pass[1] || pass[2] || pass[3]) == 0ull) continue;
+
+            float part[KB];
+#pragma unroll
+            for (int q = 0; q < GRP; ++q) {
+                const float ra_ = __builtin_amdgcn_rcpf(1.0f - alpha[q]);
+                const float Tn = T * ra_;
+                const float fac = pass[q] ? alpha[q] * Tn : 0.0f;
+                float D;
+                if (!WIDE) {
+                    D = Cc[q].x * vo[0];
+                    if (CH > 1) D = __builtin_fmaf(Cc[q].y, vo[CH > 1 ? 1 : 0], D);
+                    if (CH > 2) D = __builtin_fmaf(Cc[q].z, vo[CH > 2 ? 2 : 0], D);
+#pragma unroll
+                    for (int c = 0; c < KC; ++c) part[q * KG + c] = fac * vo[c];
+                } else {
+                    const int gid = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, Cc[q].x));
+                    const float *col = colors + (size_t)gid * C + ch_off;
+                    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;  // 4 chains: latency, not order
+#pragma unroll
+                    for (int c = 0; c < CH; c += 4) {
+                        d0 = __builtin_fmaf((FULL || c + 0 < nch) ? col[c + 0] : 0.f, vo[c + 0], d0);
+                        d1 = __builtin_fmaf((FULL || c + 1 < nch) ? col[c + 1] : 0.f, vo[c + 1], d1);
+                        d2 = __builtin_fmaf((FULL || c + 2 < nch) ? col[c + 2] : 0.f, vo[c + 2], d2);
+                        d3 = __builtin_fmaf((FULL || c + 3 < nch) ? col[c + 3] : 0.f, vo[c + 3], d3);
+                    }
+                    D = (d0 + d1) + (d2 + d3);
+                }
+                const float v_alpha = pass[q] ? (Tn * D - ra_ * W) : 0.0f;
+                W = pass[q] ? __builtin_fmaf(D, fac, W) : W;
+                T = pass[q] ? Tn : T;
+                const float v_sigma = pass[q] ? (-A[q].z * vis[q]) * v_alpha : 0.0f;
+                const float dx = dxs[q], dy = dys[q];
+                float *pg = part + q * KG + KC;
+                pg[0] = v_sigma * (B[q].x * dx + B[q].y * dy);
+                pg[1] = v_sigma * (B[q].y * dx + B[q].z * dy);
+                const float hs = 0.5f * v_sigma;
+                pg[2] = (hs * dx) * dx;
+                pg[3] = (hs * dx) * dy;
+                pg[4] = (hs * dy) * dy;
+                pg[5] = pass[q] ? vis[q] * v_alpha : 0.0f;
+                if (WIDE) {
+                    // wave-uniform: does this Gaussian get a colour-gradient row?
+                    if (__ballot(pass[q]) != 0ull) {
+                        fac_w[nslots * B2_FSTRIDE + lane] = fac;
+                        if (lane == 0) slotrow_w[nslots] = srcs[q];
+                        ++nslots;
+                        if (nslots == B2_SLOTS) flush_slots();
+                    }
+                }
+            }
+            float red[R::H2];
+            R::run(part, red);
+            float mine = red[0];
+#pragma unroll
+            for (int q = 1; q < R::H2; ++q) mine = (r16 == q) ? red[q] : mine;
+            // row of my group member (wave-uniform values, per-lane select)
+            int my_src = srcs[0];
+#pragma unroll
+            for (int q = 1; q < GRP; ++q) my_src = (my_q == q) ? srcs[q] : my_src;
+            if (owner && my_src >= 0 && my_src < BW_BATCH) {
+                atomicAdd(&slab[my_src][my_col], mine);
+                if (my_k == KG - 1) s_flag[my_src] = 1;
+            }
+        }
+        if (nslots > 0) flush_slots();
+        __syncthreads();
+        {
+            constexpr int RPI = 64 / K;
+            const int rsub = lane / K, k = lane - rsub * K;
+            for (int row0 = wave * RPI; row0 < BW_BATCH; row0 += 4 * RPI) {
+                const int row = row0 + rsub;
+                if (rsub < RPI && row < BW_BATCH && s_flag[row]) {
+                    const int gid = s_gid[row];
+                    const float val = slab[row][k];
+                    slab[row][k] = 0.0f;
+                    float *dst;
+                    if (k < CH) dst = v_colors + (size_t)gid * C + ch_off + k;
+                    else if (k < CH + 2) dst = v_xy + 2 * (size_t)gid + (k - CH);
+                    else if (k < CH + 5) dst = v_conic + 3 * (size_t)gid + (k - CH - 2);
+                    else dst = v_opacity + gid;
+                    if (k >= CH || k < nch) atomicAdd(dst, val);
+                    if (k == 0) s_flag[row] = 0;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// =============================================================================================
+// launchers used by the C ABI in blend.hip
+// =============================================================================================
+#define B2_FWD_ARGS C, off, n, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, \
+                    out_img, final_Ts, final_idx, write_final
+void gg_launch_blend2_fwd(int width, int C, int off, int n, int img_h, int img_w, int tiles_x,
+                          int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
+                          const float *colors, const float *background, float *out_img,
+                          float *final_Ts, int32_t *final_idx, int write_final, hipStream_t s) {
+    dim3 grid(ntiles), block(256);
+    if (width == 1)
+        hipLaunchKernelGGL((blend2_fwd_kernel<1, false, true>), grid, block, 0, s, B2_FWD_ARGS);
+    else if (width == 2)
+        hipLaunchKernelGGL((blend2_fwd_kernel<2, false, true>), grid, block, 0, s, B2_FWD_ARGS);
+    else if (width == 3)
+        hipLaunchKernelGGL((blend2_fwd_kernel<3, false, true>), grid, block, 0, s, B2_FWD_ARGS);
+    else if (n == 32)
+        hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true>), grid, block, 0, s, B2_FWD_ARGS);
+    else
+        hipLaunchKernelGGL((blend2_fwd_kernel<32, true, false>), grid, block, 0, s, B2_FWD_ARGS);
+}
+
+#define B2_BWD_ARGS C, off, n, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, \
+                    final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity
+void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w, int tiles_x,
+                          int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
+                          const float *colors, const float *background, const float *final_Ts,
+                          const int32_t *final_idx, const float *v_out, float *v_xy, float *v_conic,
+                          float *v_colors, float *v_opacity, hipStream_t s) {
+    dim3 grid(ntiles), block(256);
+    if (width == 1)
+        hipLaunchKernelGGL((blend2_bwd_kernel<1, false, true>), grid, block, 0, s, B2_BWD_ARGS);
+    else if (width == 2)
+        hipLaunchKernelGGL((blend2_bwd_kernel<2, false, true>), grid, block, 0, s, B2_BWD_ARGS);
+    else if (width == 3)
+        hipLaunchKernelGGL((blend2_bwd_kernel<3, false, true>), grid, block, 0, s, B2_BWD_ARGS);
+    else if (n == 32)
+        hipLaunchKernelGGL((blend2_bwd_kernel<32, true, true>), grid, block, 0, s, B2_BWD_ARGS);
+    else
+        hipLaunchKernelGGL((blend2_bwd_kernel<32, true, false>), grid, block, 0, s, B2_BWD_ARGS);
+}

@@ -1,0 +1,96 @@
+// blend_common.h — device helpers shared by the blend kernels (blend.hip: v1 kernels + C ABI,
+// blend2.hip: v2 kernels).
+#pragma once
+#include "gg_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define BW_BATCH 64
+
+struct __attribute__((aligned(16))) GRec {
+    float x, y, opac, thr;  // thr: sigma above which alpha < 1/255 for certain (conservative)
+    float ca, cb, cc, pad;
+};
+
+
+// tile index from block index: blocks are dealt round-robin to the 8 XCDs, so give each XCD a
+// contiguous run of tiles (neighbouring tiles share Gaussians -> hits in that XCD's L2).
+__device__ __forceinline__ int xcd_tile(int bid, int ntiles) {
+    int q = ntiles >> 3, r = ntiles & 7, x = bid & 7, k = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+// Does the alpha>=1/255 ellipse of a record reach the pixel rectangle [xlo,xhi]x[ylo,yhi]?
+// Exact in real arithmetic: sigma is a convex quadratic, so its minimum over the rectangle is 0
+// if the centre is inside and otherwise lies on one of the (at most two) edges facing the centre;
+// on an edge the minimiser along the free coordinate is the clamped 1-D optimum.  The record's
+// cut-off already carries the rounding margin, and the continuous minimum is <= the minimum over
+// the pixel centres, so the test never rejects a pair the exact per-pixel test would accept.
+__device__ __forceinline__ float sigma_at(const float4 b, float dx, float dy) {
+    return 0.5f * (b.x * dx * dx + b.z * dy * dy) + b.y * dx * dy;
+}
+__device__ __forceinline__ bool rec_hits_rect(const float4 a, const float4 b, float xlo, float xhi,
+                                              float ylo, float yhi) {
+    const float thr = a.w;
+    if (thr < 0.0f) return false;
+    // the argument needs a positive-definite conic (always true for projected Gaussians: the 0.3
+    // blur); anything else is never culled
+    if (!(b.x > 0.0f) || !(b.x * b.z - b.y * b.y > 0.0f)) return true;
+    // d = centre - pixel, with the pixel ranging over the rectangle
+    const float dx_lo = a.x - xhi, dx_hi = a.x - xlo, dy_lo = a.y - yhi, dy_hi = a.y - ylo;
+    const float dxn = fminf(fmaxf(0.0f, dx_lo), dx_hi);  // |d| nearest to 0 inside the range
+    const float dyn = fminf(fmaxf(0.0f, dy_lo), dy_hi);
+    // edge x = nearest x: dy free
+    const float dy1 = fminf(fmaxf(-b.y * dxn * __builtin_amdgcn_rcpf(b.z), dy_lo), dy_hi);
+    // edge y = nearest y: dx free
+    const float dx2 = fminf(fmaxf(-b.y * dyn * __builtin_amdgcn_rcpf(b.x), dx_lo), dx_hi);
+    const float smin = fminf(sigma_at(b, dxn, dy1), sigma_at(b, dx2, dyn));
+    return !(smin > thr);  // NaN (degenerate conic) -> hit, conservative
+}
+
+
+__device__ __forceinline__ float dpp_xadd_row(float v) {
+    // all-reduce inside each 16-lane row: quad xor1, quad xor2, half mirror, row mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+    return v;
+}
+__device__ __forceinline__ float swap_add32(float a, float b) {
+    // lanes 0-31: a(own) + a(lane+32) ; lanes 32-63: b(lane-32) + b(own)
+    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a),
+                                              __builtin_bit_cast(unsigned, b), false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float swap_add16(float a, float b) {
+    // even rows: a(own) + a(lane+16) ; odd rows: b(lane-16) + b(own)
+    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a),
+                                              __builtin_bit_cast(unsigned, b), false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
+// Halving butterfly: K per-lane values -> H2 registers; afterwards the 16 lanes of row
+// (b5,b4) all hold, in register j, the wave total of value red_var<K>(j,b4,b5).
+template <int K>
+struct Red {
+    static constexpr int H1 = (K + 1) / 2;
+    static constexpr int H2 = (H1 + 1) / 2;
+    __device__ static __forceinline__ void run(const float (&v)[K], float (&out)[H2]) {
+        float a[H1];
+#pragma unroll
+        for (int j = 0; j < H1; ++j) a[j] = swap_add32(v[j], (j + H1 < K) ? v[j + H1] : v[j]);
+#pragma unroll
+        for (int j = 0; j < H2; ++j)
+            out[j] = dpp_xadd_row(swap_add16(a[j], (j + H2 < H1) ? a[j + H2] : a[j]));
+    }
+    // which value does (register j, row bits b4,b5) hold, and is this row its unique owner?
+    __device__ static __forceinline__ int var(int j, int b4, int b5, bool &owner) {
+        owner = true;
+        int i = j;
+        if (j + H2 < H1) i = j + H2 * b4; else owner = owner && (b4 == 0);
+        int k = i;
+        if (i + H1 < K) k = i + H1 * b5; else owner = owner && (b5 == 0);
+        return k;
+    }
+};
+

@@ -31,7 +31,7 @@ void gg_set_error(const char *fmt, ...);
 void gg_prof_begin(int kernel_id, hipStream_t s);
 void gg_prof_end(int kernel_id, hipStream_t s);
 static inline int gg_width_index(int w) {
-    return w <= 1 ? 0 : w == 3 ? 1 : w == 4 ? 2 : w == 8 ? 3 : w == 16 ? 4 : 5;
+    return w <= 1 ? 0 : w <= 3 ? 1 : w == 4 ? 2 : w == 8 ? 3 : w == 16 ? 4 : 5;
 }
 
 static inline size_t gg_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

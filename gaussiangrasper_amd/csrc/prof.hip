@@ -20,7 +20,7 @@ void gg_prof_begin(int id, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);
     Pair p{id, nullptr, nullptr, true};
     if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
-    hipEventRecord(p.a, s);
+    (void)hipEventRecord(p.a, s);
     g_pairs.push_back(p);
 }
 void gg_prof_end(int id, hipStream_t s) {
@@ -28,7 +28,7 @@ void gg_prof_end(int id, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (size_t i = g_pairs.size(); i-- > 0;)
         if (g_pairs[i].id == id && g_pairs[i].open) {
-            hipEventRecord(g_pairs[i].b, s);
+            (void)hipEventRecord(g_pairs[i].b, s);
             g_pairs[i].open = false;
             return;
         }
@@ -42,8 +42,8 @@ extern "C" int gg_prof_enable(int on) {
 extern "C" int gg_prof_reset(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto &p : g_pairs) {
-        hipEventDestroy(p.a);
-        hipEventDestroy(p.b);
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
     }
     g_pairs.clear();
     return GG_OK;

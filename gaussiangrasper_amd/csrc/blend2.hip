@@ -41,7 +41,7 @@ __device__ __forceinline__ int lane_prefix(uint64_t m) {
 
 // Stage one chunk: returns the survivor count; list[OFF + k] = k-th survivor in list order,
 // GRP null records (opacity 0 -> never pass) on both sides.
-template <int CH, bool WIDE>
+template <int CH, bool WIDE, bool REL = false>
 __device__ __forceinline__ int stage_chunk(WaveList &L, int lane, int e, bool valid,
                                            const int32_t *__restrict__ ids,
                                            const GRec *__restrict__ rec,
@@ -55,7 +55,8 @@ __device__ __forceinline__ int stage_chunk(WaveList &L, int lane, int e, bool va
     const int cnt = __builtin_popcountll(m);
     const int pos = GRP + lane_prefix(m);
     if (hit) {
-        float4 cc = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, e + 1));
+        // .w: forward = list position + 1 (final_idx); backward = position inside the chunk
+        float4 cc = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, REL ? lane : e + 1));
         if (WIDE) {
             cc.x = __builtin_bit_cast(float, g);
         } else {
@@ -65,13 +66,13 @@ __device__ __forceinline__ int stage_chunk(WaveList &L, int lane, int e, bool va
             if (CH > 2 && nch > 2) cc.z = col[2];
         }
         L.a[pos] = ra;
-        L.b[pos] = rb;
+        L.b[pos] = make_float4(rb.x, rb.y, rb.z, __builtin_bit_cast(float, g));  // .w = Gaussian id
         L.c[pos] = cc;
     }
     if (lane < 2 * GRP) {  // null pads: opacity 0, conic 0 -> alpha = 0 < 1/255
         const int q = (lane < GRP) ? lane : (cnt + lane);
         L.a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        L.b[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        L.b[q] = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, -1));
         L.c[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __builtin_amdgcn_wave_barrier();
@@ -208,37 +209,28 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
 }
 
 // =============================================================================================
-// backward
+// backward, narrow (<= 3 channels): wave-autonomous, no workgroup barrier, no LDS slab
 // =============================================================================================
-#define B2_SLOTS 32
-#define B2_FSTRIDE 65
-
-// NARROW: CH <= 3, colours in the record, all CH+6 partials of the four Gaussians of a group go
-//         through ONE register butterfly (Red<4*(CH+6)>).
-// WIDE  : CH = 32 chunk; colours by wave-uniform scalar loads for D = <colour, v_out>, colour
-//         gradients through LDS-parked fac + v_mfma_f32_32x32x2_f32 (see blend.hip v1 wide kernel),
-//         the 4*6 geometry partials through one butterfly.
-template <int CH, bool WIDE, bool FULL>
-__global__ __launch_bounds__(256) void blend2_bwd_kernel(
-    int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
+// Every wave walks its quadrant's part of the tile list back to front on its own, four survivors
+// per iteration.  All CH+6 partial gradients of the four Gaussians of a group go through ONE
+// register butterfly (Red<4*(CH+6)>), which leaves each of the 4*(CH+6) totals on its own lane;
+// those lanes add them straight into the gradient rows with ONE global float-atomic
+// wave-instruction per group (4 Gaussians x (CH+6) consecutive-ish floats).
+// Measured alternatives (profiles/README.md): combining the four waves of a tile through an LDS
+// slab with two __syncthreads() per chunk, and a wave-private slab flushed per chunk, were both
+// slower — the per-chunk flush loop costs more instructions than the atomics it saves.
+template <int CH>
+__global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
+    int C, int ch_off, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
     const float *__restrict__ colors, const float *__restrict__ background,
     const float *__restrict__ final_T, const int32_t *__restrict__ final_idx,
     const float *__restrict__ v_out, float *__restrict__ v_xy, float *__restrict__ v_conic,
     float *__restrict__ v_colors, float *__restrict__ v_opacity) {
-    constexpr int KC = WIDE ? 0 : CH;   // colour partials that go through the butterfly
-    constexpr int KG = KC + 6;          // per-Gaussian values in the butterfly
-    constexpr int KB = GRP * KG;        // butterfly width
-    constexpr int K = CH + 6;           // slab row: CH colours, xy(2), conic(3), opacity(1)
-    constexpr int KP = (K + 3) & ~3;
+    constexpr int K = CH + 6;       // per-Gaussian values: CH colours, xy(2), conic(3), opacity(1)
+    constexpr int KB = GRP * K;     // butterfly width
     using R = Red<KB>;
     __shared__ WaveList lists[4];
-    __shared__ float slab[BW_BATCH][KP];
-    __shared__ float s_fac[WIDE ? 4 : 1][WIDE ? B2_SLOTS * B2_FSTRIDE : 1];
-    __shared__ int s_slotrow[4][B2_SLOTS];
-    __shared__ int s_gid[BW_BATCH];
-    __shared__ int s_flag[BW_BATCH];
-    __shared__ int s_hi[4];
 
     const int tile = xcd_tile(blockIdx.x, ntiles);
     const int lane = threadIdx.x & 63;
@@ -252,8 +244,6 @@ __global__ __launch_bounds__(256) void blend2_bwd_kernel(
     const float xlo = (float)qx0, xhi = (float)(qx0 + 7), ylo = (float)qy0, yhi = (float)(qy0 + 7);
     const int2 range = bins[tile];
     const size_t p = inside ? ((size_t)i * img_w + j) : 0;
-    float *fac_w = s_fac[WIDE ? wave : 0];
-    int *slotrow_w = s_slotrow[wave];
 
     const float T_final = inside ? final_T[p] : 1.0f;
     const int fin = inside ? final_idx[p] : range.x;
@@ -264,67 +254,35 @@ __global__ __launch_bounds__(256) void blend2_bwd_kernel(
         float Bsum = 0.0f;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            vo[c] = (inside && (FULL || c < nch)) ? v_out[p * C + ch_off + c] : 0.0f;
-            if (FULL || c < nch) Bsum = __builtin_fmaf(background[ch_off + c], vo[c], Bsum);
+            vo[c] = inside ? v_out[p * C + ch_off + c] : 0.0f;
+            Bsum = __builtin_fmaf(background[ch_off + c], vo[c], Bsum);
         }
         W = T_final * Bsum;
     }
-    float vob[WIDE ? 32 : 1];
-    if (WIDE) {
-        const int cch = lane & 31, hf = lane >> 5;
-#pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            const int pq = 2 * s + hf;
-            const int pj = qx0 + (pq & 7), pi = qy0 + (pq >> 3);
-            const bool ok = (pi < img_h) && (pj < img_w) && (FULL || cch < nch);
-            vob[s] = ok ? v_out[((size_t)pi * img_w + pj) * C + ch_off + cch] : 0.0f;
-        }
-    }
-    int hi = fin;
+    int hi = fin;  // this wave's upper end of the walk
     for (int off = 32; off > 0; off >>= 1) hi = max(hi, __shfl_xor(hi, off, 64));
-    if (lane == 0) s_hi[wave] = hi;
-    for (int t = threadIdx.x; t < BW_BATCH * KP; t += 256) (&slab[0][0])[t] = 0.0f;
-    if (threadIdx.x < BW_BATCH) s_flag[threadIdx.x] = 0;
-    __syncthreads();
-    const int block_hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+    hi = __builtin_amdgcn_readfirstlane(hi);
 
-    // butterfly result map: which (group member, value) does this lane own?
+    // which (group member q, value k) does this lane own after the butterfly, and where does it go?
     const int b4 = (lane >> 4) & 1, b5 = lane >> 5, r16 = lane & 15;
     bool owner = false;
     int myvar = 0;
     if (r16 < R::H2) myvar = R::var(r16, b4, b5, owner);
     owner = owner && (r16 < R::H2);
-    const int my_q = myvar / KG, my_k = myvar - my_q * KG;
-    // slab column of my value: colours first (narrow), then the 6 geometry values after CH colours
-    const int my_col = (my_k < KC) ? my_k : (CH + (my_k - KC));
+    const int my_q = myvar / K, my_k = myvar - my_q * K;
+    float *my_base;     // gradient array of my value
+    int my_stride;      // floats per Gaussian in that array
+    if (my_k < CH) { my_base = v_colors + ch_off + my_k; my_stride = C; }
+    else if (my_k < CH + 2) { my_base = v_xy + (my_k - CH); my_stride = 2; }
+    else if (my_k < CH + 5) { my_base = v_conic + (my_k - CH - 2); my_stride = 3; }
+    else { my_base = v_opacity; my_stride = 1; }
 
-    int nslots = 0;
-    auto flush_slots = [&]() {
-        if (WIDE) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            const float *arow = fac_w + (lane & 31) * B2_FSTRIDE + (lane >> 5);
-#pragma unroll
-            for (int s = 0; s < 32; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * s], vob[s], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int slot = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (slot < nslots) atomicAdd(&slab[slotrow_w[slot]][lane & 31], acc[r]);
-            }
-        }
-        nslots = 0;
-    };
-
-    for (int top = block_hi; top > range.x; top -= BW_BATCH) {
-        const int e = top - BW_BATCH + lane;
-        const bool valid = (e >= range.x) && (e < hi);
-        if (wave == 0) s_gid[lane] = (e >= range.x) ? ids[e] : 0;
-        const int cnt = stage_chunk<CH, WIDE>(L, lane, e, valid, ids, rec, colors, C, ch_off, nch,
-                                              xlo, xhi, ylo, yhi);
-        // survivors sit at L[GRP .. GRP+cnt); walk them back to front, four at a time;
-        // member q of a group is list slot (kk - q): q = 0 is the farthest of the four.
+    for (int top = hi; top > range.x; top -= 64) {
+        const int e = top - 64 + lane;
+        const bool valid = e >= range.x;
+        const int cnt = stage_chunk<CH, false, true>(L, lane, e, valid, ids, rec, colors, C, ch_off,
+                                                     CH, xlo, xhi, ylo, yhi);
+        const int fin_rel = fin - (top - 64);  // entries at chunk position >= fin_rel are not mine
         for (int kk = GRP + cnt - 1; kk >= GRP; kk -= GRP) {
             float4 A[GRP], B[GRP], Cc[GRP];
 #pragma unroll
@@ -335,7 +293,6 @@ __global__ __launch_bounds__(256) void blend2_bwd_kernel(
             }
             float vis[GRP], alpha[GRP], dxs[GRP], dys[GRP];
             bool pass[GRP];
-            int srcs[GRP];
 #pragma unroll
             for (int q = 0; q < GRP; ++q) {
                 const float dx = A[q].x - px, dy = A[q].y - py;
@@ -345,9 +302,9 @@ __global__ __launch_bounds__(256) void blend2_bwd_kernel(
                     0.5f, __builtin_fmaf(B[q].x * dx, dx, (B[q].z * dy) * dy), (B[q].y * dx) * dy);
                 vis[q] = gg_expf(-sigma);
                 alpha[q] = fminf(GG_ALPHA_MAX_BWD, A[q].z * vis[q]);
-                const int idx = __builtin_bit_cast(int, Cc[q].w) - 1;  // -1 for null pads
-                srcs[q] = idx - (top - BW_BATCH);
-                pass[q] = (idx >= 0) && (idx < fin) && sigma >= 0.0f && !(alpha[q] < GG_ALPHA_MIN);
+                // .w = position inside the chunk; null pads have opacity 0 -> alpha 0 -> no pass
+                pass[q] = (__builtin_bit_cast(int, Cc[q].w) < fin_rel) && sigma >= 0.0f &&
+                          !(alpha[q] < GG_ALPHA_MIN);
             }
             if (__ballot(pass[0] || pass[1] || pass[2] || pass[3]) == 0ull) continue;
 
@@ -357,32 +314,17 @@ __global__ __launch_bounds__(256) void blend2_bwd_kernel(
                 const float ra_ = __builtin_amdgcn_rcpf(1.0f - alpha[q]);
                 const float Tn = T * ra_;
                 const float fac = pass[q] ? alpha[q] * Tn : 0.0f;
-                float D;
-                if (!WIDE) {
-                    D = Cc[q].x * vo[0];
-                    if (CH > 1) D = __builtin_fmaf(Cc[q].y, vo[CH > 1 ? 1 : 0], D);
-                    if (CH > 2) D = __builtin_fmaf(Cc[q].z, vo[CH > 2 ? 2 : 0], D);
+                float D = Cc[q].x * vo[0];
+                if (CH > 1) D = __builtin_fmaf(Cc[q].y, vo[CH > 1 ? 1 : 0], D);
+                if (CH > 2) D = __builtin_fmaf(Cc[q].z, vo[CH > 2 ? 2 : 0], D);
 #pragma unroll
-                    for (int c = 0; c < KC; ++c) part[q * KG + c] = fac * vo[c];
-                } else {
-                    const int gid = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, Cc[q].x));
-                    const float *col = colors + (size_t)gid * C + ch_off;
-                    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;  // 4 chains: latency, not order
-#pragma unroll
-                    for (int c = 0; c < CH; c += 4) {
-                        d0 = __builtin_fmaf((FULL || c + 0 < nch) ? col[c + 0] : 0.f, vo[c + 0], d0);
-                        d1 = __builtin_fmaf((FULL || c + 1 < nch) ? col[c + 1] : 0.f, vo[c + 1], d1);
-                        d2 = __builtin_fmaf((FULL || c + 2 < nch) ? col[c + 2] : 0.f, vo[c + 2], d2);
-                        d3 = __builtin_fmaf((FULL || c + 3 < nch) ? col[c + 3] : 0.f, vo[c + 3], d3);
-                    }
-                    D = (d0 + d1) + (d2 + d3);
-                }
+                for (int c = 0; c < CH; ++c) part[q * K + c] = fac * vo[c];
                 const float v_alpha = pass[q] ? (Tn * D - ra_ * W) : 0.0f;
                 W = pass[q] ? __builtin_fmaf(D, fac, W) : W;
                 T = pass[q] ? Tn : T;
-                const float v_sigma = pass[q] ? (-A[q].z * vis[q]) * v_alpha : 0.0f;
+                const float v_sigma = pass[q] ? (-A[q].z * vis[q]) * v_alpha : 0.0f;  // vis may be inf
                 const float dx = dxs[q], dy = dys[q];
-                float *pg = part + q * KG + KC;
+                float *pg = part + q * K + CH;
                 pg[0] = v_sigma * (B[q].x * dx + B[q].y * dy);
                 pg[1] = v_sigma * (B[q].y * dx + B[q].z * dy);
                 const float hs = 0.5f * v_sigma;
@@ -390,52 +332,18 @@ __global__ __launch_bounds__(256) void blend2_bwd_kernel(
                 pg[3] = (hs * dx) * dy;
                 pg[4] = (hs * dy) * dy;
                 pg[5] = pass[q] ? vis[q] * v_alpha : 0.0f;
-                if (WIDE) {
-                    // wave-uniform: does this Gaussian get a colour-gradient row?
-                    if (__ballot(pass[q]) != 0ull) {
-                        fac_w[nslots * B2_FSTRIDE + lane] = fac;
-                        if (lane == 0) slotrow_w[nslots] = srcs[q];
-                        ++nslots;
-                        if (nslots == B2_SLOTS) flush_slots();
-                    }
-                }
             }
             float red[R::H2];
             R::run(part, red);
             float mine = red[0];
 #pragma unroll
             for (int q = 1; q < R::H2; ++q) mine = (r16 == q) ? red[q] : mine;
-            // row of my group member (wave-uniform values, per-lane select)
-            int my_src = srcs[0];
-#pragma unroll
-            for (int q = 1; q < GRP; ++q) my_src = (my_q == q) ? srcs[q] : my_src;
-            if (owner && my_src >= 0 && my_src < BW_BATCH) {
-                atomicAdd(&slab[my_src][my_col], mine);
-                if (my_k == KG - 1) s_flag[my_src] = 1;
-            }
+            // Gaussian id of my group member: per-lane LDS read (4 distinct addresses per wave);
+            // id bits live in b.w of the record
+            const int my_gid = __builtin_bit_cast(int, L.b[kk - my_q].w);
+            if (owner && my_gid >= 0) atomicAdd(my_base + (size_t)my_gid * my_stride, mine);
         }
-        if (nslots > 0) flush_slots();
-        __syncthreads();
-        {
-            constexpr int RPI = 64 / K;
-            const int rsub = lane / K, k = lane - rsub * K;
-            for (int row0 = wave * RPI; row0 < BW_BATCH; row0 += 4 * RPI) {
-                const int row = row0 + rsub;
-                if (rsub < RPI && row < BW_BATCH && s_flag[row]) {
-                    const int gid = s_gid[row];
-                    const float val = slab[row][k];
-                    slab[row][k] = 0.0f;
-                    float *dst;
-                    if (k < CH) dst = v_colors + (size_t)gid * C + ch_off + k;
-                    else if (k < CH + 2) dst = v_xy + 2 * (size_t)gid + (k - CH);
-                    else if (k < CH + 5) dst = v_conic + 3 * (size_t)gid + (k - CH - 2);
-                    else dst = v_opacity + gid;
-                    if (k >= CH || k < nch) atomicAdd(dst, val);
-                    if (k == 0) s_flag[row] = 0;
-                }
-            }
-        }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();  // the list is rewritten by the next chunk
     }
 }
 
@@ -461,22 +369,19 @@ void gg_launch_blend2_fwd(int width, int C, int off, int n, int img_h, int img_w
         hipLaunchKernelGGL((blend2_fwd_kernel<32, true, false>), grid, block, 0, s, B2_FWD_ARGS);
 }
 
-#define B2_BWD_ARGS C, off, n, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, \
-                    final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity
+#define B2_BWDN_ARGS C, off, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, \
+                     final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity
 void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w, int tiles_x,
                           int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
                           const float *colors, const float *background, const float *final_Ts,
                           const int32_t *final_idx, const float *v_out, float *v_xy, float *v_conic,
                           float *v_colors, float *v_opacity, hipStream_t s) {
+    (void)n;
     dim3 grid(ntiles), block(256);
     if (width == 1)
-        hipLaunchKernelGGL((blend2_bwd_kernel<1, false, true>), grid, block, 0, s, B2_BWD_ARGS);
+        hipLaunchKernelGGL((blend2_bwd_narrow_kernel<1>), grid, block, 0, s, B2_BWDN_ARGS);
     else if (width == 2)
-        hipLaunchKernelGGL((blend2_bwd_kernel<2, false, true>), grid, block, 0, s, B2_BWD_ARGS);
-    else if (width == 3)
-        hipLaunchKernelGGL((blend2_bwd_kernel<3, false, true>), grid, block, 0, s, B2_BWD_ARGS);
-    else if (n == 32)
-        hipLaunchKernelGGL((blend2_bwd_kernel<32, true, true>), grid, block, 0, s, B2_BWD_ARGS);
+        hipLaunchKernelGGL((blend2_bwd_narrow_kernel<2>), grid, block, 0, s, B2_BWDN_ARGS);
     else
-        hipLaunchKernelGGL((blend2_bwd_kernel<32, true, false>), grid, block, 0, s, B2_BWD_ARGS);
+        hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3>), grid, block, 0, s, B2_BWDN_ARGS);
 }

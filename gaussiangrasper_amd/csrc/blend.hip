@@ -527,6 +527,22 @@ static int blend_impl() {
     return impl;
 }
 static int chunk_width2(int remaining) { return remaining <= 3 ? remaining : 32; }
+static int g_wide_impl = 2;  // 2: blend2_bwd_wide_kernel, 1: blend_bwd_wide_kernel (A/B, gg_debug_set_ablation(100+x))
+static int g_ablate = 0;  // measurement only (gg_debug_set_ablation)
+extern "C" int gg_debug_set_ablation(int level) {
+    int prev = g_ablate;
+    if (level >= 100) {  // 101 / 102: choose the wide-backward implementation
+        g_wide_impl = level - 100;
+        return prev;
+    }
+    g_ablate = level;
+    return prev;
+}
+void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, int tiles_x,
+                                 int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
+                                 const float *colors, const float *background, const float *final_Ts,
+                                 const int32_t *final_idx, const float *v_out, float *v_xy,
+                                 float *v_conic, float *v_colors, float *v_opacity, hipStream_t s);
 
 static int chunk_width(int remaining) {
     if (remaining >= 32) return 32;
@@ -654,7 +670,11 @@ extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *i
         int w = chunk_width2(C - off);
         int n = min(w, C - off);
         gg_prof_begin(GG_K_BLEND_BWD + gg_width_index(w), s);
-        if (w <= 3)
+        if (w == 3 && g_ablate > 0)
+            gg_launch_blend2_bwd_ablate(g_ablate, C, off, img_h, img_w, tiles_x, ntiles, ids,
+                                        (const int2 *)tile_bins, rec, colors, background, final_Ts,
+                                        final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, s);
+        else if (w <= 3 || g_wide_impl == 2)
             gg_launch_blend2_bwd(w, C, off, n, img_h, img_w, tiles_x, ntiles, ids,
                                  (const int2 *)tile_bins, rec, colors, background, final_Ts,
                                  final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, s);

@@ -219,7 +219,11 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
 // Measured alternatives (profiles/README.md): combining the four waves of a tile through an LDS
 // slab with two __syncthreads() per chunk, and a wave-private slab flushed per chunk, were both
 // slower — the per-chunk flush loop costs more instructions than the atomics it saves.
-template <int CH>
+// ABL > 0: ablation builds for the measurement harness (tools/kbench.py) — NOT used by the product:
+//   1 = no global atomics, 2 = also no butterfly, 3 = also no recurrence/partials (geometry only),
+//   4 = staging + cull only (no group loop)
+#define KEEP(x) asm volatile("" ::"v"(x))
+template <int CH, int ABL = 0>
 __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
     int C, int ch_off, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
@@ -283,6 +287,7 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
         const int cnt = stage_chunk<CH, false, true>(L, lane, e, valid, ids, rec, colors, C, ch_off,
                                                      CH, xlo, xhi, ylo, yhi);
         const int fin_rel = fin - (top - 64);  // entries at chunk position >= fin_rel are not mine
+        if (ABL >= 4) { KEEP(cnt); continue; }
         for (int kk = GRP + cnt - 1; kk >= GRP; kk -= GRP) {
             float4 A[GRP], B[GRP], Cc[GRP];
 #pragma unroll
@@ -307,6 +312,11 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
                           !(alpha[q] < GG_ALPHA_MIN);
             }
             if (__ballot(pass[0] || pass[1] || pass[2] || pass[3]) == 0ull) continue;
+            if (ABL >= 3) {
+#pragma unroll
+                for (int q = 0; q < GRP; ++q) { KEEP(vis[q]); KEEP(alpha[q]); KEEP((int)pass[q]); }
+                continue;
+            }
 
             float part[KB];
 #pragma unroll
@@ -333,6 +343,11 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
                 pg[4] = (hs * dy) * dy;
                 pg[5] = pass[q] ? vis[q] * v_alpha : 0.0f;
             }
+            if (ABL >= 2) {
+#pragma unroll
+                for (int v = 0; v < KB; ++v) KEEP(part[v]);
+                continue;
+            }
             float red[R::H2];
             R::run(part, red);
             float mine = red[0];
@@ -341,10 +356,198 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
             // Gaussian id of my group member: per-lane LDS read (4 distinct addresses per wave);
             // id bits live in b.w of the record
             const int my_gid = __builtin_bit_cast(int, L.b[kk - my_q].w);
+            if (ABL >= 1) { KEEP(mine); KEEP(my_gid); continue; }
             if (owner && my_gid >= 0) atomicAdd(my_base + (size_t)my_gid * my_stride, mine);
         }
         __builtin_amdgcn_wave_barrier();  // the list is rewritten by the next chunk
     }
+}
+
+// =============================================================================================
+// backward, wide (32-channel chunk): wave-autonomous, matrix pipe for the colour gradients
+// =============================================================================================
+// Same walk as the narrow kernel.  Per Gaussian with at least one contributing pixel:
+//   D = <colour, v_out> with the colour row in SGPRs (wave-uniform scalar loads, 4 fma chains);
+//   fac is parked in LDS ([slot][pixel]); after 32 slots FAC[32 x 64] * V_OUT[64 x 32] runs as 32
+//   v_mfma_f32_32x32x2_f32 (exact fp32 fma chains) and the 32x32 result goes to v_colors with 16
+//   global-atomic wave-instructions of two full 128-byte rows each.
+// The 6 geometry partials of the four Gaussians of a group share one butterfly (Red<24>) and one
+// atomic wave-instruction.  No LDS slab, no workgroup barrier.
+#define B2_SLOTS 32
+#define B2_FSTRIDE 65
+
+template <bool FULL>
+__global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
+    int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
+    const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
+    const float *__restrict__ colors, const float *__restrict__ background,
+    const float *__restrict__ final_T, const int32_t *__restrict__ final_idx,
+    const float *__restrict__ v_out, float *__restrict__ v_xy, float *__restrict__ v_conic,
+    float *__restrict__ v_colors, float *__restrict__ v_opacity) {
+    constexpr int CH = 32;
+    constexpr int KG = 6;
+    constexpr int KB = GRP * KG;
+    using R = Red<KB>;
+    __shared__ WaveList lists[4];
+    __shared__ float s_fac[4][B2_SLOTS * B2_FSTRIDE];
+    __shared__ int s_slotgid[4][B2_SLOTS];
+
+    const int tile = xcd_tile(blockIdx.x, ntiles);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    WaveList &L = lists[wave];
+    float *fac_w = s_fac[wave];
+    int *slotgid = s_slotgid[wave];
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int qx0 = tx * GG_BLOCK + (wave & 1) * 8, qy0 = ty * GG_BLOCK + (wave >> 1) * 8;
+    const int j = qx0 + (lane & 7), i = qy0 + (lane >> 3);
+    const bool inside = (i < img_h) && (j < img_w);
+    const float px = (float)j, py = (float)i;
+    const float xlo = (float)qx0, xhi = (float)(qx0 + 7), ylo = (float)qy0, yhi = (float)(qy0 + 7);
+    const int2 range = bins[tile];
+    const size_t p = inside ? ((size_t)i * img_w + j) : 0;
+
+    const float T_final = inside ? final_T[p] : 1.0f;
+    const int fin = inside ? final_idx[p] : range.x;
+    float T = T_final;
+    float vo[CH];
+    float W;
+    {
+        float Bsum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            vo[c] = (inside && (FULL || c < nch)) ? v_out[p * C + ch_off + c] : 0.0f;
+            if (FULL || c < nch) Bsum = __builtin_fmaf(background[ch_off + c], vo[c], Bsum);
+        }
+        W = T_final * Bsum;
+    }
+    const int wch = lane & 31, half = lane >> 5;
+    const bool wch_ok = FULL || wch < nch;
+    float vob[32];  // MFMA B operands: V_OUT[pixel 2s + half][channel wch]
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        const int pq = 2 * s + half;
+        const int pj = qx0 + (pq & 7), pi = qy0 + (pq >> 3);
+        const bool ok = (pi < img_h) && (pj < img_w) && wch_ok;
+        vob[s] = ok ? v_out[((size_t)pi * img_w + pj) * C + ch_off + wch] : 0.0f;
+    }
+    int hi = fin;
+    for (int off = 32; off > 0; off >>= 1) hi = max(hi, __shfl_xor(hi, off, 64));
+    hi = __builtin_amdgcn_readfirstlane(hi);
+
+    const int b4 = (lane >> 4) & 1, b5 = lane >> 5, r16 = lane & 15;
+    bool owner = false;
+    int myvar = 0;
+    if (r16 < R::H2) myvar = R::var(r16, b4, b5, owner);
+    owner = owner && (r16 < R::H2);
+    const int my_q = myvar / KG, my_k = myvar - my_q * KG;
+    float *my_base;
+    int my_stride;
+    if (my_k < 2) { my_base = v_xy + my_k; my_stride = 2; }
+    else if (my_k < 5) { my_base = v_conic + (my_k - 2); my_stride = 3; }
+    else { my_base = v_opacity; my_stride = 1; }
+
+    int nslots = 0;  // wave-uniform
+    auto flush_slots = [&]() {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const float *arow = fac_w + (lane & 31) * B2_FSTRIDE + half;
+#pragma unroll
+        for (int s = 0; s < 32; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * s], vob[s], acc, 0, 0, 0);
+        // D: column = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*half (slot): every instruction
+        // below adds two complete 128-byte colour-gradient rows
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int slot = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (slot < nslots && wch_ok)
+                atomicAdd(v_colors + (size_t)slotgid[slot] * C + ch_off + wch, acc[r]);
+        }
+        nslots = 0;
+    };
+
+    for (int top = hi; top > range.x; top -= 64) {
+        const int e = top - 64 + lane;
+        const bool valid = e >= range.x;
+        const int cnt = stage_chunk<CH, true, true>(L, lane, e, valid, ids, rec, colors, C, ch_off,
+                                                    nch, xlo, xhi, ylo, yhi);
+        const int fin_rel = fin - (top - 64);
+        for (int kk = GRP + cnt - 1; kk >= GRP; kk -= GRP) {
+            float vis[GRP], alpha[GRP], dxs[GRP], dys[GRP], opac[GRP];
+            float ca[GRP], cb[GRP], cc[GRP];
+            bool pass[GRP];
+#pragma unroll
+            for (int q = 0; q < GRP; ++q) {
+                const float4 A = L.a[kk - q], B = L.b[kk - q];
+                const int pos = __builtin_bit_cast(int, L.c[kk - q].w);
+                const float dx = A.x - px, dy = A.y - py;
+                dxs[q] = dx;
+                dys[q] = dy;
+                opac[q] = A.z;
+                ca[q] = B.x;
+                cb[q] = B.y;
+                cc[q] = B.z;
+                const float sigma = __builtin_fmaf(
+                    0.5f, __builtin_fmaf(B.x * dx, dx, (B.z * dy) * dy), (B.y * dx) * dy);
+                vis[q] = gg_expf(-sigma);
+                alpha[q] = fminf(GG_ALPHA_MAX_BWD, A.z * vis[q]);
+                pass[q] = (pos < fin_rel) && sigma >= 0.0f && !(alpha[q] < GG_ALPHA_MIN);
+            }
+            if (__ballot(pass[0] || pass[1] || pass[2] || pass[3]) == 0ull) continue;
+
+            float part[KB];
+#pragma unroll
+            for (int q = 0; q < GRP; ++q) {
+                float *pg = part + q * KG;
+                if (__ballot(pass[q]) == 0ull) {  // wave-uniform: nobody blends this Gaussian
+#pragma unroll
+                    for (int v = 0; v < KG; ++v) pg[v] = 0.0f;
+                    continue;
+                }
+                const int gid = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, L.b[kk - q].w));
+                const float *col = colors + (size_t)gid * C + ch_off;
+                float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;  // 4 chains: latency, not order
+#pragma unroll
+                for (int c = 0; c < CH; c += 4) {
+                    d0 = __builtin_fmaf((FULL || c + 0 < nch) ? col[c + 0] : 0.f, vo[c + 0], d0);
+                    d1 = __builtin_fmaf((FULL || c + 1 < nch) ? col[c + 1] : 0.f, vo[c + 1], d1);
+                    d2 = __builtin_fmaf((FULL || c + 2 < nch) ? col[c + 2] : 0.f, vo[c + 2], d2);
+                    d3 = __builtin_fmaf((FULL || c + 3 < nch) ? col[c + 3] : 0.f, vo[c + 3], d3);
+                }
+                const float D = (d0 + d1) + (d2 + d3);
+                const float ra_ = __builtin_amdgcn_rcpf(1.0f - alpha[q]);
+                const float Tn = T * ra_;
+                const float fac = pass[q] ? alpha[q] * Tn : 0.0f;
+                const float v_alpha = pass[q] ? (Tn * D - ra_ * W) : 0.0f;
+                W = pass[q] ? __builtin_fmaf(D, fac, W) : W;
+                T = pass[q] ? Tn : T;
+                const float v_sigma = pass[q] ? (-opac[q] * vis[q]) * v_alpha : 0.0f;
+                const float dx = dxs[q], dy = dys[q];
+                pg[0] = v_sigma * (ca[q] * dx + cb[q] * dy);
+                pg[1] = v_sigma * (cb[q] * dx + cc[q] * dy);
+                const float hs = 0.5f * v_sigma;
+                pg[2] = (hs * dx) * dx;
+                pg[3] = (hs * dx) * dy;
+                pg[4] = (hs * dy) * dy;
+                pg[5] = pass[q] ? vis[q] * v_alpha : 0.0f;
+                // park fac for the matrix pipe
+                fac_w[nslots * B2_FSTRIDE + lane] = fac;
+                if (lane == 0) slotgid[nslots] = gid;
+                ++nslots;
+                if (nslots == B2_SLOTS) flush_slots();
+            }
+            float red[R::H2];
+            R::run(part, red);
+            float mine = red[0];
+#pragma unroll
+            for (int q = 1; q < R::H2; ++q) mine = (r16 == q) ? red[q] : mine;
+            const int my_gid = __builtin_bit_cast(int, L.b[kk - my_q].w);
+            if (owner && my_gid >= 0) atomicAdd(my_base + (size_t)my_gid * my_stride, mine);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (nslots > 0) flush_slots();
 }
 
 // =============================================================================================
@@ -376,12 +579,35 @@ void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w
                           const float *colors, const float *background, const float *final_Ts,
                           const int32_t *final_idx, const float *v_out, float *v_xy, float *v_conic,
                           float *v_colors, float *v_opacity, hipStream_t s) {
-    (void)n;
     dim3 grid(ntiles), block(256);
     if (width == 1)
         hipLaunchKernelGGL((blend2_bwd_narrow_kernel<1>), grid, block, 0, s, B2_BWDN_ARGS);
     else if (width == 2)
         hipLaunchKernelGGL((blend2_bwd_narrow_kernel<2>), grid, block, 0, s, B2_BWDN_ARGS);
-    else
+    else if (width == 3)
         hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3>), grid, block, 0, s, B2_BWDN_ARGS);
+    else if (n == 32)
+        hipLaunchKernelGGL((blend2_bwd_wide_kernel<true>), grid, block, 0, s, C, off, n, img_h, img_w,
+                           tiles_x, ntiles, ids, bins, rec, colors, background, final_Ts, final_idx,
+                           v_out, v_xy, v_conic, v_colors, v_opacity);
+    else
+        hipLaunchKernelGGL((blend2_bwd_wide_kernel<false>), grid, block, 0, s, C, off, n, img_h, img_w,
+                           tiles_x, ntiles, ids, bins, rec, colors, background, final_Ts, final_idx,
+                           v_out, v_xy, v_conic, v_colors, v_opacity);
+}
+
+// measurement-only entry (tools/kbench.py): ablated builds of the 3-channel backward
+void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, int tiles_x,
+                                 int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
+                                 const float *colors, const float *background, const float *final_Ts,
+                                 const int32_t *final_idx, const float *v_out, float *v_xy,
+                                 float *v_conic, float *v_colors, float *v_opacity, hipStream_t s) {
+    dim3 grid(ntiles), block(256);
+    switch (abl) {
+        case 1: hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3, 1>), grid, block, 0, s, B2_BWDN_ARGS); break;
+        case 2: hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3, 2>), grid, block, 0, s, B2_BWDN_ARGS); break;
+        case 3: hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3, 3>), grid, block, 0, s, B2_BWDN_ARGS); break;
+        case 4: hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3, 4>), grid, block, 0, s, B2_BWDN_ARGS); break;
+        default: hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3, 0>), grid, block, 0, s, B2_BWDN_ARGS); break;
+    }
 }

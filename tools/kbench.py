@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Kernel-level measurement harness (GPU box): times the blend kernels on the bench workload
+through the C ABI with the in-library hipEvent brackets, optionally with the ablated builds of the
+3-channel backward.  Usage: python tools/kbench.py [--reps 5]"""
+import argparse
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "shim")]
+import torch  # noqa: E402
+
+from gaussiangrasper_amd import _lib, ops  # noqa: E402
+from gaussiangrasper_amd.camera import ring_cameras  # noqa: E402
+from gaussiangrasper_amd.scene import make_scene  # noqa: E402
+
+
+def prof(lib):
+    out = {}
+    for kid in range(32):
+        n, ms = ctypes.c_int(0), ctypes.c_double(0.0)
+        lib.gg_prof_get(kid, ctypes.byref(n), ctypes.byref(ms))
+        if n.value:
+            out[lib.gg_prof_name(kid).decode()] = ms.value / n.value
+    lib.gg_prof_reset()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--points", type=int, default=1_000_000)
+    args = ap.parse_args()
+    dev = "cuda:0"
+    lib = _lib.load()
+    h, w = 1200, 1600
+    sc = make_scene(args.points, config_index=3).to(dev)
+    v = ring_cameras(8, h, w, device=dev)[0]
+    xys, depths, radii, conics, nth, _ = ops.ProjectGaussians.apply(
+        sc.means, sc.scales.exp(), 1, sc.quats, v.viewmat[:3], v.projmat, v.fx, v.fy, v.cx, v.cy, h, w,
+        v.tile_bounds)
+    opac = torch.sigmoid(sc.opacities)
+    rgb = torch.rand(args.points, 3, device=dev)
+    feat = sc.feature
+
+    def run(colors, label):
+        c = colors.detach().requires_grad_(True)
+        x = xys.detach().requires_grad_(True)
+        op = ops.RasterizeGaussians if c.shape[1] == 3 else ops.NDRasterizeGaussians
+        vo = torch.randn(h, w, c.shape[1], device=dev)
+        lib.gg_prof_reset()
+        lib.gg_prof_enable(1)
+        for _ in range(args.reps):
+            out = op.apply(x, depths, radii, conics.detach(), nth, c, opac.detach(), h, w,
+                           torch.zeros(c.shape[1], device=dev))
+            out.backward(vo)
+        torch.cuda.synchronize()
+        lib.gg_prof_enable(0)
+        r = prof(lib)
+        print(label, {k: round(t, 4) for k, t in r.items() if "blend" in k}, flush=True)
+
+    run(rgb, "C=3 full   ")
+    for lvl, name in ((1, "no atomics "), (2, "no butterfly"), (3, "geometry only"), (4, "staging only")):
+        lib.gg_debug_set_ablation(lvl)
+        run(rgb, f"C=3 abl{lvl} {name}")
+    lib.gg_debug_set_ablation(0)
+    run(feat, "C=32 v2 wide bwd")
+    lib.gg_debug_set_ablation(101)
+    run(feat, "C=32 v1 wide bwd")
+    lib.gg_debug_set_ablation(102)
+
+
+if __name__ == "__main__":
+    main()

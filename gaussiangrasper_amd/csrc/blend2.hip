@@ -1,4 +1,4 @@
-// blend2.hip — second-generation blend kernels (same results as blend.hip's, ~2-3x fewer stalls).
+// blend2.hip — the blend kernels (second generation; the first, profiles/r01_v1_*, is gone).
 //
 // What the first generation measured (profiles/r01_v1_*, PMC passes): only ~28 % of wave-cycles
 // issue an instruction; SALU instruction count is ~70 % of VALU; the rest is s_waitcnt and

@@ -75,10 +75,42 @@ def rasterize_activated(act: Dict, view: ViewParams, ops, sh_degree_to_use: int 
     return out
 
 
+def rasterize_activated_fused(act: Dict, view: ViewParams, ops, sh_degree_to_use: int = 4
+                              ) -> Dict[str, torch.Tensor]:
+    """the four outputs from ONE rasterize call — feature(D) | rgb(3) | depth(1) |
+    normal(3) concatenated into one (N, D+7) colour tensor for NDRasterizeGaussians (the reference
+    renders depth as 3 replicated channels and keeps one; here it is one channel).  Same images,
+    bit for bit, as the four separate calls; one opacity activation, one set of geometry gradients.
+    What a maintainer would call from `get_outputs` instead of :735-784."""
+    dev = act["means"].device
+    h, w = view.height, view.width
+    opac = act["opac"]() if callable(act["opac"]) else act["opac"]
+    xys, depths, radii, conics, num_tiles_hit, cov3d = ops.ProjectGaussians.apply(
+        act["means"], act["scales"], 1, act["quats"], view.viewmat[:3, :].to(dev),
+        view.projmat.to(dev), view.fx, view.fy, view.cx, view.cy, h, w, view.tile_bounds)
+    if xys.requires_grad:
+        xys.retain_grad()
+    rgbs = ops.SphericalHarmonics.apply(sh_degree_to_use, act["viewdirs"], act["sh"])
+    rgbs = torch.clamp(rgbs + 0.5, 0.0, 1.0)
+    d = act["feature"].shape[1]
+    colors = torch.cat([act["feature"], rgbs, depths[:, None], act["normals"]], dim=1)
+    background = torch.zeros(d + 7, device=dev)
+    background[d + 3] = 10.0
+    img = ops.NDRasterizeGaussians.apply(xys, depths, radii, conics, num_tiles_hit, colors, opac, h, w,
+                                         background)
+    # one split (its backward is a single cat of the four cotangents, not four zero-padded adds)
+    feature, rgb, depth, normal = torch.split(img, [d, 3, 1, 3], dim=-1)
+    return {"xys": xys, "radii": radii, "depths": depths, "conics": conics,
+            "num_tiles_hit": num_tiles_hit, "feature": feature, "rgb": rgb, "depth": depth,
+            "normal": normal}
+
+
 def render_view(scene: Scene, view: ViewParams, ops, sh_degree_to_use: int = 4,
-                channels=CHANNELS) -> Dict[str, torch.Tensor]:
-    return rasterize_activated(activate(scene, view, ops.quat_to_rotmat), view, ops,
-                               sh_degree_to_use, channels)
+                channels=CHANNELS, fused: bool = False) -> Dict[str, torch.Tensor]:
+    act = activate(scene, view, ops.quat_to_rotmat)
+    if fused:
+        return rasterize_activated_fused(act, view, ops, sh_degree_to_use)
+    return rasterize_activated(act, view, ops, sh_degree_to_use, channels)
 
 
 def seeded_cotangents(outputs: Dict[str, torch.Tensor], seed: int = 0) -> Dict[str, torch.Tensor]:

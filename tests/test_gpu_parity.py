@@ -289,6 +289,29 @@ def test_operator_sequence_bitexact_vs_oracle(oracle, n, h, w, d):
     assert P.bin_cache_stats["hits"] - hits0 == 3  # one sort shared by the four rasterize calls
 
 
+def test_fused_multi_output_equals_four_calls():
+    """one NDRasterize call on feature|rgb|depth|normal (39 channels) gives the four
+    images of the reference's four calls bit for bit, and the same parameter gradients up to fp32
+    summation order (tolerance 1e-4*max|grad| + 2e-3*|grad|)."""
+    from gaussiangrasper_amd.pipeline import activate, rasterize_activated, rasterize_activated_fused
+    n, h, w = 60000, 300, 400
+    sc, v = _scene_view(n, h, w)
+    act = activate(sc, v, P.quat_to_rotmat)
+    a4, af = _activated_leaves(act, DEV), _activated_leaves(act, DEV)
+    P.clear_bin_cache()
+    out4 = rasterize_activated(a4, v, P)
+    cot = seeded_cotangents(out4, seed=3)
+    backward_view(out4, cot)
+    P.clear_bin_cache()
+    outf = rasterize_activated_fused(af, v, P)
+    backward_view(outf, cot)
+    for k in ("rgb", "feature", "depth", "normal"):
+        assert torch.equal(outf[k], out4[k]), k
+    for name in ("means", "scales", "quats", "opac", "sh", "feature", "normals"):
+        assert_close(_np(af[name].grad), _np(a4[name].grad), f"grad.{name}", rtol=2e-3, atol_frac=1e-4)
+    assert_close(_np(outf["xys"].grad), _np(out4["xys"].grad), "xys.grad", rtol=2e-3, atol_frac=1e-4)
+
+
 def test_full_host_path_vs_oracle(oracle):
     """render_view() end to end from raw parameters on both sides.  The caller-side activations
     (exp, sigmoid, normalise) run in torch on each device and differ in the last bit, so this

@@ -65,10 +65,7 @@ def main():
         lib.gg_debug_set_ablation(lvl)
         run(rgb, f"C=3 abl{lvl} {name}")
     lib.gg_debug_set_ablation(0)
-    run(feat, "C=32 v2 wide bwd")
-    lib.gg_debug_set_ablation(101)
-    run(feat, "C=32 v1 wide bwd")
-    lib.gg_debug_set_ablation(102)
+    run(feat, "C=32 full  ")
 
 
 if __name__ == "__main__":

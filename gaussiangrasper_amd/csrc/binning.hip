@@ -21,9 +21,10 @@
 #include "gg_common.h"
 
 #define RS_THREADS 256
-#define RS_ITEMS 16
-#define RS_TILE (RS_THREADS * RS_ITEMS)  // keys per block
 #define RS_WAVES (RS_THREADS / GG_WAVE)
+// keys per thread: 16 for large inputs; 4 when that would leave fewer than ~4 workgroups per CU
+// (the N = 1 M depth sort: 245 workgroups of 16 keys/thread ran latency-bound at 32 us per pass)
+static inline int rs_items(int64_t n) { return n >= (int64_t)4096 * 1024 ? 16 : 4; }
 
 // ---------------------------------------------------------------------------------------------
 // sum(num_tiles_hit) -> device int64
@@ -81,9 +82,11 @@ __global__ __launch_bounds__(256) void depth_keys_kernel(int N, const float *__r
 // ---------------------------------------------------------------------------------------------
 // radix pass, step 1: per-block digit histogram, stored digit-major: G[d * nblocks + b]
 // ---------------------------------------------------------------------------------------------
+template <int RS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(
     int64_t n, const uint32_t *__restrict__ keys, int shift, uint32_t mask, int nblocks,
     uint32_t *__restrict__ G) {
+    constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
     __shared__ uint32_t hist[256];
     hist[threadIdx.x] = 0;
     __syncthreads();
@@ -128,10 +131,12 @@ __global__ __launch_bounds__(256) void radix_colscan_kernel(int nblocks, uint32_
 }
 
 // step 3: stable scatter
+template <int RS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     int64_t n, const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int shift, uint32_t mask,
     int nblocks, const uint32_t *__restrict__ G, const uint32_t *__restrict__ totals) {
+    constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
     __shared__ uint32_t whist[RS_WAVES][256];
     __shared__ uint32_t digit_base[256];
     __shared__ uint32_t wsum[4];
@@ -336,7 +341,10 @@ __global__ __launch_bounds__(256) void tile_bins_kernel(int64_t I,
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-static int radix_nblocks(int64_t n) { return (int)((n + RS_TILE - 1) / RS_TILE); }
+static int radix_nblocks(int64_t n) {
+    const int64_t tile = (int64_t)RS_THREADS * rs_items(n);
+    return (int)((n + tile - 1) / tile);
+}
 
 struct BinWs {
     uint32_t *dkeyA, *dkeyB, *dvalA, *dvalB;  // N each
@@ -378,11 +386,19 @@ extern "C" size_t gg_bin_sort_workspace(int num_points, int64_t num_intersects) 
 static void radix_pass(int64_t n, const uint32_t *kin, const uint32_t *vin, uint32_t *kout,
                        uint32_t *vout, int shift, uint32_t mask, BinWs &w, hipStream_t s) {
     int nb = radix_nblocks(n);
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(RS_THREADS), 0, s, n, kin, shift, mask,
-                       nb, w.G);
+    if (rs_items(n) == 16)
+        hipLaunchKernelGGL(radix_hist_kernel<16>, dim3(nb), dim3(RS_THREADS), 0, s, n, kin, shift,
+                           mask, nb, w.G);
+    else
+        hipLaunchKernelGGL(radix_hist_kernel<4>, dim3(nb), dim3(RS_THREADS), 0, s, n, kin, shift,
+                           mask, nb, w.G);
     hipLaunchKernelGGL(radix_colscan_kernel, dim3(256), dim3(256), 0, s, nb, w.G, w.totals);
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(RS_THREADS), 0, s, n, kin, vin, kout,
-                       vout, shift, mask, nb, w.G, w.totals);
+    if (rs_items(n) == 16)
+        hipLaunchKernelGGL(radix_scatter_kernel<16>, dim3(nb), dim3(RS_THREADS), 0, s, n, kin, vin,
+                           kout, vout, shift, mask, nb, w.G, w.totals);
+    else
+        hipLaunchKernelGGL(radix_scatter_kernel<4>, dim3(nb), dim3(RS_THREADS), 0, s, n, kin, vin,
+                           kout, vout, shift, mask, nb, w.G, w.totals);
 }
 
 extern "C" int gg_bin_sort(int N, int64_t I, const float *xys, const float *depths,

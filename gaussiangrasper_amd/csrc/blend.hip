@@ -130,11 +130,18 @@ extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *i
     hipLaunchKernelGGL(blend_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, xys, conics,
                        opacity, rec);
     gg_prof_end(GG_K_BLEND_PREP, s);
-    // the kernels accumulate with atomics: the four gradient arrays start at zero
-    bool fail = hipMemsetAsync(v_xy, 0, sizeof(float) * 2 * (size_t)N, s) != hipSuccess;
-    fail |= hipMemsetAsync(v_conic, 0, sizeof(float) * 3 * (size_t)N, s) != hipSuccess;
-    fail |= hipMemsetAsync(v_colors, 0, sizeof(float) * (size_t)C * (size_t)N, s) != hipSuccess;
-    fail |= hipMemsetAsync(v_opacity, 0, sizeof(float) * (size_t)N, s) != hipSuccess;
+    // the kernels accumulate with atomics: the four gradient arrays start at zero (one memset when
+    // the caller laid them out back to back: v_xy | v_conic | v_opacity | v_colors)
+    bool fail;
+    if (v_conic == v_xy + 2 * (size_t)N && v_opacity == v_conic + 3 * (size_t)N &&
+        v_colors == v_opacity + (size_t)N) {
+        fail = hipMemsetAsync(v_xy, 0, sizeof(float) * (6 + (size_t)C) * (size_t)N, s) != hipSuccess;
+    } else {
+        fail = hipMemsetAsync(v_xy, 0, sizeof(float) * 2 * (size_t)N, s) != hipSuccess;
+        fail |= hipMemsetAsync(v_conic, 0, sizeof(float) * 3 * (size_t)N, s) != hipSuccess;
+        fail |= hipMemsetAsync(v_colors, 0, sizeof(float) * (size_t)C * (size_t)N, s) != hipSuccess;
+        fail |= hipMemsetAsync(v_opacity, 0, sizeof(float) * (size_t)N, s) != hipSuccess;
+    }
     if (fail) {
         gg_set_error("gg_blend_bwd: memset failed");
         return GG_ERR_LAUNCH;

@@ -288,10 +288,13 @@ def _rasterize_backward(ctx, v_out_img):
          final_idx) = ctx.saved_tensors
         dev, n, ch = xys.device, xys.shape[0], colors.shape[1]
         v_out_img = _f32(v_out_img)
-        v_xy = torch.empty(n, 2, dtype=torch.float32, device=dev)
-        v_conic = torch.empty(n, 3, dtype=torch.float32, device=dev)
-        v_colors = torch.empty(n, ch, dtype=torch.float32, device=dev)
-        v_opacity = torch.empty(n, 1, dtype=torch.float32, device=dev)
+        # one allocation laid out v_xy | v_conic | v_opacity | v_colors: the library zeroes it with a
+        # single memset (the kernels accumulate with atomics)
+        flat = torch.empty(n * (6 + ch), dtype=torch.float32, device=dev)
+        v_xy = flat[:2 * n].view(n, 2)
+        v_conic = flat[2 * n:5 * n].view(n, 3)
+        v_opacity = flat[5 * n:6 * n].view(n, 1)
+        v_colors = flat[6 * n:].view(n, ch)
         lib = _lib.load()
         ws = _workspace(lib.gg_blend_workspace(n), dev)
         _lib.check(lib.gg_blend_bwd(ch, n, img_height, img_width, _ptr(ids_sorted),

@@ -465,3 +465,34 @@ def test_full_size_properties():
     assert torch.equal(both[..., :3], r_img) and torch.equal(both[..., 3:], f_img)
     lin = P.NDRasterizeGaussians.apply(xys, depths, radii, conics, nth, 2 * feat, opac, h, w, zeros(32))
     assert torch.equal(lin, 2 * f_img)  # scaling by 2 is exact in binary fp
+
+
+def test_config5_render_only_5m_128ch_1080p():
+    """BASELINE config 5 at full size (5 M Gaussians, 128-dim feature, 1920x1080, render-only):
+    size-independent properties — every 32-channel chunk of the 128-channel render equals the same
+    channels rendered alone (bit-exact), transmittance conservation, lists partition the
+    intersections.  Exercises int32/size_t index ranges (N*C = 640 M floats, P*C = 265 M floats)."""
+    n, h, w, d = 5_000_000, 1080, 1920, 128
+    sc = make_scene(n, feature_dim=d, sh_degree=0, config_index=4)
+    v = ring_cameras(8, h, w, device=DEV)[2]
+    means, scales, quats = sc.means.to(DEV), sc.scales.exp().to(DEV), sc.quats.to(DEV)
+    xys, depths, radii, conics, nth, _ = P.ProjectGaussians.apply(
+        means, scales, 1, quats, v.viewmat[:3], v.projmat, v.fx, v.fy, v.cx, v.cy, h, w, v.tile_bounds)
+    opac = torch.sigmoid(sc.opacities.to(DEV))
+    feat = sc.feature.to(DEV)
+    with torch.no_grad():
+        img = P.NDRasterizeGaussians.apply(xys, depths, radii, conics, nth, feat, opac, h, w,
+                                           torch.zeros(d, device=DEV))
+        b = P.bin_and_sort_gaussians(xys, depths, radii, nth, h, w)
+        assert b.num_intersects == int(nth.long().sum()) > 10_000_000
+        lens = (b.tile_bins[:, 1] - b.tile_bins[:, 0]).long()
+        assert int(lens.sum()) == b.num_intersects
+        part = P.NDRasterizeGaussians.apply(xys, depths, radii, conics, nth, feat[:, 64:96].contiguous(),
+                                            opac, h, w, torch.zeros(32, device=DEV))
+        assert torch.equal(img[..., 64:96], part)
+        ones = P.NDRasterizeGaussians.apply(xys, depths, radii, conics, nth, torch.ones(n, 1, device=DEV),
+                                            opac, h, w, torch.zeros(1, device=DEV))
+        tfin = P.NDRasterizeGaussians.apply(xys, depths, radii, conics, nth, torch.zeros(n, 1, device=DEV),
+                                            opac, h, w, torch.ones(1, device=DEV))
+        assert float((ones + tfin - 1).abs().max()) < 2e-5
+    assert img.shape == (h, w, d) and bool(torch.isfinite(img).all())

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
 // =============================================================================================
 // Every wave walks its quadrant's part of the tile list back to front on its own, four survivors
 // per iteration.  All CH+6 partial gradients of the four Gaussians of a group go through ONE
-// register butterfly (Red<4*(CH+6)>), which leaves each of the 4*(CH+6) totals on its own lane;
+// register butterfly (Red6<4*(CH+6)>), which leaves each of the 4*(CH+6) totals on its own lane;
 // those lanes add them straight into the gradient rows with ONE global float-atomic
 // wave-instruction per group (4 Gaussians x (CH+6) consecutive-ish floats).
 // Measured alternatives (profiles/README.md): combining the four waves of a tile through an LDS
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
     float *__restrict__ v_colors, float *__restrict__ v_opacity) {
     constexpr int K = CH + 6;       // per-Gaussian values: CH colours, xy(2), conic(3), opacity(1)
     constexpr int KB = GRP * K;     // butterfly width
-    using R = Red<KB>;
+    using R = Red6<KB>;
     __shared__ WaveList lists[4];
 
     const int tile = xcd_tile(blockIdx.x, ntiles);
@@ -268,11 +268,8 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
     hi = __builtin_amdgcn_readfirstlane(hi);
 
     // which (group member q, value k) does this lane own after the butterfly, and where does it go?
-    const int b4 = (lane >> 4) & 1, b5 = lane >> 5, r16 = lane & 15;
-    bool owner = false;
-    int myvar = 0;
-    if (r16 < R::H2) myvar = R::var(r16, b4, b5, owner);
-    owner = owner && (r16 < R::H2);
+    bool owner;
+    const int myvar = R::var(lane, owner);
     const int my_q = myvar / K, my_k = myvar - my_q * K;
     float *my_base;     // gradient array of my value
     int my_stride;      // floats per Gaussian in that array
@@ -348,11 +345,7 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
                 for (int v = 0; v < KB; ++v) KEEP(part[v]);
                 continue;
             }
-            float red[R::H2];
-            R::run(part, red);
-            float mine = red[0];
-#pragma unroll
-            for (int q = 1; q < R::H2; ++q) mine = (r16 == q) ? red[q] : mine;
+            const float mine = R::run(part, lane);
             // Gaussian id of my group member: per-lane LDS read (4 distinct addresses per wave);
             // id bits live in b.w of the record
             const int my_gid = __builtin_bit_cast(int, L.b[kk - my_q].w);
@@ -371,7 +364,7 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
 //   fac is parked in LDS ([slot][pixel]); after 32 slots FAC[32 x 64] * V_OUT[64 x 32] runs as 32
 //   v_mfma_f32_32x32x2_f32 (exact fp32 fma chains) and the 32x32 result goes to v_colors with 16
 //   global-atomic wave-instructions of two full 128-byte rows each.
-// The 6 geometry partials of the four Gaussians of a group share one butterfly (Red<24>) and one
+// The 6 geometry partials of the four Gaussians of a group share one butterfly (Red6<24>) and one
 // atomic wave-instruction.  No LDS slab, no workgroup barrier.
 #define B2_SLOTS 32
 #define B2_FSTRIDE 65
@@ -387,7 +380,7 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
     constexpr int CH = 32;
     constexpr int KG = 6;
     constexpr int KB = GRP * KG;
-    using R = Red<KB>;
+    using R = Red6<KB>;
     __shared__ WaveList lists[4];
     __shared__ float s_fac[4][B2_SLOTS * B2_FSTRIDE];
     __shared__ int s_slotgid[4][B2_SLOTS];
@@ -435,11 +428,8 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
     for (int off = 32; off > 0; off >>= 1) hi = max(hi, __shfl_xor(hi, off, 64));
     hi = __builtin_amdgcn_readfirstlane(hi);
 
-    const int b4 = (lane >> 4) & 1, b5 = lane >> 5, r16 = lane & 15;
-    bool owner = false;
-    int myvar = 0;
-    if (r16 < R::H2) myvar = R::var(r16, b4, b5, owner);
-    owner = owner && (r16 < R::H2);
+    bool owner;
+    const int myvar = R::var(lane, owner);
     const int my_q = myvar / KG, my_k = myvar - my_q * KG;
     float *my_base;
     int my_stride;
@@ -537,11 +527,7 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
                 ++nslots;
                 if (nslots == B2_SLOTS) flush_slots();
             }
-            float red[R::H2];
-            R::run(part, red);
-            float mine = red[0];
-#pragma unroll
-            for (int q = 1; q < R::H2; ++q) mine = (r16 == q) ? red[q] : mine;
+            const float mine = R::run(part, lane);
             const int my_gid = __builtin_bit_cast(int, L.b[kk - my_q].w);
             if (owner && my_gid >= 0) atomicAdd(my_base + (size_t)my_gid * my_stride, mine);
         }

@@ -94,3 +94,85 @@ struct Red {
     }
 };
 
+
+// ---------------------------------------------------------------------------------------------
+// Red6<K>: full halving butterfly, K <= 64 per-lane values -> ONE register per lane.
+// Six levels, each pairs lanes that differ in one lane-index bit; at a level the lanes with that
+// bit clear keep the first half of the values, the others the second half, and each receives its
+// partner's copy of what it keeps — so the value count halves at every level and the expensive
+// exchanges run last, on the fewest values.  Measured cost on gfx950 (tools/ubench_xlane.hip):
+// plain VALU 1 ns, DPP add 2.5 ns, v_permlane16/32_swap 5.5 ns per SIMD.  Level order and exchange:
+//   bit0 quad_perm[1,0,3,2]   bit1 quad_perm[2,3,0,1]   bit3 row_ror:8
+//   bit2 row_shl:4 / row_shr:4 (two bank-masked DPP moves)   bit4 v_permlane16_swap   bit5 v_permlane32_swap
+// After run(): lane l holds the wave total of value var(l) (owner(l) marks one lane per value).
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_xor4(float v) {
+    int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x104 /*row_shl:4*/, 0xf, 0x5, true);
+    t = __builtin_amdgcn_update_dpp(t, __builtin_bit_cast(int, v), 0x114 /*row_shr:4*/, 0xf, 0xa, true);
+    return __builtin_bit_cast(float, t);
+}
+// MODE: 0 bit0, 1 bit1, 2 bit3, 3 bit2, 4 bit4, 5 bit5
+template <int MODE>
+__device__ __forceinline__ float red6_partner(float send) {
+    if (MODE == 0) return dpp_mov<0xB1>(send);
+    if (MODE == 1) return dpp_mov<0x4E>(send);
+    if (MODE == 2) return dpp_mov<0x128>(send);  // row_ror:8
+    return dpp_xor4(send);
+}
+template <int NIN, int MODE>
+__device__ __forceinline__ void red6_level(const float (&in)[NIN], float (&out)[(NIN + 1) / 2], bool bit) {
+    constexpr int H = (NIN + 1) / 2;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+        if (j + H < NIN) {
+            const float a = in[j], b = in[j + H];
+            if (MODE < 4) {
+                const float send = bit ? a : b, keep = bit ? b : a;
+                out[j] = keep + red6_partner<MODE>(send);
+            } else if (MODE == 4) {
+                out[j] = swap_add16(a, b);
+            } else {
+                out[j] = swap_add32(a, b);
+            }
+        } else {  // odd count: this value is fully added on both sides (stays replicated)
+            if (MODE < 4) out[j] = in[j] + red6_partner<MODE>(in[j]);
+            else if (MODE == 4) out[j] = swap_add16(in[j], in[j]);
+            else out[j] = swap_add32(in[j], in[j]);
+        }
+    }
+}
+template <int K>
+struct Red6 {
+    static_assert(K >= 1 && K <= 64, "Red6 handles up to 64 values");
+    static constexpr int N0 = K, N1 = (N0 + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2,
+                         N4 = (N3 + 1) / 2, N5 = (N4 + 1) / 2, N6 = (N5 + 1) / 2;
+    __device__ static __forceinline__ float run(const float (&v)[K], int lane) {
+        float a1[N1], a2[N2], a3[N3], a4[N4], a5[N5], a6[N6];
+        red6_level<N0, 0>(v, a1, (lane & 1) != 0);
+        red6_level<N1, 1>(a1, a2, (lane & 2) != 0);
+        red6_level<N2, 2>(a2, a3, (lane & 8) != 0);
+        red6_level<N3, 3>(a3, a4, (lane & 4) != 0);
+        red6_level<N4, 4>(a4, a5, (lane & 16) != 0);
+        red6_level<N5, 5>(a5, a6, (lane & 32) != 0);
+        return a6[0];
+    }
+    // which value does `lane` hold, and is it the unique owner?
+    __device__ static __forceinline__ int var(int lane, bool &owner) {
+        const int nin[6] = {N0, N1, N2, N3, N4, N5};
+        const int bits[6] = {lane & 1, (lane >> 1) & 1, (lane >> 3) & 1, (lane >> 2) & 1,
+                             (lane >> 4) & 1, (lane >> 5) & 1};
+        int idx = 0;
+        owner = true;
+#pragma unroll
+        for (int m = 5; m >= 0; --m) {
+            const int h = (nin[m] + 1) / 2;
+            if (idx + h < nin[m]) idx += h * bits[m];
+            else owner = owner && (bits[m] == 0);
+        }
+        return idx;
+    }
+};

@@ -153,7 +153,7 @@ extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *i
         const int w = chunk_width(C - off);
         const int n = min(w, C - off);
         gg_prof_begin(GG_K_BLEND_BWD + gg_width_index(w), s);
-        if (w == 3 && g_ablate > 0)
+        if ((w == 3 && g_ablate > 0 && g_ablate < 10) || (w == 32 && n == 32 && g_ablate > 10))
             gg_launch_blend2_bwd_ablate(g_ablate, C, off, img_h, img_w, tiles_x, ntiles, ids,
                                         (const int2 *)tile_bins, rec, colors, background, final_Ts,
                                         final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, s);

@@ -369,7 +369,9 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
 #define B2_SLOTS 32
 #define B2_FSTRIDE 65
 
-template <bool FULL>
+// ABL > 0 (measurement builds only): 1 no colour-gradient atomics, 2 also no MFMA flush,
+// 3 also no butterfly / geometry atomics, 4 also no D (colour loads + 32 fma), 5 geometry only
+template <bool FULL, int ABL = 0>
 __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
@@ -439,6 +441,7 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
 
     int nslots = 0;  // wave-uniform
     auto flush_slots = [&]() {
+        if (ABL >= 2) { nslots = 0; return; }
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -451,6 +454,7 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int slot = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (ABL >= 1) { KEEP(acc[r]); continue; }
             if (slot < nslots && wch_ok)
                 atomicAdd(v_colors + (size_t)slotgid[slot] * C + ch_off + wch, acc[r]);
         }
@@ -485,6 +489,11 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
                 pass[q] = (pos < fin_rel) && sigma >= 0.0f && !(alpha[q] < GG_ALPHA_MIN);
             }
             if (__ballot(pass[0] || pass[1] || pass[2] || pass[3]) == 0ull) continue;
+            if (ABL >= 5) {
+#pragma unroll
+                for (int q = 0; q < GRP; ++q) { KEEP(vis[q]); KEEP(alpha[q]); KEEP((int)pass[q]); }
+                continue;
+            }
 
             float part[KB];
 #pragma unroll
@@ -505,7 +514,8 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
                     d2 = __builtin_fmaf((FULL || c + 2 < nch) ? col[c + 2] : 0.f, vo[c + 2], d2);
                     d3 = __builtin_fmaf((FULL || c + 3 < nch) ? col[c + 3] : 0.f, vo[c + 3], d3);
                 }
-                const float D = (d0 + d1) + (d2 + d3);
+                float D = (d0 + d1) + (d2 + d3);
+                if (ABL >= 4) D = vo[0] * (float)gid;
                 const float ra_ = __builtin_amdgcn_rcpf(1.0f - alpha[q]);
                 const float Tn = T * ra_;
                 const float fac = pass[q] ? alpha[q] * Tn : 0.0f;
@@ -526,6 +536,11 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
                 if (lane == 0) slotgid[nslots] = gid;
                 ++nslots;
                 if (nslots == B2_SLOTS) flush_slots();
+            }
+            if (ABL >= 3) {
+#pragma unroll
+                for (int v = 0; v < KB; ++v) KEEP(part[v]);
+                continue;
             }
             const float mine = R::run(part, lane);
             const int my_gid = __builtin_bit_cast(int, L.b[kk - my_q].w);
@@ -590,6 +605,14 @@ void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, 
                                  float *v_conic, float *v_colors, float *v_opacity, hipStream_t s) {
     dim3 grid(ntiles), block(256);
     switch (abl) {
+#define B2_WABL(L) hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, L>), grid, block, 0, s, C, off, 32, \
+        img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, final_Ts, final_idx, v_out, \
+        v_xy, v_conic, v_colors, v_opacity)
+        case 11: B2_WABL(1); break;
+        case 12: B2_WABL(2); break;
+        case 13: B2_WABL(3); break;
+        case 14: B2_WABL(4); break;
+        case 15: B2_WABL(5); break;
         case 1: hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3, 1>), grid, block, 0, s, B2_BWDN_ARGS); break;
         case 2: hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3, 2>), grid, block, 0, s, B2_BWDN_ARGS); break;
         case 3: hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3, 3>), grid, block, 0, s, B2_BWDN_ARGS); break;

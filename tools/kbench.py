@@ -66,6 +66,11 @@ def main():
         run(rgb, f"C=3 abl{lvl} {name}")
     lib.gg_debug_set_ablation(0)
     run(feat, "C=32 full  ")
+    for lvl, name in ((11, "no colour atomics"), (12, "no MFMA flush"), (13, "no butterfly"), (14, "no D"),
+                      (15, "geometry only")):
+        lib.gg_debug_set_ablation(lvl)
+        run(feat, f"C=32 abl{lvl} {name}")
+    lib.gg_debug_set_ablation(0)
 
 
 if __name__ == "__main__":

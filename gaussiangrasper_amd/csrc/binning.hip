@@ -321,19 +321,23 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, const uint32_t *__rest
 
 __global__ __launch_bounds__(256) void tile_bins_kernel(int64_t I,
                                                         const uint32_t *__restrict__ tkeys_sorted,
+                                                        uint32_t num_tiles,
                                                         int32_t *__restrict__ tile_bins,
                                                         int32_t *__restrict__ tile_out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= I) return;
     uint32_t cur = tkeys_sorted[i];
     if (tile_out) tile_out[i] = (int32_t)cur;
-    if (i == 0) tile_bins[2 * cur] = 0;
-    if (i == I - 1) tile_bins[2 * cur + 1] = (int32_t)I;
+    // tile ids >= num_tiles can only appear if the caller's I exceeds sum(num_tiles_hit) (entries
+    // never emitted); they are ignored instead of being used as an index
+    const bool cur_ok = cur < num_tiles;
+    if (i == 0 && cur_ok) tile_bins[2 * cur] = 0;
+    if (i == I - 1 && cur_ok) tile_bins[2 * cur + 1] = (int32_t)I;
     if (i > 0) {
         uint32_t prev = tkeys_sorted[i - 1];
         if (prev != cur) {
-            tile_bins[2 * prev + 1] = (int32_t)i;
-            tile_bins[2 * cur] = (int32_t)i;
+            if (prev < num_tiles) tile_bins[2 * prev + 1] = (int32_t)i;
+            if (cur_ok) tile_bins[2 * cur] = (int32_t)i;
         }
     }
 }
@@ -449,6 +453,10 @@ extern "C" int gg_bin_sort(int N, int64_t I, const float *xys, const float *dept
     uint32_t *kcur = w.tkeyA, *kalt = w.tkeyB;
     uint32_t *vcur = (passes % 2 == 0) ? out_vals : w.tvalTmp;
     uint32_t *valt = (passes % 2 == 0) ? w.tvalTmp : out_vals;
+    // entries the emission does not reach (caller's I larger than the true total) get an
+    // out-of-range tile id and id 0, so they sort to the end and are never dereferenced
+    (void)hipMemsetAsync(kcur, 0xFF, sizeof(uint32_t) * (size_t)I, s);
+    (void)hipMemsetAsync(vcur, 0, sizeof(uint32_t) * (size_t)I, s);
     hipLaunchKernelGGL(emit_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, order, w.offsets,
                        xys, radii, tiles_x, tiles_y, I, kcur, vcur);
     for (int pass = 0; pass < passes; ++pass) {
@@ -459,7 +467,7 @@ extern "C" int gg_bin_sort(int N, int64_t I, const float *xys, const float *dept
     }
     // 5. tile ranges
     hipLaunchKernelGGL(tile_bins_kernel, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, s, I, kcur,
-                       tile_bins, isect_tile_sorted);
+                       (uint32_t)T, tile_bins, isect_tile_sorted);
     gg_prof_end(GG_K_BIN_SORT, s);
     GG_CHECK_LAUNCH();
     return GG_OK;

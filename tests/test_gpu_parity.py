@@ -496,3 +496,27 @@ def test_config5_render_only_5m_128ch_1080p():
                                             opac, h, w, torch.ones(1, device=DEV))
         assert float((ones + tfin - 1).abs().max()) < 2e-5
     assert img.shape == (h, w, d) and bool(torch.isfinite(img).all())
+
+
+def test_bin_sort_tolerates_an_oversized_intersection_count(oracle):
+    """C-ABI robustness: a caller-supplied I larger than sum(num_tiles_hit) must not index out of
+    range; the real entries still come out exactly as the oracle's lists."""
+    from gaussiangrasper_amd import _lib
+    n, h, w = 20000, 160, 208
+    sc, v = _scene_view(n, h, w)
+    xys, depths, radii, conics, nth, _ = _project_oracle(oracle, sc, v)
+    ref = oracle.bin_and_sort(xys, depths, radii, nth, v.tile_bounds)
+    true_i, extra = ref["num_intersects"], 777
+    lib = _lib.load()
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    xt, dt, rt, nt = t(xys), t(depths), t(radii), t(nth)
+    tiles = v.tile_bounds[0] * v.tile_bounds[1]
+    ids = torch.empty(true_i + extra, dtype=torch.int32, device=DEV)
+    bins = torch.empty(tiles, 2, dtype=torch.int32, device=DEV)
+    ws = torch.empty(lib.gg_bin_sort_workspace(n, true_i + extra), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.gg_bin_sort(n, true_i + extra, P._ptr(xt), P._ptr(dt), P._ptr(rt), P._ptr(nt),
+                               v.tile_bounds[0], v.tile_bounds[1], P._ptr(ids), P._ptr(bins), None,
+                               P._ptr(ws), ws.numel(), P._stream(xt.device)), "gg_bin_sort")
+    torch.cuda.synchronize()
+    assert_bitexact(_np(bins), ref["tile_bins"], "tile_bins")
+    assert_bitexact(_np(ids[:true_i]), ref["gaussian_ids_sorted"], "gaussian_ids_sorted")

@@ -48,14 +48,6 @@ __device__ __forceinline__ bool rec_hits_rect(const float4 a, const float4 b, fl
 }
 
 
-__device__ __forceinline__ float dpp_xadd_row(float v) {
-    // all-reduce inside each 16-lane row: quad xor1, quad xor2, half mirror, row mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
-    return v;
-}
 __device__ __forceinline__ float swap_add32(float a, float b) {
     // lanes 0-31: a(own) + a(lane+32) ; lanes 32-63: b(lane-32) + b(own)
     auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a),
@@ -68,32 +60,6 @@ __device__ __forceinline__ float swap_add16(float a, float b) {
                                               __builtin_bit_cast(unsigned, b), false, false);
     return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
-
-// Halving butterfly: K per-lane values -> H2 registers; afterwards the 16 lanes of row
-// (b5,b4) all hold, in register j, the wave total of value red_var<K>(j,b4,b5).
-template <int K>
-struct Red {
-    static constexpr int H1 = (K + 1) / 2;
-    static constexpr int H2 = (H1 + 1) / 2;
-    __device__ static __forceinline__ void run(const float (&v)[K], float (&out)[H2]) {
-        float a[H1];
-#pragma unroll
-        for (int j = 0; j < H1; ++j) a[j] = swap_add32(v[j], (j + H1 < K) ? v[j + H1] : v[j]);
-#pragma unroll
-        for (int j = 0; j < H2; ++j)
-            out[j] = dpp_xadd_row(swap_add16(a[j], (j + H2 < H1) ? a[j + H2] : a[j]));
-    }
-    // which value does (register j, row bits b4,b5) hold, and is this row its unique owner?
-    __device__ static __forceinline__ int var(int j, int b4, int b5, bool &owner) {
-        owner = true;
-        int i = j;
-        if (j + H2 < H1) i = j + H2 * b4; else owner = owner && (b4 == 0);
-        int k = i;
-        if (i + H1 < K) k = i + H1 * b5; else owner = owner && (b5 == 0);
-        return k;
-    }
-};
-
 
 // ---------------------------------------------------------------------------------------------
 // Red6<K>: full halving butterfly, K <= 64 per-lane values -> ONE register per lane.

@@ -75,26 +75,3 @@ __device__ __forceinline__ void gg_tile_bbox(float cx, float cy, float radius, i
     y0 = gg_clampi_f(tcy - tr, tiles_y);
     y1 = gg_clampi_f((tcy + tr) + 1.0f, tiles_y);
 }
-
-// ---------------------------------------------------------------------------------------------
-// Wave64 helpers (DPP; no LDS traffic).
-// ---------------------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-__device__ __forceinline__ float gg_dpp_add(float v) {
-    int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK,
-                                            BANK_MASK, true);
-    return v + __builtin_bit_cast(float, moved);
-}
-// Sum over the 64 lanes; the total is valid in lane 63.
-__device__ __forceinline__ float gg_wave_sum_to_lane63(float v) {
-    v = gg_dpp_add<0x111, 0xf, 0xf>(v);  // row_shr:1
-    v = gg_dpp_add<0x112, 0xf, 0xf>(v);  // row_shr:2
-    v = gg_dpp_add<0x114, 0xf, 0xe>(v);  // row_shr:4
-    v = gg_dpp_add<0x118, 0xf, 0xc>(v);  // row_shr:8
-    v = gg_dpp_add<0x142, 0xa, 0xf>(v);  // row_bcast:15
-    v = gg_dpp_add<0x143, 0xc, 0xf>(v);  // row_bcast:31
-    return v;
-}
-__device__ __forceinline__ int gg_lane_id() {
-    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-}

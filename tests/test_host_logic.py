@@ -136,6 +136,31 @@ def test_all_four_outputs_and_xys_grad_accumulates():
     assert torch.allclose(out["xys"].grad, sum(g_each), rtol=1e-5, atol=1e-6)
 
 
+def test_fused_single_call_path_matches_four_calls_on_cpu():
+    """SURVEY 8f-1 host logic: feature|rgb|depth|normal through ONE ND call (oracle-backed on CPU)
+    gives the four images of the four separate calls and the same parameter gradients."""
+    import oracle_ops
+    from gaussiangrasper_amd.camera import ring_cameras
+    from gaussiangrasper_amd.pipeline import backward_view, render_view, seeded_cotangents
+    from gaussiangrasper_amd.scene import make_scene
+    v = ring_cameras(2, 48, 64)[1]
+    outs, grads = [], []
+    for fused in (False, True):
+        sc = make_scene(600, feature_dim=5, config_index=8)
+        sc.scales.add_(1.5)
+        for p in sc.params():
+            p.requires_grad_(True)
+        out = render_view(sc, v, oracle_ops, fused=fused)
+        backward_view(out, seeded_cotangents(out, seed=5))
+        outs.append(out)
+        grads.append([p.grad.clone() for p in sc.params()])
+    for k in ("rgb", "feature", "depth", "normal"):
+        assert outs[0][k].shape == outs[1][k].shape
+        assert torch.equal(outs[0][k], outs[1][k]), k       # same per-channel fmaf sequence
+    for a, b in zip(grads[0], grads[1]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * float(a.abs().max()))
+
+
 def test_view_sharding():
     from gaussiangrasper_amd.dist import shard_views
     assert shard_views(64, 3, 8) == list(range(3, 64, 8))

@@ -62,6 +62,47 @@ def _workspace(nbytes: int, dev: torch.device) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------------
+# intersection count: started right after the projection, read when the first rasterize call needs it
+# ------------------------------------------------------------------------------------------------
+# The reference reads the cumulative tile count with `.item()` inside every rasterize call (SURVEY
+# a5): a full host<->device round trip with the GPU idle while the host then enqueues the sort.  Here
+# the count kernel and an async copy to pinned memory are enqueued at the end of
+# ProjectGaussians.forward, followed by an event; whatever the caller enqueues next (SH, activations)
+# keeps the GPU busy, and bin_and_sort_gaussians only waits on that event.
+_PIN_SLOTS = 64
+_pin_ring = {}          # device index -> (pinned int64[_PIN_SLOTS], next slot)
+_pending_counts = {}    # (data_ptr, version) of num_tiles_hit -> (event, pinned view, keep-alive)
+
+
+def _start_count(num_tiles_hit: Tensor) -> None:
+    dev = num_tiles_hit.device
+    lib = _lib.load()
+    ring, nxt = _pin_ring.get(dev.index, (None, 0))
+    if ring is None:
+        ring = torch.empty(_PIN_SLOTS, dtype=torch.int64).pin_memory()
+    slot = ring[nxt:nxt + 1]
+    _pin_ring[dev.index] = (ring, (nxt + 1) % _PIN_SLOTS)
+    total = torch.empty(1, dtype=torch.int64, device=dev)
+    _lib.check(lib.gg_count_intersects(num_tiles_hit.shape[0], _ptr(num_tiles_hit), _ptr(total), None, 0,
+                                       _stream(dev)), "gg_count_intersects")
+    slot.copy_(total, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    if len(_pending_counts) > 8:      # views whose count was never consumed
+        _pending_counts.clear()
+    _pending_counts[(num_tiles_hit.data_ptr(), num_tiles_hit._version)] = (ev, slot, num_tiles_hit, total)
+
+
+def _take_count(num_tiles_hit: Tensor):
+    hit = _pending_counts.pop((num_tiles_hit.data_ptr(), num_tiles_hit._version), None)
+    if hit is None or hit[2] is not num_tiles_hit:
+        return None
+    ev, slot, _, _ = hit
+    ev.synchronize()
+    return int(slot.item())
+
+
+# ------------------------------------------------------------------------------------------------
 # ProjectGaussians
 # ------------------------------------------------------------------------------------------------
 class ProjectGaussians(Function):
@@ -103,6 +144,7 @@ class ProjectGaussians(Function):
                        int(img_height), int(img_width))
         ctx.save_for_backward(means3d, scales, quats, viewmat, projmat, radii, conics)
         ctx.mark_non_differentiable(radii, num_tiles_hit)
+        _start_count(num_tiles_hit)
         return xys, depths, radii, conics, num_tiles_hit, cov3d
 
     @staticmethod
@@ -209,10 +251,12 @@ def bin_and_sort_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, num_tiles
     tiles_y = (img_height + BLOCK - 1) // BLOCK
     xys_c, depths_c = _f32(xys.detach()), _f32(depths.detach())
     radii_c, nth_c = _i32(radii), _i32(num_tiles_hit)
-    total = torch.empty(1, dtype=torch.int64, device=dev)
-    _lib.check(lib.gg_count_intersects(n, _ptr(nth_c), _ptr(total), None, 0, _stream(dev)),
-               "gg_count_intersects")
-    num_intersects = int(total.item())
+    num_intersects = _take_count(num_tiles_hit)       # started by ProjectGaussians.forward
+    if num_intersects is None:                        # tensors that did not come from our projection
+        total = torch.empty(1, dtype=torch.int64, device=dev)
+        _lib.check(lib.gg_count_intersects(n, _ptr(nth_c), _ptr(total), None, 0, _stream(dev)),
+                   "gg_count_intersects")
+        num_intersects = int(total.item())
     tile_bins = torch.empty(tiles_x * tiles_y, 2, dtype=torch.int32, device=dev)
     ids_sorted = torch.empty(max(num_intersects, 1), dtype=torch.int32, device=dev)
     ws_bytes = lib.gg_bin_sort_workspace(n, num_intersects)

@@ -371,7 +371,9 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
 
 // ABL > 0 (measurement builds only): 1 no colour-gradient atomics, 2 also no MFMA flush,
 // 3 also no butterfly / geometry atomics, 4 also no D (colour loads + 32 fma), 5 geometry only
-template <bool FULL, int ABL = 0>
+// CHD: channels of this chunk rounded up to 8, 16 or 32 — registers for v_out and the length of the
+// D loop (a 7-channel tail chunk, e.g. rgb+depth+normal of the fused call, does not pay for 32).
+template <bool FULL, int ABL = 0, int CHD = 32>
 __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
     const float *__restrict__ final_T, const int32_t *__restrict__ final_idx,
     const float *__restrict__ v_out, float *__restrict__ v_xy, float *__restrict__ v_conic,
     float *__restrict__ v_colors, float *__restrict__ v_opacity) {
-    constexpr int CH = 32;
+    constexpr int CH = CHD;
     constexpr int KG = 6;
     constexpr int KB = GRP * KG;
     using R = Red6<KB>;
@@ -587,14 +589,16 @@ void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w
         hipLaunchKernelGGL((blend2_bwd_narrow_kernel<2>), grid, block, 0, s, B2_BWDN_ARGS);
     else if (width == 3)
         hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3>), grid, block, 0, s, B2_BWDN_ARGS);
+#define B2_BWDW_ARGS C, off, n, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, \
+                     final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity
     else if (n == 32)
-        hipLaunchKernelGGL((blend2_bwd_wide_kernel<true>), grid, block, 0, s, C, off, n, img_h, img_w,
-                           tiles_x, ntiles, ids, bins, rec, colors, background, final_Ts, final_idx,
-                           v_out, v_xy, v_conic, v_colors, v_opacity);
+        hipLaunchKernelGGL((blend2_bwd_wide_kernel<true>), grid, block, 0, s, B2_BWDW_ARGS);
+    else if (n <= 8)
+        hipLaunchKernelGGL((blend2_bwd_wide_kernel<false, 0, 8>), grid, block, 0, s, B2_BWDW_ARGS);
+    else if (n <= 16)
+        hipLaunchKernelGGL((blend2_bwd_wide_kernel<false, 0, 16>), grid, block, 0, s, B2_BWDW_ARGS);
     else
-        hipLaunchKernelGGL((blend2_bwd_wide_kernel<false>), grid, block, 0, s, C, off, n, img_h, img_w,
-                           tiles_x, ntiles, ids, bins, rec, colors, background, final_Ts, final_idx,
-                           v_out, v_xy, v_conic, v_colors, v_opacity);
+        hipLaunchKernelGGL((blend2_bwd_wide_kernel<false, 0, 32>), grid, block, 0, s, B2_BWDW_ARGS);
 }
 
 // measurement-only entry (tools/kbench.py): ablated builds of the 3-channel backward

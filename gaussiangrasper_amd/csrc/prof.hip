@@ -75,6 +75,8 @@ extern "C" const char *gg_prof_name(int id) {
         case GG_K_SH_BWD: return "sh_bwd_kernel";
         case GG_K_BIN_SORT: return "gg_bin_sort(all launches)";
         case GG_K_BLEND_PREP: return "blend_prep_kernel";
+        case GG_K_QUAT_FWD: return "quat_to_rotmat_fwd_kernel";
+        case GG_K_QUAT_BWD: return "quat_to_rotmat_bwd_kernel";
         default: break;
     }
     if (id >= GG_K_BLEND_FWD && id < GG_K_BLEND_FWD + 6) {

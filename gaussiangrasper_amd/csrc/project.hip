@@ -484,6 +484,105 @@ extern "C" int gg_sh_bwd(int N, int K, int deg, const float *viewdirs, const flo
     return sh_dispatch(false, N, K, deg, viewdirs, v_colors, v_coeffs, stream);
 }
 
+// ------------------------------------------------------------------------------------------------
+// quat_to_rotmat (gsplat._torch_impl; reference gaussian_splatting.py:516,614): one lane per
+// quaternion, the (N,9) side staged through LDS so that global traffic stays coalesced.
+// Operation order is the oracle's (ggo_quat_to_rotmat_fwd): bit-exact forward.
+// ------------------------------------------------------------------------------------------------
+#define QR_THREADS 256
+__device__ __forceinline__ float quat_normalise(float4 q, float &w, float &x, float &y, float &z) {
+    float nn = ((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w;
+    float d = fmaxf(sqrtf(nn), GG_QUAT_NORM_EPS);
+    w = q.x / d;
+    x = q.y / d;
+    y = q.z / d;
+    z = q.w / d;
+    return d;
+}
+__global__ void __launch_bounds__(QR_THREADS) quat_to_rotmat_fwd_kernel(int N, const float4 *quats,
+                                                                       float *rot) {
+    __shared__ float tile[QR_THREADS * 9];
+    const int base = blockIdx.x * QR_THREADS, i = base + threadIdx.x;
+    if (i < N) {
+        float w, x, y, z;
+        quat_normalise(quats[i], w, x, y, z);
+        float *R = tile + threadIdx.x * 9;   // stride 9 words: conflict-free (9 odd)
+        R[0] = 1.0f - 2.0f * (y * y + z * z);
+        R[1] = 2.0f * (x * y - w * z);
+        R[2] = 2.0f * (x * z + w * y);
+        R[3] = 2.0f * (x * y + w * z);
+        R[4] = 1.0f - 2.0f * (x * x + z * z);
+        R[5] = 2.0f * (y * z - w * x);
+        R[6] = 2.0f * (x * z - w * y);
+        R[7] = 2.0f * (y * z + w * x);
+        R[8] = 1.0f - 2.0f * (x * x + y * y);
+    }
+    __syncthreads();
+    const long lim = (long)min(QR_THREADS, N - base) * 9;
+    float *dst = rot + (long)base * 9;
+    for (int k = threadIdx.x; k < lim; k += QR_THREADS) dst[k] = tile[k];
+}
+__global__ void __launch_bounds__(QR_THREADS) quat_to_rotmat_bwd_kernel(int N, const float4 *quats,
+                                                                       const float *v_rot,
+                                                                       float4 *v_quats) {
+    __shared__ float tile[QR_THREADS * 9];
+    const int base = blockIdx.x * QR_THREADS, i = base + threadIdx.x;
+    const long lim = (long)min(QR_THREADS, N - base) * 9;
+    const float *src = v_rot + (long)base * 9;
+    for (int k = threadIdx.x; k < lim; k += QR_THREADS) tile[k] = src[k];
+    __syncthreads();
+    if (i >= N) return;
+    float w, x, y, z;
+    const float d = quat_normalise(quats[i], w, x, y, z);
+    const float *g = tile + threadIdx.x * 9;
+    // gradient w.r.t. the normalised quaternion
+    float vw = 2.0f * (x * (g[7] - g[5]) + y * (g[2] - g[6]) + z * (g[3] - g[1]));
+    float vx = 2.0f * (y * (g[1] + g[3]) + z * (g[2] + g[6]) + w * (g[7] - g[5]) -
+                       2.0f * x * (g[4] + g[8]));
+    float vy = 2.0f * (x * (g[1] + g[3]) + z * (g[5] + g[7]) + w * (g[2] - g[6]) -
+                       2.0f * y * (g[0] + g[8]));
+    float vz = 2.0f * (x * (g[2] + g[6]) + y * (g[5] + g[7]) + w * (g[3] - g[1]) -
+                       2.0f * z * (g[0] + g[4]));
+    // through n = q / max(|q|, eps): (v - n <n, v>) / |q| above the floor, v / eps below it
+    float4 out;
+    if (d > GG_QUAT_NORM_EPS) {
+        float dot = ((w * vw + x * vx) + y * vy) + z * vz;
+        out = make_float4((vw - w * dot) / d, (vx - x * dot) / d, (vy - y * dot) / d,
+                          (vz - z * dot) / d);
+    } else {
+        out = make_float4(vw / d, vx / d, vy / d, vz / d);
+    }
+    v_quats[i] = out;
+}
+extern "C" int gg_quat_to_rotmat_fwd(int N, const float *quats, float *rot, gg_stream_t stream) {
+    GG_REQUIRE(N >= 0, "num_points < 0");
+    if (N == 0) return GG_OK;
+    GG_REQUIRE(quats && rot, "null pointer");
+    GG_REQUIRE(((uintptr_t)quats & 15) == 0, "quats must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    gg_prof_begin(GG_K_QUAT_FWD, s);
+    hipLaunchKernelGGL(quat_to_rotmat_fwd_kernel, dim3((N + QR_THREADS - 1) / QR_THREADS),
+                       dim3(QR_THREADS), 0, s, N, (const float4 *)quats, rot);
+    gg_prof_end(GG_K_QUAT_FWD, s);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+extern "C" int gg_quat_to_rotmat_bwd(int N, const float *quats, const float *v_rot, float *v_quats,
+                                     gg_stream_t stream) {
+    GG_REQUIRE(N >= 0, "num_points < 0");
+    if (N == 0) return GG_OK;
+    GG_REQUIRE(quats && v_rot && v_quats, "null pointer");
+    GG_REQUIRE((((uintptr_t)quats | (uintptr_t)v_quats) & 15) == 0,
+               "quats / v_quats must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    gg_prof_begin(GG_K_QUAT_BWD, s);
+    hipLaunchKernelGGL(quat_to_rotmat_bwd_kernel, dim3((N + QR_THREADS - 1) / QR_THREADS),
+                       dim3(QR_THREADS), 0, s, N, (const float4 *)quats, v_rot, (float4 *)v_quats);
+    gg_prof_end(GG_K_QUAT_BWD, s);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
 __global__ void expf_kernel(int n, const float *x, float *y) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = gg_expf(x[i]);

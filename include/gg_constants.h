@@ -21,6 +21,7 @@
 #define GG_EIG_FLOOR 0.1f            /* max(0.1, b^2-det) under the eigenvalue sqrt      */
 #define GG_W_EPS 1e-6f               /* rw = 1/(w_clip + 1e-6)                           */
 #define GG_PIX_OFFSET 0.5f           /* xy = 0.5*W*ndc + cx - 0.5 ; pixel centres integer */
+#define GG_QUAT_NORM_EPS 1e-12f     /* quat_to_rotmat: q / max(|q|, eps) (F.normalize default) */
 #define GG_BLOCK 16                  /* tile edge in pixels (BLOCK_X = BLOCK_Y)          */
 
 /* ---- blending ---- */

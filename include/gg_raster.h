@@ -75,6 +75,16 @@ int gg_sh_fwd(int num_points, int num_bases, int degrees_to_use, const float *vi
 int gg_sh_bwd(int num_points, int num_bases, int degrees_to_use, const float *viewdirs,
               const float *v_colors, float *v_coeffs, gg_stream_t stream);
 
+/* ---- quat_to_rotmat ------------------------------------------------------------------------
+ * Replace gsplat `_torch_impl.quat_to_rotmat` (differentiable torch code there: ~35 elementwise
+ * launches forward, ~70 backward; reference call sites gaussian_splatting.py:516,614 — the
+ * normals rendered at :772-784 — and scripts/update.py:204,229).  quats (N,4) wxyz, normalised
+ * as q / max(|q|, 1e-12); rot (N,3,3) row-major.  bwd: v_quats = d<rot, v_rot>/d quats, through
+ * the normalisation. */
+int gg_quat_to_rotmat_fwd(int num_points, const float *quats, float *rot, gg_stream_t stream);
+int gg_quat_to_rotmat_bwd(int num_points, const float *quats, const float *v_rot, float *v_quats,
+                          gg_stream_t stream);
+
 /* ---- binning -------------------------------------------------------------------------------
  * Together replace gsplat `compute_cumulative_intersects` + `bin_and_sort_gaussians`
  * (`_C.map_gaussian_to_intersects`, torch.sort, `_C.get_tile_bin_edges`) that every
@@ -129,6 +139,8 @@ int gg_blend_bwd(int channels, int num_points, int img_height, int img_width,
 #define GG_K_SH_BWD 3
 #define GG_K_BIN_SORT 4   /* the whole gg_bin_sort launch sequence */
 #define GG_K_BLEND_PREP 5
+#define GG_K_QUAT_FWD 6
+#define GG_K_QUAT_BWD 7
 #define GG_K_BLEND_FWD 10 /* + width index: template widths {1,3,4,8,16,32} -> 0..5 */
 #define GG_K_BLEND_BWD 20 /* + width index */
 #define GG_PROF_NUM_KERNELS 32

@@ -138,6 +138,61 @@ static inline void quat_to_R(const REAL *q, REAL *R, REAL *qn, REAL *inv_norm) {
 }
 
 /* ------------------------------------------------------------------------------------------
+ * quat_to_rotmat_fwd / _bwd — restate gsplat `_torch_impl.quat_to_rotmat` (†: F.normalize(q) then
+ * the standard matrix; differentiable torch code) as called at
+ * nerfstudio/models/gaussian_splatting.py:516,614 and scripts/update.py:204,229.  The backward
+ * is the analytic VJP through the matrix entries and through n = q / max(|q|, 1e-12).
+ * ---------------------------------------------------------------------------------------- */
+static inline REAL quat_normalise(const REAL *q, REAL *n) {
+    REAL nn = ((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3];
+    REAL d = SQRT(nn);
+    if (!(d >= R_(GG_QUAT_NORM_EPS))) d = R_(GG_QUAT_NORM_EPS);
+    for (int k = 0; k < 4; ++k) n[k] = q[k] / d;
+    return d;
+}
+void NAME(quat_to_rotmat_fwd)(int N, const REAL *quats, REAL *rot) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) {
+        REAL n[4];
+        quat_normalise(quats + 4 * (size_t)i, n);
+        const REAL w = n[0], x = n[1], y = n[2], z = n[3];
+        REAL *R = rot + 9 * (size_t)i;
+        R[0] = R_(1.0f) - R_(2.0f) * (y * y + z * z);
+        R[1] = R_(2.0f) * (x * y - w * z);
+        R[2] = R_(2.0f) * (x * z + w * y);
+        R[3] = R_(2.0f) * (x * y + w * z);
+        R[4] = R_(1.0f) - R_(2.0f) * (x * x + z * z);
+        R[5] = R_(2.0f) * (y * z - w * x);
+        R[6] = R_(2.0f) * (x * z - w * y);
+        R[7] = R_(2.0f) * (y * z + w * x);
+        R[8] = R_(1.0f) - R_(2.0f) * (x * x + y * y);
+    }
+}
+void NAME(quat_to_rotmat_bwd)(int N, const REAL *quats, const REAL *v_rot, REAL *v_quats) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) {
+        REAL n[4], v[4];
+        const REAL d = quat_normalise(quats + 4 * (size_t)i, n);
+        const REAL w = n[0], x = n[1], y = n[2], z = n[3];
+        const REAL *g = v_rot + 9 * (size_t)i;
+        v[0] = R_(2.0f) * (x * (g[7] - g[5]) + y * (g[2] - g[6]) + z * (g[3] - g[1]));
+        v[1] = R_(2.0f) * (y * (g[1] + g[3]) + z * (g[2] + g[6]) + w * (g[7] - g[5]) -
+                           R_(2.0f) * x * (g[4] + g[8]));
+        v[2] = R_(2.0f) * (x * (g[1] + g[3]) + z * (g[5] + g[7]) + w * (g[2] - g[6]) -
+                           R_(2.0f) * y * (g[0] + g[8]));
+        v[3] = R_(2.0f) * (x * (g[2] + g[6]) + y * (g[5] + g[7]) + w * (g[3] - g[1]) -
+                           R_(2.0f) * z * (g[0] + g[4]));
+        REAL *o = v_quats + 4 * (size_t)i;
+        if (d > R_(GG_QUAT_NORM_EPS)) {
+            REAL dot = ((w * v[0] + x * v[1]) + y * v[2]) + z * v[3];
+            for (int k = 0; k < 4; ++k) o[k] = (v[k] - n[k] * dot) / d;
+        } else {
+            for (int k = 0; k < 4; ++k) o[k] = v[k] / d;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * project_fwd — restates gsplat forward.cu project_gaussians_forward_kernel (†) as reached by
  * ProjectGaussians.apply at nerfstudio/models/gaussian_splatting.py:699-713.
  * viewmat: row-major, first 12 floats used (the caller passes viewmat[:3,:]); projmat: 4x4

@@ -211,14 +211,21 @@ def rasterize_fwd(xys, depths, radii, conics, num_tiles_hit, colors, opacity, im
     return out, dict(bins=b, final_Ts=ft, final_idx=fi)
 
 
-def quat_to_rotmat(quats):
+def quat_to_rotmat(quats, dtype=np.float32):
     """gsplat._torch_impl.quat_to_rotmat (reference call sites gaussian_splatting.py:516,614;
     scripts/update.py:204,229): normalise wxyz, standard rotation matrix, (...,3,3)."""
-    q = np.asarray(quats, np.float64)
-    q = q / np.linalg.norm(q, axis=-1, keepdims=True)
-    w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
-    m = np.stack([
-        1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
-        2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
-        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], axis=-1)
-    return m.reshape(q.shape[:-1] + (3, 3))
+    lib, pre, _ = _lib(dtype)
+    q = np.ascontiguousarray(np.asarray(quats, dtype).reshape(-1, 4))
+    rot = np.empty((q.shape[0], 9), dtype)
+    getattr(lib, pre + "quat_to_rotmat_fwd")(C.c_int(q.shape[0]), _p(q), _p(rot))
+    return rot.reshape(np.shape(quats)[:-1] + (3, 3))
+
+
+def quat_to_rotmat_bwd(quats, v_rot, dtype=np.float32):
+    """VJP of quat_to_rotmat: v_quats (...,4) for v_rot (...,3,3)."""
+    lib, pre, _ = _lib(dtype)
+    q = np.ascontiguousarray(np.asarray(quats, dtype).reshape(-1, 4))
+    g = np.ascontiguousarray(np.asarray(v_rot, dtype).reshape(-1, 9))
+    out = np.empty_like(q)
+    getattr(lib, pre + "quat_to_rotmat_bwd")(C.c_int(q.shape[0]), _p(q), _p(g), _p(out))
+    return out.reshape(np.shape(quats))

@@ -7,7 +7,6 @@ import torch
 from torch.autograd import Function
 
 from oracle import oracle as O
-from gaussiangrasper_amd.ops import quat_to_rotmat  # noqa: F401  (pure torch, device agnostic)
 
 
 def _np(t):
@@ -84,3 +83,29 @@ class RasterizeGaussians(_Rasterize):
 
 class NDRasterizeGaussians(_Rasterize):
     pass
+
+
+class _QuatToRotmat(Function):
+    @staticmethod
+    def forward(ctx, quat):
+        ctx.q = _np(quat)
+        return torch.from_numpy(O.quat_to_rotmat(ctx.q))
+
+    @staticmethod
+    def backward(ctx, v_rot):
+        return torch.from_numpy(O.quat_to_rotmat_bwd(ctx.q, _np(v_rot)))
+
+
+def quat_to_rotmat(quat):
+    return _QuatToRotmat.apply(quat)
+
+
+def quat_to_rotmat_torch(quat):
+    """The published torch expression of gsplat._torch_impl.quat_to_rotmat (†) — the plain torch
+    reference the oracle's and the HIP kernel's forward and backward are checked against."""
+    w, x, y, z = torch.unbind(torch.nn.functional.normalize(quat, dim=-1), dim=-1)
+    mat = torch.stack([
+        1 - 2 * (y ** 2 + z ** 2), 2 * (x * y - w * z), 2 * (x * z + w * y),
+        2 * (x * y + w * z), 1 - 2 * (x ** 2 + z ** 2), 2 * (y * z - w * x),
+        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x ** 2 + y ** 2)], dim=-1)
+    return mat.reshape(quat.shape[:-1] + (3, 3))

@@ -294,9 +294,10 @@ def test_fused_multi_output_equals_four_calls():
     images of the reference's four calls bit for bit, and the same parameter gradients up to fp32
     summation order (tolerance 1e-4*max|grad| + 2e-3*|grad|)."""
     from gaussiangrasper_amd.pipeline import activate, rasterize_activated, rasterize_activated_fused
+    import oracle_ops
     n, h, w = 60000, 300, 400
     sc, v = _scene_view(n, h, w)
-    act = activate(sc, v, P.quat_to_rotmat)
+    act = activate(sc, v, oracle_ops.quat_to_rotmat)
     a4, af = _activated_leaves(act, DEV), _activated_leaves(act, DEV)
     P.clear_bin_cache()
     out4 = rasterize_activated(a4, v, P)
@@ -544,3 +545,33 @@ def test_config2_config3_full_size_vs_oracle(oracle):
         assert_bitexact(_np(out_g[k]), _np(out_c[k]), f"image.{k}")
     for name in ("means", "scales", "quats", "opac", "sh", "feature", "normals"):
         assert_close(_np(a_g[name].grad), _np(a_c[name].grad), f"grad.{name}", rtol=2e-3, atol_frac=3e-5)
+
+
+def test_quat_to_rotmat_hip_vs_oracle_and_torch(oracle):
+    """gg_quat_to_rotmat_fwd bit-exact against the oracle; backward within 1e-6 + 1e-5*|g| of it and
+    of torch autograd through the published expression; batched shapes; CPU tensors refused."""
+    import oracle_ops
+    g = torch.Generator().manual_seed(5)
+    n = 100_003                                    # not a multiple of the 256-thread block
+    q = torch.randn(n, 4, generator=g) * 2
+    q[7] = 0.0                                     # |q| below the normalisation floor
+    v = torch.randn(n, 3, 3, generator=g)
+    qg = q.to(DEV).requires_grad_(True)
+    R = P.quat_to_rotmat(qg)
+    assert R.shape == (n, 3, 3)
+    assert_bitexact(_np(R), oracle.quat_to_rotmat(q.numpy()), "rot")
+    (vq,) = torch.autograd.grad(R, qg, v.to(DEV))
+    vq_o = oracle.quat_to_rotmat_bwd(q.numpy(), v.numpy())
+    assert np.allclose(_np(vq), vq_o, atol=1e-6, rtol=1e-5)
+    qt = q.clone().requires_grad_(True)
+    (vq_t,) = torch.autograd.grad(oracle_ops.quat_to_rotmat_torch(qt), qt, v)
+    keep = torch.ones(n, dtype=torch.bool)
+    keep[7] = False
+    assert np.allclose(_np(vq)[keep.numpy()], vq_t.numpy()[keep.numpy()], atol=3e-6, rtol=1e-4)
+    qb = torch.randn(3, 5, 4, generator=g).to(DEV)
+    assert P.quat_to_rotmat(qb).shape == (3, 5, 3, 3)
+    assert P.quat_to_rotmat(torch.zeros(0, 4, device=DEV)).shape == (0, 3, 3)
+    with pytest.raises(RuntimeError):
+        P.quat_to_rotmat(torch.randn(4, 4))
+    with pytest.raises(ValueError):
+        P.quat_to_rotmat(torch.randn(4, 3, device=DEV))

@@ -215,15 +215,32 @@ def test_no_intersections_returns_background(oracle):
 
 
 def test_quat_to_rotmat(oracle):
-    from gsplat._torch_impl import quat_to_rotmat
-    q = torch.randn(50, 4, generator=torch.Generator().manual_seed(0))
-    R = quat_to_rotmat(q)
+    """oracle forward/backward of quat_to_rotmat vs the published torch expression (autograd)."""
+    import oracle_ops
+    g = torch.Generator().manual_seed(0)
+    q = (torch.randn(50, 4, generator=g) * 3).requires_grad_(True)     # deliberately unnormalised
+    R = oracle_ops.quat_to_rotmat_torch(q)
     assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3).expand(50, 3, 3), atol=1e-5)
     assert torch.allclose(torch.linalg.det(R), torch.ones(50), atol=1e-5)
-    assert np.allclose(R.numpy(), oracle.quat_to_rotmat(q.numpy()), atol=1e-6)
+    assert np.allclose(R.detach().numpy(), oracle.quat_to_rotmat(q.detach().numpy()), atol=1e-6)
+    v = torch.randn(50, 3, 3, generator=g)
+    (vq_t,) = torch.autograd.grad(R, q, v)
+    vq_o = oracle.quat_to_rotmat_bwd(q.detach().numpy(), v.numpy())
+    assert np.allclose(vq_o, vq_t.numpy(), atol=2e-6, rtol=1e-5)
+    # float64 build against float64 autograd: tight
+    q64 = q.detach().double().requires_grad_(True)
+    (vq_t64,) = torch.autograd.grad(oracle_ops.quat_to_rotmat_torch(q64), q64, v.double())
+    vq_o64 = oracle.quat_to_rotmat_bwd(q64.detach().numpy(), v.double().numpy(), dtype=np.float64)
+    assert np.allclose(vq_o64, vq_t64.numpy(), atol=1e-13, rtol=1e-12)
+    # the oracle-backed autograd.Function used by the CPU replays
+    q2 = q.detach().clone().requires_grad_(True)
+    (vq_f,) = torch.autograd.grad(oracle_ops.quat_to_rotmat(q2), q2, v)
+    assert np.array_equal(vq_f.numpy(), vq_o)
+    # batched leading dims
+    assert oracle.quat_to_rotmat(np.ones((2, 5, 4), np.float32)).shape == (2, 5, 3, 3)
     # wxyz convention: 90 degrees about z maps x -> y
     s = math.sqrt(0.5)
-    Rz = quat_to_rotmat(torch.tensor([[s, 0, 0, s]]))[0]
+    Rz = torch.from_numpy(oracle.quat_to_rotmat(np.array([[s, 0, 0, s]], np.float32)))[0]
     assert torch.allclose(Rz @ torch.tensor([1.0, 0, 0]), torch.tensor([0.0, 1, 0]), atol=1e-6)
 
 

@@ -30,13 +30,10 @@ SIGNATURES = {
     "gg_count_intersects": (_I, [_I, _P, _P, _P, _SZ, _P]),
     "gg_bin_sort_workspace": (_SZ, [_I, _I64]),
     "gg_bin_sort": (_I, [_I, _I64, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
-    "gg_geo_sort_bytes": (_SZ, [_I64]),
-    "gg_geo_sort": (_I, [_I64, _P, _P, _P, _P, _P]),
-    "gg_blend_workspace": (_SZ, [_I, _I64]),
-    "gg_blend_fwd": (_I, [_I, _I, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ,
-                          _P]),
-    "gg_blend_bwd": (_I, [_I, _I, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                          _P, _P, _P, _SZ, _P]),
+    "gg_blend_workspace": (_SZ, [_I]),
+    "gg_blend_fwd": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "gg_blend_bwd": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                          _P, _SZ, _P]),
     "gg_expf_array": (_I, [_I, _P, _P, _P]),
     "gg_debug_set_ablation": (_I, [_I]),
     "gg_prof_enable": (_I, [_I]),

@@ -6,77 +6,52 @@
 #include "blend_common.h"
 
 // ---------------------------------------------------------------------------------------------
-// per-call record of the narrow path: {opacity, colour 0..2 of this channel chunk} per Gaussian — the
-// one 16-byte gather a surviving list entry makes (32-channel chunks gather the opacity alone)
+// prep: pack xys / conics / opacity into 32-byte records (one gather per list entry later)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void blend_prep_kernel(int N, int C, int ch_off, int nch,
+__global__ __launch_bounds__(256) void blend_prep_kernel(int N, const float *__restrict__ xys,
+                                                         const float *__restrict__ conics,
                                                          const float *__restrict__ opacity,
-                                                         const float *__restrict__ colors,
-                                                         float4 *__restrict__ crec) {
+                                                         GRec *__restrict__ rec) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    const float *c = colors + (size_t)i * C + ch_off;
-    crec[i] = make_float4(opacity[i], c[0], nch > 1 ? c[1] : 0.0f, nch > 2 ? c[2] : 0.0f);
+    GRec r;
+    r.x = xys[2 * (size_t)i];
+    r.y = xys[2 * (size_t)i + 1];
+    r.opac = opacity[i];
+    r.ca = conics[3 * (size_t)i];
+    r.cb = conics[3 * (size_t)i + 1];
+    r.cc = conics[3 * (size_t)i + 2];
+    r.pad = 0.0f;
+    // alpha = opac*exp(-sigma) >= 1/255  <=>  sigma <= ln(255*opac).  Margins absorb the fp32
+    // rounding of sigma (rel ~5e-7), of gg_expf (2 ulp) and of the fast log (1e-6).
+    float t = __logf(255.0f * r.opac);
+    t = t + 0.002f * fabsf(t) + 0.002f;
+    if (!(r.opac > 0.0f)) t = -1.0f;                   // alpha <= 0 < 1/255 always
+    if (r.opac != r.opac) t = __builtin_inff();         // NaN opacity: never cull (NaN propagates)
+    r.thr = t;
+    float4 *dst = reinterpret_cast<float4 *>(rec + i);
+    dst[0] = make_float4(r.x, r.y, r.opac, r.thr);
+    dst[1] = make_float4(r.ca, r.cb, r.cc, r.pad);
 }
 
-// ---------------------------------------------------------------------------------------------
-// tile-sorted geometry stream: geo[e] = geometry of Gaussian ids[e] (blend_common.h, GG_GEO_BYTES)
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void geo_sort_kernel(long I, const int32_t *__restrict__ ids,
-                                                       const float *__restrict__ xys,
-                                                       const float *__restrict__ conics,
-                                                       float4 *__restrict__ geo) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= I) return;
-    const int g = ids[e];
-    const float2 xy = reinterpret_cast<const float2 *>(xys)[g];
-    const float *cn = conics + 3 * (size_t)g;
-    geo[2 * e] = make_float4(xy.x, xy.y, cn[0], cn[1]);
-    geo[2 * e + 1] = make_float4(cn[2], __builtin_bit_cast(float, g), 0.0f, 0.0f);
-}
-
-extern "C" size_t gg_geo_sort_bytes(int64_t num_intersects) {
-    return gg_align_up((size_t)GG_GEO_BYTES * (size_t)(num_intersects > 0 ? num_intersects : 1), 256);
-}
-extern "C" int gg_geo_sort(int64_t I, const int32_t *ids, const float *xys, const float *conics,
-                           void *geo_sorted, gg_stream_t stream) {
-    GG_REQUIRE(I >= 0, "num_intersects < 0");
-    if (I == 0) return GG_OK;
-    GG_REQUIRE(ids && xys && conics && geo_sorted, "null pointer");
-    GG_REQUIRE((((uintptr_t)geo_sorted | (uintptr_t)xys) & 7) == 0 && ((uintptr_t)geo_sorted & 15) == 0,
-               "geo_sorted must be 16-byte and xys 8-byte aligned");
-    hipStream_t s = (hipStream_t)stream;
-    gg_prof_begin(GG_K_GEO_SORT, s);
-    hipLaunchKernelGGL(geo_sort_kernel, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, s, (long)I, ids,
-                       xys, conics, (float4 *)geo_sorted);
-    gg_prof_end(GG_K_GEO_SORT, s);
-    GG_CHECK_LAUNCH();
-    return GG_OK;
-}
-
-// workspace: [crec: 16 B x N][geometry stream: only used when the caller passes geo_sorted = NULL]
-static size_t crec_bytes(int N) { return gg_align_up(16 * (size_t)(N > 0 ? N : 1), 256); }
-extern "C" size_t gg_blend_workspace(int num_points, int64_t num_intersects) {
-    return crec_bytes(num_points) + gg_geo_sort_bytes(num_intersects);
+extern "C" size_t gg_blend_workspace(int num_points) {
+    return gg_align_up(sizeof(GRec) * (size_t)(num_points > 0 ? num_points : 1), 256);
 }
 
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
 void gg_launch_blend2_fwd(int width, int C, int off, int n, int img_h, int img_w, int tiles_x,
-                          int ntiles, const float4 *geo, const int2 *bins, const float4 *crec,
-                          const float *opacity,
+                          int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
                           const float *colors, const float *background, float *out_img,
                           float *final_Ts, int32_t *final_idx, int write_final, hipStream_t s);
 void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w, int tiles_x,
-                          int ntiles, const float4 *geo, const int2 *bins, const float4 *crec,
-                          const float *opacity,
+                          int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
                           const float *colors, const float *background, const float *final_Ts,
                           const int32_t *final_idx, const float *v_out, float *v_xy, float *v_conic,
                           float *v_colors, float *v_opacity, hipStream_t s);
 void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, int tiles_x,
-                                 int ntiles, const float4 *geo, const int2 *bins, const float4 *crec,
-                          const float *opacity,
+                                 int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
                                  const float *colors, const float *background, const float *final_Ts,
                                  const int32_t *final_idx, const float *v_out, float *v_xy,
                                  float *v_conic, float *v_colors, float *v_opacity, hipStream_t s);
@@ -96,61 +71,36 @@ extern "C" int gg_debug_set_ablation(int level) {
     return prev;
 }
 
-// geometry stream of this call: the caller's (gg_geo_sort, shared by the calls of a view) or one
-// built here into the workspace
-static int resolve_geo(const char *who, int N, int64_t I, const int32_t *ids, const float *xys,
-                       const float *conics, const void *geo_sorted, void *ws, size_t ws_bytes,
-                       hipStream_t s, const float4 **geo) {
-    const size_t need = crec_bytes(N) + (geo_sorted ? 0 : gg_geo_sort_bytes(I));
-    if (ws == nullptr || ws_bytes < need) {
-        gg_set_error("%s: workspace too small (%zu < %zu bytes)", who, ws_bytes, need);
-        return GG_ERR_WORKSPACE;
-    }
-    if (geo_sorted) {
-        GG_REQUIRE(((uintptr_t)geo_sorted & 15) == 0, "geo_sorted must be 16-byte aligned");
-        *geo = (const float4 *)geo_sorted;
-        return GG_OK;
-    }
-    void *mine = (char *)ws + crec_bytes(N);
-    *geo = (const float4 *)mine;
-    return gg_geo_sort(I, ids, xys, conics, mine, (gg_stream_t)s);
-}
-
-static void launch_prep(int N, int C, int off, int n, const float *opacity, const float *colors,
-                        float4 *crec, hipStream_t s) {
-    gg_prof_begin(GG_K_BLEND_PREP, s);
-    hipLaunchKernelGGL(blend_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, C, off, n, opacity,
-                       colors, crec);
-    gg_prof_end(GG_K_BLEND_PREP, s);
-}
-
-extern "C" int gg_blend_fwd(int C, int N, int64_t I, int img_h, int img_w, const int32_t *ids,
+extern "C" int gg_blend_fwd(int C, int N, int img_h, int img_w, const int32_t *ids,
                             const int32_t *tile_bins, const float *xys, const float *conics,
                             const float *colors, const float *opacity, const float *background,
-                            const void *geo_sorted, float *out_img, float *final_Ts,
-                            int32_t *final_idx, void *ws, size_t ws_bytes, gg_stream_t stream) {
+                            float *out_img, float *final_Ts, int32_t *final_idx, void *ws,
+                            size_t ws_bytes, gg_stream_t stream) {
     GG_REQUIRE(C >= 1, "channels < 1");
-    GG_REQUIRE(N >= 0 && I >= 0, "num_points or num_intersects < 0");
+    GG_REQUIRE(N >= 0, "num_points < 0");
     GG_REQUIRE(img_h > 0 && img_w > 0, "empty image");
     GG_REQUIRE(tile_bins && background && out_img && final_Ts && final_idx, "null pointer");
-    GG_REQUIRE(N == 0 || (xys && conics && colors && opacity), "null pointer");
-    GG_REQUIRE(I == 0 || (N > 0 && (ids || geo_sorted)), "intersections without ids / Gaussians");
-    hipStream_t s = (hipStream_t)stream;
-    const float4 *geo = nullptr;
-    if (I > 0) {
-        int rc = resolve_geo("gg_blend_fwd", N, I, ids, xys, conics, geo_sorted, ws, ws_bytes, s, &geo);
-        if (rc != GG_OK) return rc;
+    GG_REQUIRE(N == 0 || (ids && xys && conics && colors && opacity), "null pointer");
+    if (ws == nullptr || ws_bytes < gg_blend_workspace(N)) {
+        gg_set_error("gg_blend_fwd: workspace too small");
+        return GG_ERR_WORKSPACE;
     }
-    float4 *crec = (float4 *)ws;
+    hipStream_t s = (hipStream_t)stream;
+    GRec *rec = (GRec *)ws;
+    if (N > 0) {
+        gg_prof_begin(GG_K_BLEND_PREP, s);
+        hipLaunchKernelGGL(blend_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, xys, conics,
+                           opacity, rec);
+        gg_prof_end(GG_K_BLEND_PREP, s);
+    }
     const int tiles_x = (img_w + GG_BLOCK - 1) / GG_BLOCK, tiles_y = (img_h + GG_BLOCK - 1) / GG_BLOCK;
     const int ntiles = tiles_x * tiles_y;
     for (int off = 0; off < C;) {
         const int w = chunk_width(C - off);
         const int n = min(w, C - off);
-        if (w <= 3 && I > 0) launch_prep(N, C, off, n, opacity, colors, crec, s);
         gg_prof_begin(GG_K_BLEND_FWD + gg_width_index(w), s);
-        gg_launch_blend2_fwd(w, C, off, n, img_h, img_w, tiles_x, ntiles, geo, (const int2 *)tile_bins,
-                             crec, opacity, colors, background, out_img, final_Ts, final_idx, off == 0, s);
+        gg_launch_blend2_fwd(w, C, off, n, img_h, img_w, tiles_x, ntiles, ids, (const int2 *)tile_bins,
+                             rec, colors, background, out_img, final_Ts, final_idx, off == 0, s);
         gg_prof_end(GG_K_BLEND_FWD + gg_width_index(w), s);
         off += n;
     }
@@ -158,27 +108,29 @@ extern "C" int gg_blend_fwd(int C, int N, int64_t I, int img_h, int img_w, const
     return GG_OK;
 }
 
-extern "C" int gg_blend_bwd(int C, int N, int64_t I, int img_h, int img_w, const int32_t *ids,
+extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *ids,
                             const int32_t *tile_bins, const float *xys, const float *conics,
                             const float *colors, const float *opacity, const float *background,
-                            const void *geo_sorted, const float *final_Ts, const int32_t *final_idx,
-                            const float *v_out, float *v_xy, float *v_conic, float *v_colors,
-                            float *v_opacity, void *ws, size_t ws_bytes, gg_stream_t stream) {
+                            const float *final_Ts, const int32_t *final_idx, const float *v_out,
+                            float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
+                            void *ws, size_t ws_bytes, gg_stream_t stream) {
     GG_REQUIRE(C >= 1, "channels < 1");
-    GG_REQUIRE(N >= 0 && I >= 0, "num_points or num_intersects < 0");
+    GG_REQUIRE(N >= 0, "num_points < 0");
     GG_REQUIRE(img_h > 0 && img_w > 0, "empty image");
     if (N == 0) return GG_OK;
-    GG_REQUIRE(tile_bins && xys && conics && colors && opacity && background && final_Ts &&
+    GG_REQUIRE(ids && tile_bins && xys && conics && colors && opacity && background && final_Ts &&
                    final_idx && v_out && v_xy && v_conic && v_colors && v_opacity,
                "null pointer");
-    GG_REQUIRE(I == 0 || ids || geo_sorted, "intersections without ids");
-    hipStream_t s = (hipStream_t)stream;
-    const float4 *geo = nullptr;
-    if (I > 0) {
-        int rc = resolve_geo("gg_blend_bwd", N, I, ids, xys, conics, geo_sorted, ws, ws_bytes, s, &geo);
-        if (rc != GG_OK) return rc;
+    if (ws == nullptr || ws_bytes < gg_blend_workspace(N)) {
+        gg_set_error("gg_blend_bwd: workspace too small");
+        return GG_ERR_WORKSPACE;
     }
-    float4 *crec = (float4 *)ws;
+    hipStream_t s = (hipStream_t)stream;
+    GRec *rec = (GRec *)ws;
+    gg_prof_begin(GG_K_BLEND_PREP, s);
+    hipLaunchKernelGGL(blend_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, xys, conics,
+                       opacity, rec);
+    gg_prof_end(GG_K_BLEND_PREP, s);
     // the kernels accumulate with atomics: the four gradient arrays start at zero (one memset when
     // the caller laid them out back to back: v_xy | v_conic | v_opacity | v_colors)
     bool fail;
@@ -195,21 +147,19 @@ extern "C" int gg_blend_bwd(int C, int N, int64_t I, int img_h, int img_w, const
         gg_set_error("gg_blend_bwd: memset failed");
         return GG_ERR_LAUNCH;
     }
-    if (I == 0) return GG_OK;
     const int tiles_x = (img_w + GG_BLOCK - 1) / GG_BLOCK, tiles_y = (img_h + GG_BLOCK - 1) / GG_BLOCK;
     const int ntiles = tiles_x * tiles_y;
     for (int off = 0; off < C;) {
         const int w = chunk_width(C - off);
         const int n = min(w, C - off);
-        if (w <= 3) launch_prep(N, C, off, n, opacity, colors, crec, s);
         gg_prof_begin(GG_K_BLEND_BWD + gg_width_index(w), s);
         if ((w == 3 && g_ablate > 0 && g_ablate < 10) || (w == 32 && n == 32 && g_ablate > 10))
-            gg_launch_blend2_bwd_ablate(g_ablate, C, off, img_h, img_w, tiles_x, ntiles, geo,
-                                        (const int2 *)tile_bins, crec, opacity, colors, background,
-                                        final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, s);
+            gg_launch_blend2_bwd_ablate(g_ablate, C, off, img_h, img_w, tiles_x, ntiles, ids,
+                                        (const int2 *)tile_bins, rec, colors, background, final_Ts,
+                                        final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, s);
         else
-            gg_launch_blend2_bwd(w, C, off, n, img_h, img_w, tiles_x, ntiles, geo,
-                                 (const int2 *)tile_bins, crec, opacity, colors, background, final_Ts,
+            gg_launch_blend2_bwd(w, C, off, n, img_h, img_w, tiles_x, ntiles, ids,
+                                 (const int2 *)tile_bins, rec, colors, background, final_Ts,
                                  final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, s);
         gg_prof_end(GG_K_BLEND_BWD + gg_width_index(w), s);
         off += n;

@@ -27,112 +27,56 @@
 #include "blend_common.h"
 
 #define GRP 4          // survivors per loop iteration
-// Round geometry (measured on the bench workload: 1x64 ... 4x160 all within 2 %, so the moderate one)
-#define FWD_SUBS 2
-#define FWD_LMAX 128
-#define BWN_SUBS 2
-#define BWN_LMAX 128
-#define BWW_SUBS 2
-#define BWW_LMAX 128   // LDS of the wide backward: lists 17.4 KB + fac 33.8 KB -> 3 workgroups per CU
-// Round geometry, per kernel (template arguments of stage_round / WaveListT):
-//   SUBS     64-entry sub-chunks staged per round — their loads are all in flight together;
-//   LIST_MAX survivors one round may hold (a sub-chunk is taken only if 64 more are sure to fit).
+#define LIST_CAP 72    // 4 leading pads + 64 + 4 trailing pads
 
-// Per-wave survivor list.  a: x, y, opacity, .w = list position (fwd: +1, the final_idx value).
-// b: conic a, b, c, .w = Gaussian id (int bits, -1 for null pads).  c (narrow only): colours 0..2.
-template <bool NARROW, int LIST_MAX>
-struct WaveListT {
-    static constexpr int LIST_CAP = GRP + LIST_MAX + GRP;   // null pads on both sides
-    float4 a[LIST_CAP];
-    float4 b[LIST_CAP];
-    float4 c[NARROW ? LIST_CAP : 1];
+struct WaveList {
+    float4 a[LIST_CAP];  // x, y, opacity, (unused)
+    float4 b[LIST_CAP];  // conic a, b, c, (unused)
+    float4 c[LIST_CAP];  // narrow: colours 0..2 ; wide: .x = Gaussian id (int bits). .w = list position + 1
 };
 
 __device__ __forceinline__ int lane_prefix(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// Stage one ROUND of the tile list.
-//
-// What limited the first version of this engine was neither arithmetic nor HBM but the vector L1:
-// every wave gathered a 32-byte record (two 16-byte loads) and the colours (three 4-byte loads) of
-// every list entry by Gaussian id — ~300 fully divergent lane-requests per 64 entries, each a tag
-// look-up and mostly a 128-byte line fill, repeated by the four waves of a tile and by the eight
-// blend launches of a view: ~1 microsecond of SIMD time per staged chunk against ~1 microsecond of
-// blending (profiles/README.md "staging").  Now
-//   * the geometry comes from the tile-sorted stream (gg_geo_sort, built once per view): two
-//     COALESCED 16-byte loads per entry, addresses known in advance;
-//   * a first cull uses geometry only (cut-off of opacity 1, the largest possible); only its
-//     survivors (~40 % of the lanes) gather the per-call record — ONE 16-byte load {opacity, c0, c1,
-//     c2} for narrow calls, the opacity alone for 32-channel chunks — and the exact cut-off of that
-//     opacity is compared with the rectangle minimum already computed: one rectangle test per entry;
-//   * a round issues the loads of SUBS consecutive 64-entry sub-chunks back to back (one latency
-//     exposure per 256 entries), then compacts sub-chunk after sub-chunk into the list for as long
-//     as 64 more survivors are guaranteed to fit; sub-chunks that did not fit are staged again by
-//     the next round.
-//   forward  (BWD = false): entries [from, from + 64*SUBS) capped at `limit` = range end, list in
-//            ascending list order;
-//   backward (BWD = true):  entries [from - 64*SUBS, from) floored at `limit` = range start, list in
-//            DESCENDING list order (the walk direction), so both loops read the list front to back.
-// Returns the survivor count; `used` = sub-chunks consumed.
-template <int CH, bool WIDE, bool BWD, int SUBS, int LIST_MAX>
-__device__ __forceinline__ int stage_round(WaveListT<!WIDE, LIST_MAX> &L, int lane, int from, int limit,
-                                           int &used, const float4 *__restrict__ geo,
-                                           const float4 *__restrict__ crec,
-                                           const float *__restrict__ opacity, float xlo, float xhi,
-                                           float ylo, float yhi) {
-    int e[SUBS];
-    bool maybe[SUBS];
-    float4 s0[SUBS], s1[SUBS], cr[SUBS];
-    float smin[SUBS];
-#pragma unroll
-    for (int u = 0; u < SUBS; ++u) {
-        e[u] = BWD ? from - 64 * (u + 1) + lane : from + 64 * u + lane;
-        const bool valid = BWD ? e[u] >= limit : e[u] < limit;
-        const int ee = valid ? e[u] : (BWD ? limit : limit - 1);   // any in-range entry
-        s0[u] = geo[2 * (size_t)ee];
-        s1[u] = geo[2 * (size_t)ee + 1];
-        maybe[u] = valid;
-    }
-#pragma unroll
-    for (int u = 0; u < SUBS; ++u) {
-        smin[u] = rect_min_sigma(s0[u].x, s0[u].y, s0[u].z, s0[u].w, s1[u].x, xlo, xhi, ylo, yhi);
-        maybe[u] = maybe[u] && sigma_reaches(smin[u], GG_THR_MAX);
-        const int g = __builtin_bit_cast(int, s1[u].y);
+// Stage one chunk: returns the survivor count; list[OFF + k] = k-th survivor in list order,
+// GRP null records (opacity 0 -> never pass) on both sides.
+template <int CH, bool WIDE, bool REL = false>
+__device__ __forceinline__ int stage_chunk(WaveList &L, int lane, int e, bool valid,
+                                           const int32_t *__restrict__ ids,
+                                           const GRec *__restrict__ rec,
+                                           const float *__restrict__ colors, int C, int ch_off, int nch,
+                                           float xlo, float xhi, float ylo, float yhi) {
+    const int g = valid ? ids[e] : 0;
+    const float4 ra = reinterpret_cast<const float4 *>(rec + g)[0];
+    const float4 rb = reinterpret_cast<const float4 *>(rec + g)[1];
+    const bool hit = valid && rec_hits_rect(ra, rb, xlo, xhi, ylo, yhi);
+    const uint64_t m = __ballot(hit);
+    const int cnt = __builtin_popcountll(m);
+    const int pos = GRP + lane_prefix(m);
+    if (hit) {
+        // .w: forward = list position + 1 (final_idx); backward = position inside the chunk
+        float4 cc = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, REL ? lane : e + 1));
         if (WIDE) {
-            cr[u].x = maybe[u] ? opacity[g] : 0.0f;
+            cc.x = __builtin_bit_cast(float, g);
         } else {
-            cr[u] = maybe[u] ? crec[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float *col = colors + (size_t)g * C + ch_off;
+            cc.x = col[0];
+            if (CH > 1 && nch > 1) cc.y = col[1];
+            if (CH > 2 && nch > 2) cc.z = col[2];
         }
-    }
-    int tail = 0;
-    used = 0;
-#pragma unroll
-    for (int u = 0; u < SUBS; ++u) {
-        const bool any = BWD ? (from - 64 * u > limit) : (from + 64 * u < limit);  // wave-uniform
-        if (!any || tail + 64 > LIST_MAX) break;
-        const bool hit = maybe[u] && sigma_reaches(smin[u], gg_alpha_cutoff(cr[u].x));
-        const uint64_t m = __ballot(hit);
-        const int cnt = __builtin_popcountll(m);
-        const int pre = lane_prefix(m);
-        const int pos = GRP + tail + (BWD ? cnt - 1 - pre : pre);
-        if (hit) {
-            L.a[pos] = make_float4(s0[u].x, s0[u].y, cr[u].x,
-                                   __builtin_bit_cast(float, BWD ? e[u] : e[u] + 1));
-            L.b[pos] = make_float4(s0[u].z, s0[u].w, s1[u].x, s1[u].y);
-            if (!WIDE) L.c[pos] = make_float4(cr[u].y, cr[u].z, cr[u].w, 0.f);
-        }
-        tail += cnt;
-        ++used;
+        L.a[pos] = ra;
+        L.b[pos] = make_float4(rb.x, rb.y, rb.z, __builtin_bit_cast(float, g));  // .w = Gaussian id
+        L.c[pos] = cc;
     }
     if (lane < 2 * GRP) {  // null pads: opacity 0, conic 0 -> alpha = 0 < 1/255
-        const int q = (lane < GRP) ? lane : (tail + lane);
+        const int q = (lane < GRP) ? lane : (cnt + lane);
         L.a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         L.b[q] = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, -1));
-        if (!WIDE) L.c[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        L.c[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __builtin_amdgcn_wave_barrier();
-    return tail;
+    return cnt;
 }
 
 // =============================================================================================
@@ -141,18 +85,16 @@ __device__ __forceinline__ int stage_round(WaveListT<!WIDE, LIST_MAX> &L, int la
 template <int CH, bool WIDE, bool FULL>
 __global__ __launch_bounds__(256) void blend2_fwd_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
-    const float4 *__restrict__ geo, const int2 *__restrict__ bins, const float4 *__restrict__ crec,
-    const float *__restrict__ opacity,
+    const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
     const float *__restrict__ colors, const float *__restrict__ background,
     float *__restrict__ out_img, float *__restrict__ final_T, int32_t *__restrict__ final_idx,
     int write_final) {
-    constexpr int SUBS = FWD_SUBS, LMAX = FWD_LMAX;
-    __shared__ WaveListT<!WIDE, LMAX> lists[4];
+    __shared__ WaveList lists[4];
     const int tile = xcd_tile(blockIdx.x, ntiles);
     if (tile < 0) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    WaveListT<!WIDE, LMAX> &L = lists[wave];
+    WaveList &L = lists[wave];
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int qx0 = tx * GG_BLOCK + (wave & 1) * 8, qy0 = ty * GG_BLOCK + (wave >> 1) * 8;
     const int j = qx0 + (lane & 7), i = qy0 + (lane >> 3);
@@ -173,12 +115,11 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
     const int wch = lane & 31, half = lane >> 5;
     const bool wch_ok = FULL || wch < nch;
 
-    for (int base = range.x; base < range.y;) {
+    for (int base = range.x; base < range.y; base += 64) {
         if (__ballot(!done) == 0ull) break;
-        int used;
-        const int cnt = stage_round<CH, WIDE, false, SUBS, LMAX>(L, lane, base, range.y, used, geo, crec,
-                                                                 opacity, xlo, xhi, ylo, yhi);
-        base += 64 * used;
+        const int e = base + lane;
+        const int cnt = stage_chunk<CH, WIDE>(L, lane, e, e < range.y, ids, rec, colors, C, ch_off,
+                                              nch, xlo, xhi, ylo, yhi);
         for (int k = 0; k < cnt; k += GRP) {
             if (k > 0 && __ballot(!done) == 0ull) break;
             float4 A[GRP], B[GRP], Cc[GRP];
@@ -186,28 +127,26 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
             for (int q = 0; q < GRP; ++q) {
                 A[q] = L.a[GRP + k + q];
                 B[q] = L.b[GRP + k + q];
-                if (!WIDE) Cc[q] = L.c[GRP + k + q];
+                Cc[q] = L.c[GRP + k + q];
             }
             float colB[GRP / 2];
             if (WIDE) {
 #pragma unroll
                 for (int pr = 0; pr < GRP / 2; ++pr) {
                     // lanes 0-31 fetch the colour row of the even Gaussian, 32-63 of the odd one
-                    const int gid = __builtin_bit_cast(int, L.b[GRP + k + 2 * pr + half].w);
-                    colB[pr] = (wch_ok && gid >= 0) ? colors[(size_t)gid * C + ch_off + wch] : 0.0f;
+                    const int gid = __builtin_bit_cast(int, L.c[GRP + k + 2 * pr + half].x);
+                    colB[pr] = wch_ok ? colors[(size_t)gid * C + ch_off + wch] : 0.0f;
                 }
             }
             float alpha[GRP];
             bool pass[GRP];
 #pragma unroll
-            for (int q = 0; q < GRP; q += 2) {   // two Gaussians per packed instruction
-                v2f dx, dy;
-                const v2f sigma = gg_sigma2(A[q], B[q], A[q + 1], B[q + 1], px, py, dx, dy);
-                const v2f ao = (v2f){A[q].z, A[q + 1].z} * gg_expf2(-sigma);
-                alpha[q] = fminf(GG_ALPHA_MAX_FWD, ao.x);
-                alpha[q + 1] = fminf(GG_ALPHA_MAX_FWD, ao.y);
-                pass[q] = sigma.x >= 0.0f && !(alpha[q] < GG_ALPHA_MIN);
-                pass[q + 1] = sigma.y >= 0.0f && !(alpha[q + 1] < GG_ALPHA_MIN);
+            for (int q = 0; q < GRP; ++q) {
+                const float dx = A[q].x - px, dy = A[q].y - py;
+                const float sigma = __builtin_fmaf(
+                    0.5f, __builtin_fmaf(B[q].x * dx, dx, (B[q].z * dy) * dy), (B[q].y * dx) * dy);
+                alpha[q] = fminf(GG_ALPHA_MAX_FWD, A[q].z * gg_expf(-sigma));
+                pass[q] = sigma >= 0.0f && !(alpha[q] < GG_ALPHA_MIN);
             }
             float vis[GRP];
 #pragma unroll
@@ -218,7 +157,7 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
                 const bool blend = live && !stop;
                 vis[q] = blend ? alpha[q] * T : 0.0f;
                 T = blend ? next_T : T;
-                last = blend ? __builtin_bit_cast(int, A[q].w) : last;
+                last = blend ? __builtin_bit_cast(int, Cc[q].w) : last;
                 done = done || stop;
                 if (!WIDE) {
                     acc[0] = __builtin_fmaf(Cc[q].x, vis[q], acc[0]);
@@ -288,8 +227,7 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
 template <int CH, int ABL = 0>
 __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
     int C, int ch_off, int img_h, int img_w, int tiles_x, int ntiles,
-    const float4 *__restrict__ geo, const int2 *__restrict__ bins, const float4 *__restrict__ crec,
-    const float *__restrict__ opacity,
+    const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
     const float *__restrict__ colors, const float *__restrict__ background,
     const float *__restrict__ final_T, const int32_t *__restrict__ final_idx,
     const float *__restrict__ v_out, float *__restrict__ v_xy, float *__restrict__ v_conic,
@@ -297,14 +235,13 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
     constexpr int K = CH + 6;       // per-Gaussian values: CH colours, xy(2), conic(3), opacity(1)
     constexpr int KB = GRP * K;     // butterfly width
     using R = Red6<KB>;
-    constexpr int SUBS = BWN_SUBS, LMAX = BWN_LMAX;
-    __shared__ WaveListT<true, LMAX> lists[4];
+    __shared__ WaveList lists[4];
 
     const int tile = xcd_tile(blockIdx.x, ntiles);
     if (tile < 0) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    WaveListT<true, LMAX> &L = lists[wave];
+    WaveList &L = lists[wave];
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int qx0 = tx * GG_BLOCK + (wave & 1) * 8, qy0 = ty * GG_BLOCK + (wave >> 1) * 8;
     const int j = qx0 + (lane & 7), i = qy0 + (lane >> 3);
@@ -343,19 +280,20 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
     else if (my_k < CH + 5) { my_base = v_conic + (my_k - CH - 2); my_stride = 3; }
     else { my_base = v_opacity; my_stride = 1; }
 
-    for (int top = hi; top > range.x;) {
-        int used;
-        const int cnt = stage_round<CH, false, true, SUBS, LMAX>(L, lane, top, range.x, used, geo, crec,
-                                                                 opacity, xlo, xhi, ylo, yhi);
-        top -= 64 * used;
+    for (int top = hi; top > range.x; top -= 64) {
+        const int e = top - 64 + lane;
+        const bool valid = e >= range.x;
+        const int cnt = stage_chunk<CH, false, true>(L, lane, e, valid, ids, rec, colors, C, ch_off,
+                                                     CH, xlo, xhi, ylo, yhi);
+        const int fin_rel = fin - (top - 64);  // entries at chunk position >= fin_rel are not mine
         if (ABL >= 4) { KEEP(cnt); continue; }
-        for (int k = 0; k < cnt; k += GRP) {   // the list is in walk order (descending position)
+        for (int kk = GRP + cnt - 1; kk >= GRP; kk -= GRP) {
             float4 A[GRP], B[GRP], Cc[GRP];
 #pragma unroll
             for (int q = 0; q < GRP; ++q) {
-                A[q] = L.a[GRP + k + q];
-                B[q] = L.b[GRP + k + q];
-                Cc[q] = L.c[GRP + k + q];
+                A[q] = L.a[kk - q];
+                B[q] = L.b[kk - q];
+                Cc[q] = L.c[kk - q];
             }
             float vis[GRP], alpha[GRP], dxs[GRP], dys[GRP];
             bool pass[GRP];
@@ -368,8 +306,8 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
                     0.5f, __builtin_fmaf(B[q].x * dx, dx, (B[q].z * dy) * dy), (B[q].y * dx) * dy);
                 vis[q] = gg_expf(-sigma);
                 alpha[q] = fminf(GG_ALPHA_MAX_BWD, A[q].z * vis[q]);
-                // a.w = list position; null pads have opacity 0 -> alpha 0 -> no pass
-                pass[q] = (__builtin_bit_cast(int, A[q].w) < fin) && sigma >= 0.0f &&
+                // .w = position inside the chunk; null pads have opacity 0 -> alpha 0 -> no pass
+                pass[q] = (__builtin_bit_cast(int, Cc[q].w) < fin_rel) && sigma >= 0.0f &&
                           !(alpha[q] < GG_ALPHA_MIN);
             }
             if (__ballot(pass[0] || pass[1] || pass[2] || pass[3]) == 0ull) continue;
@@ -412,7 +350,7 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
             const float mine = R::run(part, lane);
             // Gaussian id of my group member: per-lane LDS read (4 distinct addresses per wave);
             // id bits live in b.w of the record
-            const int my_gid = __builtin_bit_cast(int, L.b[GRP + k + my_q].w);
+            const int my_gid = __builtin_bit_cast(int, L.b[kk - my_q].w);
             if (ABL >= 1) { KEEP(mine); KEEP(my_gid); continue; }
             if (owner && my_gid >= 0) atomicAdd(my_base + (size_t)my_gid * my_stride, mine);
         }
@@ -440,8 +378,7 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
 template <bool FULL, int ABL = 0, int CHD = 32>
 __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
-    const float4 *__restrict__ geo, const int2 *__restrict__ bins, const float4 *__restrict__ crec,
-    const float *__restrict__ opacity,
+    const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
     const float *__restrict__ colors, const float *__restrict__ background,
     const float *__restrict__ final_T, const int32_t *__restrict__ final_idx,
     const float *__restrict__ v_out, float *__restrict__ v_xy, float *__restrict__ v_conic,
@@ -450,8 +387,7 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
     constexpr int KG = 6;
     constexpr int KB = GRP * KG;
     using R = Red6<KB>;
-    constexpr int SUBS = BWW_SUBS, LMAX = BWW_LMAX;
-    __shared__ WaveListT<false, LMAX> lists[4];
+    __shared__ WaveList lists[4];
     __shared__ float s_fac[4][B2_SLOTS * B2_FSTRIDE];
     __shared__ int s_slotgid[4][B2_SLOTS];
 
@@ -459,7 +395,7 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
     if (tile < 0) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    WaveListT<false, LMAX> &L = lists[wave];
+    WaveList &L = lists[wave];
     float *fac_w = s_fac[wave];
     int *slotgid = s_slotgid[wave];
     const int tx = tile % tiles_x, ty = tile / tiles_x;
@@ -530,19 +466,20 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
         nslots = 0;
     };
 
-    for (int top = hi; top > range.x;) {
-        int used;
-        const int cnt = stage_round<CH, true, true, SUBS, LMAX>(L, lane, top, range.x, used, geo, crec,
-                                                                opacity, xlo, xhi, ylo, yhi);
-        top -= 64 * used;
-        for (int k = 0; k < cnt; k += GRP) {   // the list is in walk order (descending position)
+    for (int top = hi; top > range.x; top -= 64) {
+        const int e = top - 64 + lane;
+        const bool valid = e >= range.x;
+        const int cnt = stage_chunk<CH, true, true>(L, lane, e, valid, ids, rec, colors, C, ch_off,
+                                                    nch, xlo, xhi, ylo, yhi);
+        const int fin_rel = fin - (top - 64);
+        for (int kk = GRP + cnt - 1; kk >= GRP; kk -= GRP) {
             float vis[GRP], alpha[GRP], dxs[GRP], dys[GRP], opac[GRP];
             float ca[GRP], cb[GRP], cc[GRP];
             bool pass[GRP];
 #pragma unroll
             for (int q = 0; q < GRP; ++q) {
-                const float4 A = L.a[GRP + k + q], B = L.b[GRP + k + q];
-                const int pos = __builtin_bit_cast(int, A.w);
+                const float4 A = L.a[kk - q], B = L.b[kk - q];
+                const int pos = __builtin_bit_cast(int, L.c[kk - q].w);
                 const float dx = A.x - px, dy = A.y - py;
                 dxs[q] = dx;
                 dys[q] = dy;
@@ -554,7 +491,7 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
                     0.5f, __builtin_fmaf(B.x * dx, dx, (B.z * dy) * dy), (B.y * dx) * dy);
                 vis[q] = gg_expf(-sigma);
                 alpha[q] = fminf(GG_ALPHA_MAX_BWD, A.z * vis[q]);
-                pass[q] = (pos < fin) && sigma >= 0.0f && !(alpha[q] < GG_ALPHA_MIN);
+                pass[q] = (pos < fin_rel) && sigma >= 0.0f && !(alpha[q] < GG_ALPHA_MIN);
             }
             if (__ballot(pass[0] || pass[1] || pass[2] || pass[3]) == 0ull) continue;
             if (ABL >= 5) {
@@ -572,7 +509,7 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
                     for (int v = 0; v < KG; ++v) pg[v] = 0.0f;
                     continue;
                 }
-                const int gid = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, L.b[GRP + k + q].w));
+                const int gid = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, L.b[kk - q].w));
                 const float *col = colors + (size_t)gid * C + ch_off;
                 float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;  // 4 chains: latency, not order
 #pragma unroll
@@ -611,7 +548,7 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
                 continue;
             }
             const float mine = R::run(part, lane);
-            const int my_gid = __builtin_bit_cast(int, L.b[GRP + k + my_q].w);
+            const int my_gid = __builtin_bit_cast(int, L.b[kk - my_q].w);
             if (owner && my_gid >= 0) atomicAdd(my_base + (size_t)my_gid * my_stride, mine);
         }
         __builtin_amdgcn_wave_barrier();
@@ -622,11 +559,10 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
 // =============================================================================================
 // launchers used by the C ABI in blend.hip
 // =============================================================================================
-#define B2_FWD_ARGS C, off, n, img_h, img_w, tiles_x, ntiles, geo, bins, crec, opacity, colors, background, \
+#define B2_FWD_ARGS C, off, n, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, \
                     out_img, final_Ts, final_idx, write_final
 void gg_launch_blend2_fwd(int width, int C, int off, int n, int img_h, int img_w, int tiles_x,
-                          int ntiles, const float4 *geo, const int2 *bins, const float4 *crec,
-                          const float *opacity,
+                          int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
                           const float *colors, const float *background, float *out_img,
                           float *final_Ts, int32_t *final_idx, int write_final, hipStream_t s) {
     dim3 grid(gg_tile_grid(ntiles)), block(256);
@@ -642,11 +578,10 @@ void gg_launch_blend2_fwd(int width, int C, int off, int n, int img_h, int img_w
         hipLaunchKernelGGL((blend2_fwd_kernel<32, true, false>), grid, block, 0, s, B2_FWD_ARGS);
 }
 
-#define B2_BWDN_ARGS C, off, img_h, img_w, tiles_x, ntiles, geo, bins, crec, opacity, colors, background, \
+#define B2_BWDN_ARGS C, off, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, \
                      final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity
 void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w, int tiles_x,
-                          int ntiles, const float4 *geo, const int2 *bins, const float4 *crec,
-                          const float *opacity,
+                          int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
                           const float *colors, const float *background, const float *final_Ts,
                           const int32_t *final_idx, const float *v_out, float *v_xy, float *v_conic,
                           float *v_colors, float *v_opacity, hipStream_t s) {
@@ -657,7 +592,7 @@ void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w
         hipLaunchKernelGGL((blend2_bwd_narrow_kernel<2>), grid, block, 0, s, B2_BWDN_ARGS);
     else if (width == 3)
         hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3>), grid, block, 0, s, B2_BWDN_ARGS);
-#define B2_BWDW_ARGS C, off, n, img_h, img_w, tiles_x, ntiles, geo, bins, crec, opacity, colors, background, \
+#define B2_BWDW_ARGS C, off, n, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, \
                      final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity
     else if (n == 32)
         hipLaunchKernelGGL((blend2_bwd_wide_kernel<true>), grid, block, 0, s, B2_BWDW_ARGS);
@@ -671,15 +606,14 @@ void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w
 
 // measurement-only entry (tools/kbench.py): ablated builds of the 3-channel backward
 void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, int tiles_x,
-                                 int ntiles, const float4 *geo, const int2 *bins, const float4 *crec,
-                          const float *opacity,
+                                 int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
                                  const float *colors, const float *background, const float *final_Ts,
                                  const int32_t *final_idx, const float *v_out, float *v_xy,
                                  float *v_conic, float *v_colors, float *v_opacity, hipStream_t s) {
     dim3 grid(gg_tile_grid(ntiles)), block(256);
     switch (abl) {
 #define B2_WABL(L) hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, L>), grid, block, 0, s, C, off, 32, \
-        img_h, img_w, tiles_x, ntiles, geo, bins, crec, opacity, colors, background, final_Ts, final_idx, v_out, \
+        img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, final_Ts, final_idx, v_out, \
         v_xy, v_conic, v_colors, v_opacity)
         case 11: B2_WABL(1); break;
         case 12: B2_WABL(2); break;
@@ -693,4 +627,3 @@ void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, 
         default: hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3, 0>), grid, block, 0, s, B2_BWDN_ARGS); break;
     }
 }
-

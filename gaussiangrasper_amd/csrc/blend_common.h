@@ -6,31 +6,21 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define BW_BATCH 64
 
-// Tile-sorted geometry stream (gg_geo_sort): one 32-byte record per list entry, in list order, so the
-// blend kernels read the geometry of a chunk with coalesced 16-byte loads instead of gathering it per
-// Gaussian id:   s0 = {x, y, conic a, conic b}   s1 = {conic c, Gaussian id (int bits), 0, 0}.
-#define GG_GEO_BYTES 32
-// Largest cut-off any opacity can produce (opacity <= 1): ln(255), with the margins of gg_alpha_cutoff.
-#define GG_THR_MAX 5.5545f
+struct __attribute__((aligned(16))) GRec {
+    float x, y, opac, thr;  // thr: sigma above which alpha < 1/255 for certain (conservative)
+    float ca, cb, cc, pad;
+};
 
-// sigma above which alpha = opacity * exp(-sigma) < 1/255 for certain.  Margins absorb the fp32 rounding
-// of sigma (rel ~5e-7), of gg_expf (2 ulp) and of the fast log (1e-6).  < 0: never visible.
-__device__ __forceinline__ float gg_alpha_cutoff(float opac) {
-    float t = __logf(255.0f * opac);
-    t = t + 0.002f * fabsf(t) + 0.002f;
-    if (!(opac > 0.0f)) t = -1.0f;               // alpha <= 0 < 1/255 always
-    if (opac != opac) t = __builtin_inff();      // NaN opacity: never cull (NaN propagates)
-    return t;
-}
 
 // Tile of a workgroup.  Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD
 // b & 7), each with its own L2.  XCD x takes the strips s = x, x+8, x+16, ... of GG_STRIP consecutive
-// tiles of a tile row: the tiles of a strip share most of their Gaussians (L2 hits for the per-call
-// records), and the strips of an XCD are spread over the whole image, so every XCD gets the same
-// share of dense and empty regions.  (The first mapping gave each XCD one contiguous band of the
-// image: on the bench view the busiest XCD then had 24 % of the blend work and the top band 0 % —
-// 1.9x the balanced time.  profiles/README.md "XCD balance".)
-// Launch with gg_tile_grid(ntiles) workgroups; returns -1 for the padding workgroups.
+// tiles of a tile row: the tiles of a strip share most of their Gaussians (L2 hits), and the strips
+// of an XCD are spread over the whole image, so every XCD gets the same share of dense and empty
+// regions.  The first mapping gave each XCD one contiguous band of the image: on the bench view the
+// busiest XCD then had 24 % of the blend work and the top band 0 % (max/mean 1.93), and the blend
+// kernels ran 1.1-1.4x slower (profiles/README.md "XCD balance").  Strips of 4, 2x2 / 4x4 / 8x8 tile
+// blocks, whole tile rows and plain round-robin all measure the same within noise.
+// Launch with gg_tile_grid(ntiles) workgroups; xcd_tile returns -1 for the padding workgroups.
 #define GG_STRIP 4
 __host__ __device__ __forceinline__ int gg_tile_grid(int ntiles) {
     return ((ntiles + 8 * GG_STRIP - 1) / (8 * GG_STRIP)) * (8 * GG_STRIP);
@@ -41,30 +31,32 @@ __device__ __forceinline__ int xcd_tile(int bid, int ntiles) {
     return tile < ntiles ? tile : -1;
 }
 
-// Minimum of sigma(d) = 0.5*(a dx^2 + c dy^2) + b dx dy over the pixel rectangle [xlo,xhi]x[ylo,yhi]
-// (d = centre - pixel).  Exact in real arithmetic: sigma is a convex quadratic, so its minimum over the
-// rectangle is 0 if the centre is inside and otherwise lies on one of the (at most two) edges facing
-// the centre; on an edge the minimiser along the free coordinate is the clamped 1-D optimum.  The
-// continuous minimum is <= the minimum over the pixel centres, so `min > cutoff` never rejects a pair
-// the exact per-pixel test would accept (the cut-off carries the rounding margin).  A conic that is
-// not positive definite (never for projected Gaussians: the 0.3 blur) returns -inf: never culled.
-__device__ __forceinline__ float sigma_at(float ca, float cb, float cc, float dx, float dy) {
-    return 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+// Does the alpha>=1/255 ellipse of a record reach the pixel rectangle [xlo,xhi]x[ylo,yhi]?
+// Exact in real arithmetic: sigma is a convex quadratic, so its minimum over the rectangle is 0
+// if the centre is inside and otherwise lies on one of the (at most two) edges facing the centre;
+// on an edge the minimiser along the free coordinate is the clamped 1-D optimum.  The record's
+// cut-off already carries the rounding margin, and the continuous minimum is <= the minimum over
+// the pixel centres, so the test never rejects a pair the exact per-pixel test would accept.
+__device__ __forceinline__ float sigma_at(const float4 b, float dx, float dy) {
+    return 0.5f * (b.x * dx * dx + b.z * dy * dy) + b.y * dx * dy;
 }
-__device__ __forceinline__ float rect_min_sigma(float cx, float cy, float ca, float cb, float cc,
-                                                float xlo, float xhi, float ylo, float yhi) {
-    if (!(ca > 0.0f) || !(ca * cc - cb * cb > 0.0f)) return -__builtin_inff();
-    const float dx_lo = cx - xhi, dx_hi = cx - xlo, dy_lo = cy - yhi, dy_hi = cy - ylo;
+__device__ __forceinline__ bool rec_hits_rect(const float4 a, const float4 b, float xlo, float xhi,
+                                              float ylo, float yhi) {
+    const float thr = a.w;
+    if (thr < 0.0f) return false;
+    // the argument needs a positive-definite conic (always true for projected Gaussians: the 0.3
+    // blur); anything else is never culled
+    if (!(b.x > 0.0f) || !(b.x * b.z - b.y * b.y > 0.0f)) return true;
+    // d = centre - pixel, with the pixel ranging over the rectangle
+    const float dx_lo = a.x - xhi, dx_hi = a.x - xlo, dy_lo = a.y - yhi, dy_hi = a.y - ylo;
     const float dxn = fminf(fmaxf(0.0f, dx_lo), dx_hi);  // |d| nearest to 0 inside the range
     const float dyn = fminf(fmaxf(0.0f, dy_lo), dy_hi);
-    // edge x = nearest x: dy free ; edge y = nearest y: dx free
-    const float dy1 = fminf(fmaxf(-cb * dxn * __builtin_amdgcn_rcpf(cc), dy_lo), dy_hi);
-    const float dx2 = fminf(fmaxf(-cb * dyn * __builtin_amdgcn_rcpf(ca), dx_lo), dx_hi);
-    return fminf(sigma_at(ca, cb, cc, dxn, dy1), sigma_at(ca, cb, cc, dx2, dyn));
-}
-// hit test from a rectangle minimum and a cut-off; NaN minimum (degenerate conic) -> hit
-__device__ __forceinline__ bool sigma_reaches(float smin, float cutoff) {
-    return cutoff >= 0.0f && !(smin > cutoff);
+    // edge x = nearest x: dy free
+    const float dy1 = fminf(fmaxf(-b.y * dxn * __builtin_amdgcn_rcpf(b.z), dy_lo), dy_hi);
+    // edge y = nearest y: dx free
+    const float dx2 = fminf(fmaxf(-b.y * dyn * __builtin_amdgcn_rcpf(b.x), dx_lo), dx_hi);
+    const float smin = fminf(sigma_at(b, dxn, dy1), sigma_at(b, dx2, dyn));
+    return !(smin > thr);  // NaN (degenerate conic) -> hit, conservative
 }
 
 

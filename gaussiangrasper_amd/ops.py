@@ -210,8 +210,7 @@ class SphericalHarmonics(Function):
 # ------------------------------------------------------------------------------------------------
 class Binning:
     """Result of compute_cumulative_intersects + bin_and_sort_gaussians for one view."""
-    __slots__ = ("num_intersects", "gaussian_ids_sorted", "tile_bins", "key", "keep", "geo", "geo_key",
-                 "geo_keep")
+    __slots__ = ("num_intersects", "gaussian_ids_sorted", "tile_bins", "key", "keep")
 
     def __init__(self, num_intersects, gaussian_ids_sorted, tile_bins, key, keep):
         self.num_intersects = num_intersects
@@ -219,24 +218,6 @@ class Binning:
         self.tile_bins = tile_bins
         self.key = key
         self.keep = keep  # the keyed tensors stay alive so data_ptr cannot be recycled
-        self.geo = None       # tile-sorted geometry stream (gg_geo_sort) of ...
-        self.geo_key = None   # ... this conics tensor (data_ptr, version); the tensor is kept alive
-        self.geo_keep = None
-
-    def geo_stream(self, xys_c: Tensor, conics: Tensor, conics_c: Tensor) -> Tensor:
-        """The geometry of every list entry in list order (32 B each), built once per view and
-        shared by the rasterize calls that pass the same conics tensor (the reference passes the
-        ProjectGaussians output to all four)."""
-        key = (conics.data_ptr(), conics._version, tuple(conics.shape))
-        if self.geo is not None and self.geo_key == key:
-            return self.geo
-        lib = _lib.load()
-        dev = xys_c.device
-        geo = torch.empty(lib.gg_geo_sort_bytes(self.num_intersects), dtype=torch.uint8, device=dev)
-        _lib.check(lib.gg_geo_sort(self.num_intersects, _ptr(self.gaussian_ids_sorted), _ptr(xys_c),
-                                   _ptr(conics_c), _ptr(geo), _stream(dev)), "gg_geo_sort")
-        self.geo, self.geo_key, self.geo_keep = geo, key, conics
-        return geo
 
 
 _bin_cache: Optional[Binning] = None
@@ -329,15 +310,14 @@ def _rasterize_forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, o
     out_img = torch.empty(img_height, img_width, ch, dtype=torch.float32, device=dev)
     final_Ts = torch.empty(img_height, img_width, dtype=torch.float32, device=dev)
     final_idx = torch.empty(img_height, img_width, dtype=torch.int32, device=dev)
-    geo = bins.geo_stream(xys_c, conics, conics_c)
-    ws = _workspace(lib.gg_blend_workspace(n, 0), dev)
-    _lib.check(lib.gg_blend_fwd(ch, n, bins.num_intersects, img_height, img_width,
-                                _ptr(bins.gaussian_ids_sorted), _ptr(bins.tile_bins), _ptr(xys_c),
-                                _ptr(conics_c), _ptr(colors_c), _ptr(opacity_c), _ptr(background),
-                                _ptr(geo), _ptr(out_img), _ptr(final_Ts), _ptr(final_idx), _ptr(ws),
-                                ws.numel(), _stream(dev)), "gg_blend_fwd")
+    ws = _workspace(lib.gg_blend_workspace(n), dev)
+    _lib.check(lib.gg_blend_fwd(ch, n, img_height, img_width, _ptr(bins.gaussian_ids_sorted),
+                                _ptr(bins.tile_bins), _ptr(xys_c), _ptr(conics_c), _ptr(colors_c),
+                                _ptr(opacity_c), _ptr(background), _ptr(out_img), _ptr(final_Ts),
+                                _ptr(final_idx), _ptr(ws), ws.numel(), _stream(dev)),
+               "gg_blend_fwd")
     ctx.save_for_backward(xys_c, conics_c, colors_c, opacity_c, background,
-                          bins.gaussian_ids_sorted, bins.tile_bins, final_Ts, final_idx, geo)
+                          bins.gaussian_ids_sorted, bins.tile_bins, final_Ts, final_idx)
     return out_img
 
 
@@ -349,7 +329,7 @@ def _rasterize_backward(ctx, v_out_img):
         v_colors, v_opacity = torch.zeros_like(colors), torch.zeros_like(opacity)
     else:
         (xys, conics, colors, opacity, background, ids_sorted, tile_bins, final_Ts,
-         final_idx, geo) = ctx.saved_tensors
+         final_idx) = ctx.saved_tensors
         dev, n, ch = xys.device, xys.shape[0], colors.shape[1]
         v_out_img = _f32(v_out_img)
         # one allocation laid out v_xy | v_conic | v_opacity | v_colors: the library zeroes it with a
@@ -360,13 +340,13 @@ def _rasterize_backward(ctx, v_out_img):
         v_opacity = flat[5 * n:6 * n].view(n, 1)
         v_colors = flat[6 * n:].view(n, ch)
         lib = _lib.load()
-        ws = _workspace(lib.gg_blend_workspace(n, 0), dev)
-        _lib.check(lib.gg_blend_bwd(ch, n, ctx.num_intersects, img_height, img_width,
-                                    _ptr(ids_sorted), _ptr(tile_bins), _ptr(xys), _ptr(conics),
-                                    _ptr(colors), _ptr(opacity), _ptr(background), _ptr(geo),
-                                    _ptr(final_Ts), _ptr(final_idx), _ptr(v_out_img), _ptr(v_xy),
-                                    _ptr(v_conic), _ptr(v_colors), _ptr(v_opacity), _ptr(ws),
-                                    ws.numel(), _stream(dev)), "gg_blend_bwd")
+        ws = _workspace(lib.gg_blend_workspace(n), dev)
+        _lib.check(lib.gg_blend_bwd(ch, n, img_height, img_width, _ptr(ids_sorted),
+                                    _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(colors),
+                                    _ptr(opacity), _ptr(background), _ptr(final_Ts),
+                                    _ptr(final_idx), _ptr(v_out_img), _ptr(v_xy), _ptr(v_conic),
+                                    _ptr(v_colors), _ptr(v_opacity), _ptr(ws), ws.numel(),
+                                    _stream(dev)), "gg_blend_bwd")
     return (v_xy, None, None, v_conic, None, v_colors, v_opacity.reshape(ctx.opacity_shape),
             None, None, None)
 

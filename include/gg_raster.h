@@ -109,36 +109,24 @@ int gg_bin_sort(int num_points, int64_t num_intersects, const float *xys, const 
                 void *ws, size_t ws_bytes, gg_stream_t stream);
 
 /* ---- alpha blending ----------------------------------------------------------------------
- * gg_geo_sort: the tile-sorted geometry stream of one view — for every entry of
- * gaussian_ids_sorted, in list order, 32 bytes {x, y, conic a, conic b | conic c, id, 0, 0}
- * (gg_geo_sort_bytes(I) bytes, 16-byte aligned).  It depends only on (gaussian_ids_sorted, xys,
- * conics), so ONE stream serves every rasterize call of a view and its backward: the blend kernels
- * read geometry with coalesced loads instead of gathering it per Gaussian id in each of the
- * reference's 4 forward + 4 backward launches (gaussian_splatting.py:735,747,759,773). */
-size_t gg_geo_sort_bytes(int64_t num_intersects);
-int gg_geo_sort(int64_t num_intersects, const int32_t *gaussian_ids_sorted, const float *xys,
-                const float *conics, void *geo_sorted, gg_stream_t stream);
-
-/* gg_blend_fwd replaces gsplat `_C.rasterize_forward` (C=3) and `_C.nd_rasterize_forward`
+ * gg_blend_fwd replaces gsplat `_C.rasterize_forward` (C=3) and `_C.nd_rasterize_forward`
  * (any C >= 1).  colors (N,C), opacity (N,) or (N,1), background (C,), out_img (H,W,C),
- * final_Ts (H,W), final_idx (H,W).  geo_sorted: the stream of gg_geo_sort for these
- * (gaussian_ids_sorted, xys, conics), or NULL — then it is built into the workspace first.
- * ws: gg_blend_workspace(num_points, geo_sorted ? 0 : num_intersects) bytes. */
-size_t gg_blend_workspace(int num_points, int64_t num_intersects_if_no_geo);
-int gg_blend_fwd(int channels, int num_points, int64_t num_intersects, int img_height, int img_width,
+ * final_Ts (H,W), final_idx (H,W).  ws: gg_blend_workspace(num_points) bytes. */
+size_t gg_blend_workspace(int num_points);
+int gg_blend_fwd(int channels, int num_points, int img_height, int img_width,
                  const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                  const float *conics, const float *colors, const float *opacity,
-                 const float *background, const void *geo_sorted, float *out_img, float *final_Ts,
-                 int32_t *final_idx, void *ws, size_t ws_bytes, gg_stream_t stream);
+                 const float *background, float *out_img, float *final_Ts, int32_t *final_idx,
+                 void *ws, size_t ws_bytes, gg_stream_t stream);
 
 /* gg_blend_bwd replaces gsplat `_C.rasterize_backward` / `_C.nd_rasterize_backward`.
  * v_xy (N,2), v_conic (N,3), v_colors (N,C), v_opacity (N,) are fully written. */
-int gg_blend_bwd(int channels, int num_points, int64_t num_intersects, int img_height, int img_width,
+int gg_blend_bwd(int channels, int num_points, int img_height, int img_width,
                  const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                  const float *conics, const float *colors, const float *opacity,
-                 const float *background, const void *geo_sorted, const float *final_Ts,
-                 const int32_t *final_idx, const float *v_out_img, float *v_xy, float *v_conic,
-                 float *v_colors, float *v_opacity, void *ws, size_t ws_bytes, gg_stream_t stream);
+                 const float *background, const float *final_Ts, const int32_t *final_idx,
+                 const float *v_out_img, float *v_xy, float *v_conic, float *v_colors,
+                 float *v_opacity, void *ws, size_t ws_bytes, gg_stream_t stream);
 
 /* ---- in-library kernel timing (measurement only; off by default) --------------------------------
  * When enabled, every launch of the kernels below is bracketed by a hipEvent pair recorded on the
@@ -153,7 +141,6 @@ int gg_blend_bwd(int channels, int num_points, int64_t num_intersects, int img_h
 #define GG_K_BLEND_PREP 5
 #define GG_K_QUAT_FWD 6
 #define GG_K_QUAT_BWD 7
-#define GG_K_GEO_SORT 8
 #define GG_K_BLEND_FWD 10 /* + width index: template widths {1,3,4,8,16,32} -> 0..5 */
 #define GG_K_BLEND_BWD 20 /* + width index */
 #define GG_PROF_NUM_KERNELS 32

@@ -39,10 +39,8 @@ def test_library_exports_every_declared_symbol():
 def test_workspace_queries_are_pure_host_calls():
     from gaussiangrasper_amd import _lib
     lib = _lib.load()
-    assert lib.gg_blend_workspace(1000, 0) >= 16 * 1000
-    assert lib.gg_blend_workspace(1000, 5000) >= 16 * 1000 + 32 * 5000   # + geometry stream
-    assert lib.gg_blend_workspace(0, 0) > 0
-    assert lib.gg_geo_sort_bytes(5000) >= 32 * 5000
+    assert lib.gg_blend_workspace(1000) >= 32 * 1000
+    assert lib.gg_blend_workspace(0) > 0
     small, big = lib.gg_bin_sort_workspace(1000, 5000), lib.gg_bin_sort_workspace(1_000_000, 4_000_000)
     assert 0 < small < big < 200 * 2 ** 20   # 1M / 4M intersections needs < 200 MiB of scratch
 
@@ -62,7 +60,7 @@ def test_argument_validation_without_a_gpu():
     assert st == -1 and b"num_bases" in lib.gg_last_error()
     st = lib.gg_sh_fwd(4, 4, 2, n, n, n, n)
     assert st == -1 and b"degrees_to_use" in lib.gg_last_error()
-    st = lib.gg_blend_fwd(0, 4, 0, 16, 16, n, n, n, n, n, n, n, n, n, n, n, n, 0, n)
+    st = lib.gg_blend_fwd(0, 4, 16, 16, n, n, n, n, n, n, n, n, n, n, n, 0, n)
     assert st == -1
     with pytest.raises(_lib.GGError):
         _lib.check(st, "gg_blend_fwd")

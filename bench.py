@@ -208,16 +208,20 @@ def main():
             P = args.height * args.width
             b_alg = algorithmic_bytes_blend_bwd(P, n_isect, n_vis, 32)
             achieved = b_alg / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
-            traffic = None
-            tfile = os.path.join(ROOT, "profiles", "traffic.json")   # from a separate --pmc run
+            traffic = valu_busy = None
+            tfile = os.path.join(ROOT, "profiles", "traffic.json")   # from separate --pmc runs
             if os.path.exists(tfile):
                 try:
-                    traffic = json.load(open(tfile)).get(dom)
+                    pmc = json.load(open(tfile))
+                    traffic = pmc.get(dom)
+                    valu_busy = pmc.get("valu_busy", {}).get(dom)
                 except Exception:  # noqa: BLE001
-                    traffic = None
+                    traffic = valu_busy = None
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                         "algorithmic_bytes_per_launch": b_alg,
+                        # the kernel is VALU-issue bound: share of VALU issue slots used (PMC pass)
+                        "valu_busy": valu_busy,
                         "avg_launch_ms": kernels[dom]["avg_ms"], "launches": kernels[dom]["launches"]}
         result["roofline"] = roofline
         result["kernels"] = {k: round(v["avg_ms"], 4) for k, v in sorted(kernels.items())}

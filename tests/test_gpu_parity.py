@@ -182,7 +182,9 @@ def _blend_inputs(oracle, n, h, w, ch, seed=0, cfg=1):
 @pytest.mark.parametrize("n,h,w,ch", [(1, 16, 16, 3), (7, 45, 70, 3), (2000, 48, 64, 1),
                                       (2000, 48, 64, 5), (50000, 300, 400, 3),
                                       (50000, 300, 400, 32), (20000, 150, 200, 39),
-                                      (5000, 100, 120, 128), (300000, 600, 800, 32)])
+                                      (5000, 100, 120, 128), (300000, 600, 800, 32),
+                                      (3000, 64, 80, 2), (3000, 64, 80, 8), (3000, 64, 80, 12),
+                                      (3000, 64, 80, 17), (3000, 64, 80, 35)])
 def test_blend_fwd_bitexact(oracle, n, h, w, ch):
     xys, depths, radii, conics, nth, colors, opac, bg = _blend_inputs(oracle, n, h, w, ch)
     ref_out, saved = oracle.rasterize_fwd(xys, depths, radii, conics, nth, colors, opac, h, w, bg)
@@ -206,7 +208,9 @@ def test_blend_fwd_bitexact(oracle, n, h, w, ch):
 
 @pytest.mark.parametrize("n,h,w,ch", [(1, 16, 16, 3), (7, 45, 70, 3), (2000, 48, 64, 1),
                                       (2000, 48, 64, 5), (50000, 300, 400, 3),
-                                      (50000, 300, 400, 32), (20000, 150, 200, 39)])
+                                      (50000, 300, 400, 32), (20000, 150, 200, 39),
+                                      (3000, 64, 80, 2), (3000, 64, 80, 8), (3000, 64, 80, 12),
+                                      (3000, 64, 80, 17), (3000, 64, 80, 35)])
 def test_blend_bwd(oracle, n, h, w, ch):
     """tolerance: |gpu-oracle| <= 2e-5*max|grad| + 1e-3*|grad| (fp32 atomics vs fp64-summed oracle;
     the kernel uses the algebraically-equal scalar-W form of v_alpha, see blend.hip header)"""

@@ -1,0 +1,238 @@
+// mlp.hip — feature up-projection MLP on the matrix pipe.
+//
+// Replaces the reference's `MLP(32, 512, hidden_list=[128])` forward (nerfstudio/models/
+// gaussian_splatting.py:198-213; `self.fea_up`, applied to EVERY pixel of the rendered 32-channel
+// feature image by render.sh, nerfstudio/pipelines/base_pipeline.py:408):
+//     y = W2 · relu(W1 · x + b1) + b2        x (P, IN)  ->  y (P, OUT),  hidden = 128, fp32.
+// At 1600x1200 that is 1.92 M x (32·128 + 128·512) x 2 = 267 GFLOP and 3.9 GB of output per view:
+// MFMA-bound in fp32 (157 TFLOP/s dense -> 1.70 ms), the only dense contraction near the path.
+//
+// One fused kernel, no intermediate in HBM, no LDS transpose between the layers:
+//   * everything is computed TRANSPOSED — H^T = W1·X^T, Y^T = W2·H^T — with
+//     v_mfma_f32_32x32x2_f32 (A[32x2]·B[2x32], exact fp32 fma chain).  The accumulator layout of
+//     layer 1 (lane = pixel column, registers = hidden rows (r&3) + 8(r>>2) + 4·(lane>>5)) IS the
+//     B-operand layout layer 2 wants (lane%32 = pixel, lane>>5 = which of the two k of the step) if
+//     the contraction over the hidden units runs in the order the registers hold them: step
+//     (blk, r) contracts hidden 32·blk + (r&3) + 8(r>>2) [lanes 0-31] and that + 4 [lanes 32-63].
+//     The A operand (W2) is laid out in LDS in that order once per workgroup.  The oracle
+//     (oracle/gg_oracle.c: mlp_fwd) sums in the same order, so results are bit-identical;
+//   * biases initialise the accumulators (C operand), ReLU is one v_max per hidden value;
+//   * persistent workgroups (one per CU, 4 waves = one per SIMD): the W2 slice of 256 output rows
+//     (128 KB, the LDS of a CU holds one) is staged once per slice, then every wave streams 64-pixel
+//     blocks: 64 MFMAs per 32-pixel tile for layer 1 (W1 lives in 64 VGPRs), 8 x 64 for layer 2 with
+//     one conflict-free ds_read_b32 per MFMA, results stored as 16-byte pieces (32 contiguous bytes
+//     per pixel and instruction).  Layer 1 is recomputed per slice (+6 % flops) instead of keeping H.
+// Measured alternatives (tools/mlp_bench.py): 4 waves x 2 tiles (one wave per SIMD) 2.52 ms; H as the
+// A operand of layer 2 (output columns on the lanes, full 128-byte rows per store) 2.57 ms; stores
+// of the previous block pair interleaved with the MFMAs of the next (ping-pong accumulators) 3.96 ms
+// (register cap at two waves per SIMD); x of the next block prefetched during layer 2: no change; this
+// form 2.46 ms = 109 TFLOP/s.  Ablations: no stores
+// -15 %, no x loads -6 %, no W2 staging gathers -6 %; a bare MFMA loop on this box sustains 144-153.
+#include "gg_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MLP_HID 128
+#define MLP_SLICE_NB 8                       // 32-row output blocks per W2 slice (8 x 64 x 64 x 4 B = 128 KB)
+#define MLP_STEPS (MLP_HID / 2)
+#ifndef MLP_ABL
+#define MLP_ABL 0   // measurement builds: 1 no stores, 2 no x loads, 3 no W2 gathers
+#endif
+#ifndef MLP_TPW
+#define MLP_TPW 1                            // 32-pixel tiles per wave (see the kernel)
+#endif              // k-steps of layer 2 (two hidden units per MFMA)
+
+// hidden unit supplied by lane-half `half` at k-step `step` of layer 2 (= accumulator row of layer 1)
+__host__ __device__ __forceinline__ int mlp_hidden_of(int step, int half) {
+    const int blk = step >> 4, r = step & 15;
+    return 32 * blk + (r & 3) + 8 * (r >> 2) + 4 * half;
+}
+
+// TPW: 32-pixel tiles per wave.  A workgroup always covers 256 pixels per iteration:
+// TPW = 2 -> 4 waves (one per SIMD, ~390 registers each); TPW = 1 -> 8 waves (two per SIMD, <= 256).
+template <int IN, int TPW>
+__global__ __launch_bounds__(256 * 2 / TPW) void mlp_fwd_kernel(long P, int out_dim,
+                                                               const float *__restrict__ x,
+                                                               const float *__restrict__ w1,
+                                                               const float *__restrict__ b1,
+                                                               const float *__restrict__ w2,
+                                                               const float *__restrict__ b2,
+                                                               float *__restrict__ y) {
+    static_assert(IN % 4 == 0 && IN >= 4 && IN <= 64, "in_dim: multiple of 4, <= 64");
+    constexpr int THREADS = 256 * 2 / TPW;
+    extern __shared__ float lds[];
+    float *w2s = lds;                                         // [nb][step][lane]
+    float *b1s = lds + MLP_SLICE_NB * MLP_STEPS * 64;         // [128]
+    float *b2s = b1s + MLP_HID;                               // [slice rows <= 256]
+    const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // W1 as A operands of layer 1: lane holds W1[32 blk + col][2 s + half]
+    float w1r[4][IN / 2];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int s = 0; s < IN / 2; ++s) w1r[blk][s] = w1[(size_t)(32 * blk + col) * IN + 2 * s + half];
+    for (int i = threadIdx.x; i < MLP_HID; i += THREADS) b1s[i] = b1[i];
+
+    const long nblocks = (P + 255) / 256;   // 256 pixels per workgroup iteration
+    const int nb_total = out_dim / 32;
+    for (int nb0 = 0; nb0 < nb_total; nb0 += MLP_SLICE_NB) {
+        const int nbs = min(MLP_SLICE_NB, nb_total - nb0);
+        __syncthreads();   // previous slice fully consumed
+        // stage the slice: w2s[nb][step][lane] = W2[32 (nb0+nb) + lane%32][hidden_of(step, lane>>5)].
+        // A thread takes four consecutive hidden units k = 4 q .. 4 q + 3 of one W2 row (one 16-byte
+        // load): they are the rows (r & 3) = 0..3 of one (blk, r >> 2, half), i.e. four consecutive
+        // k-steps for the same lane — four conflict-free LDS writes.
+        for (int i = threadIdx.x; i < nbs * 32 * (MLP_HID / 4); i += THREADS) {
+            const int row = i % (nbs * 32), q = i / (nbs * 32);       // lanes of a wave: consecutive rows
+            const float4 v = (MLP_ABL == 3) ? make_float4(1.f, 2.f, 3.f, 4.f)
+                                            : *reinterpret_cast<const float4 *>(
+                                                  w2 + (size_t)(32 * nb0 + row) * MLP_HID + 4 * q);
+            const int blk = q >> 3, w8 = q & 7;          // k = 32 blk + 4 w8 + (0..3)
+            const int hf = w8 & 1, rhi = w8 >> 1;        // k % 32 = (r & 3) + 4 half + 8 (r >> 2)
+            const int step = 16 * blk + 4 * rhi;         // + (r & 3)
+            float *dst = w2s + ((size_t)(row >> 5) * MLP_STEPS + step) * 64 + (row & 31) + 32 * hf;
+            dst[0] = v.x;
+            dst[64] = v.y;
+            dst[128] = v.z;
+            dst[192] = v.w;
+        }
+        for (int i = threadIdx.x; i < nbs * 32; i += THREADS) b2s[i] = b2[32 * nb0 + i];
+        __syncthreads();
+
+        for (long blkid = blockIdx.x; blkid < nblocks; blkid += gridDim.x) {
+            const long pix0 = blkid * 256 + wave * (32 * TPW);   // this wave's tiles
+            if (pix0 >= P) continue;
+            // ---------------- layer 1: H^T[hid][pixel] = W1 · X^T + b1, ReLU --------------------
+            f32x16 h[TPW][4];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const long pix = pix0 + 32 * t + col;
+                const bool ok = pix < P;
+                float xr[IN / 2];   // X^T as B operand: x[pixel][2 s + half]
+                const float4 *xp = reinterpret_cast<const float4 *>(x + (size_t)(ok ? pix : 0) * IN);
+#pragma unroll
+                for (int j = 0; j < IN / 4; ++j) {
+                    const float4 v = (MLP_ABL == 2) ? make_float4(1.f, 2.f, (float)pix, 4.f)
+                                     : ok ? xp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    xr[2 * j] = half ? v.y : v.x;
+                    xr[2 * j + 1] = half ? v.w : v.z;
+                }
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {   // rows 8 j + 4 half + 0..3 of the block
+                        const float4 bv = *reinterpret_cast<const float4 *>(b1s + 32 * blk + 8 * j + 4 * half);
+                        acc[4 * j] = bv.x;
+                        acc[4 * j + 1] = bv.y;
+                        acc[4 * j + 2] = bv.z;
+                        acc[4 * j + 3] = bv.w;
+                    }
+#pragma unroll
+                    for (int s = 0; s < IN / 2; ++s)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1r[blk][s], xr[s], acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.0f);
+                    h[t][blk] = acc;
+                }
+            }
+            // ---------------- layer 2: Y^T[out][pixel] = W2 · H^T + b2 ---------------------------
+            // 2 / TPW output blocks x TPW pixel tiles = two independent accumulator chains per wave
+            constexpr int NBW = 2 / TPW;
+            for (int nb = 0; nb < nbs; nb += NBW) {
+                f32x16 acc[NBW][TPW];
+                const float *arow[NBW];
+#pragma unroll
+                for (int u = 0; u < NBW; ++u) {
+                    const int nbu = min(nb + u, nbs - 1);   // odd block count: the last one twice
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {            // rows 8 j + 4 half + 0..3 of the block
+                        const float4 bv = *reinterpret_cast<const float4 *>(b2s + 32 * nbu + 8 * j + 4 * half);
+#pragma unroll
+                        for (int t = 0; t < TPW; ++t) {
+                            acc[u][t][4 * j] = bv.x;
+                            acc[u][t][4 * j + 1] = bv.y;
+                            acc[u][t][4 * j + 2] = bv.z;
+                            acc[u][t][4 * j + 3] = bv.w;
+                        }
+                    }
+                    arow[u] = w2s + (size_t)nbu * MLP_STEPS * 64 + lane;
+                }
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                        for (int u = 0; u < NBW; ++u) {
+                            const float a = arow[u][(16 * blk + r) * 64];
+#pragma unroll
+                            for (int t = 0; t < TPW; ++t)
+                                acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h[t][blk][r], acc[u][t], 0, 0, 0);
+                        }
+                    }
+                // lane holds Y[pixel col][32 (nb0+nb+u) + 8 j + 4 half + 0..3]: one 16-byte store per j
+#pragma unroll
+                for (int u = 0; u < NBW; ++u) {
+                    if (nb + u >= nbs) break;
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) {
+                        const long pix = pix0 + 32 * t + col;
+                        if (pix < P && MLP_ABL != 1) {
+                            float *yp = y + (size_t)pix * out_dim + 32 * (nb0 + nb + u) + 4 * half;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                *reinterpret_cast<float4 *>(yp + 8 * j) =
+                                    make_float4(acc[u][t][4 * j], acc[u][t][4 * j + 1], acc[u][t][4 * j + 2],
+                                                acc[u][t][4 * j + 3]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+extern "C" int gg_mlp_fwd(int64_t num_rows, int in_dim, int hidden_dim, int out_dim, const float *x,
+                          const float *w1, const float *b1, const float *w2, const float *b2, float *y,
+                          gg_stream_t stream) {
+    GG_REQUIRE(num_rows >= 0, "num_rows < 0");
+    GG_REQUIRE(hidden_dim == MLP_HID, "hidden_dim must be 128 (the reference's fea_up)");
+    GG_REQUIRE(in_dim == 8 || in_dim == 16 || in_dim == 32 || in_dim == 64,
+               "in_dim must be 8, 16, 32 or 64");
+    GG_REQUIRE(out_dim > 0 && out_dim % 32 == 0, "out_dim must be a positive multiple of 32");
+    if (num_rows == 0) return GG_OK;
+    GG_REQUIRE(x && w1 && b1 && w2 && b2 && y, "null pointer");
+    GG_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "x and y must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds_bytes = sizeof(float) * ((size_t)MLP_SLICE_NB * MLP_STEPS * 64 + MLP_HID + 32 * MLP_SLICE_NB);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const long nblocks = (num_rows + 255) / 256;
+    const int grid = (int)(nblocks < cus ? nblocks : cus);
+    hipError_t e = hipSuccess;
+#define MLP_LAUNCH(IN_)                                                                                   \
+    do {                                                                                                  \
+        e = hipFuncSetAttribute((const void *)mlp_fwd_kernel<IN_, MLP_TPW>,                               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);              \
+        if (e == hipSuccess)                                                                              \
+            hipLaunchKernelGGL((mlp_fwd_kernel<IN_, MLP_TPW>), dim3(grid), dim3(256 * 2 / MLP_TPW),       \
+                               lds_bytes, s, (long)num_rows, out_dim, x, w1, b1, w2, b2, y);              \
+    } while (0)
+    gg_prof_begin(GG_K_MLP_FWD, s);
+    if (in_dim == 8) MLP_LAUNCH(8);
+    else if (in_dim == 16) MLP_LAUNCH(16);
+    else if (in_dim == 32) MLP_LAUNCH(32);
+    else MLP_LAUNCH(64);
+    gg_prof_end(GG_K_MLP_FWD, s);
+    if (e != hipSuccess) {
+        gg_set_error("gg_mlp_fwd: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
+        return GG_ERR_LAUNCH;
+    }
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}

@@ -77,6 +77,7 @@ extern "C" const char *gg_prof_name(int id) {
         case GG_K_BLEND_PREP: return "blend_prep_kernel";
         case GG_K_QUAT_FWD: return "quat_to_rotmat_fwd_kernel";
         case GG_K_QUAT_BWD: return "quat_to_rotmat_bwd_kernel";
+        case GG_K_MLP_FWD: return "mlp_fwd_kernel";
         default: break;
     }
     if (id >= GG_K_BLEND_FWD && id < GG_K_BLEND_FWD + 6) {

@@ -1,0 +1,76 @@
+"""Feature up-projection MLP: host-side mirror of the reference's `MLP` module
+(nerfstudio/models/gaussian_splatting.py:198-213; instantiated as
+`self.fea_up = MLP(self.feature_dim, self.clip_dim, hidden_list=[128])` at :258, applied to every
+pixel of the rendered feature image by render.sh at nerfstudio/pipelines/base_pipeline.py:408 and to
+1000 sampled pixels per training step at :917).
+
+Same constructor, same sub-module layout (`layers = Sequential(Linear, ReLU, Linear)`, so reference
+checkpoints' `fea_up.layers.{0,2}.{weight,bias}` load unchanged) and same call.  The forward is ONE
+fused fp32 MFMA kernel (csrc/mlp.hip) behind `gg_mlp_fwd`; there is no CPU path.  The backward (only
+the 1000-point training use needs it) recomputes the hidden layer and uses plain library GEMMs."""
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+from torch import Tensor, nn
+from torch.autograd import Function
+
+from . import _lib
+from .ops import _f32, _ptr, _require_hip, _stream
+
+HIDDEN = 128
+SUPPORTED_IN = (8, 16, 32, 64)
+
+
+class _MLPForward(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor) -> Tensor:
+        dev = _require_hip(x, w1, b1, w2, b2)
+        in_dim, out_dim = w1.shape[1], w2.shape[0]
+        if tuple(w1.shape) != (HIDDEN, in_dim) or tuple(b1.shape) != (HIDDEN,) or \
+                tuple(w2.shape) != (out_dim, HIDDEN) or tuple(b2.shape) != (out_dim,):
+            raise ValueError("expected w1 (128, in), b1 (128,), w2 (out, 128), b2 (out,)")
+        if x.shape[-1] != in_dim:
+            raise ValueError(f"x has {x.shape[-1]} features, the first layer takes {in_dim}")
+        x2 = _f32(x).reshape(-1, in_dim)
+        w1c, b1c, w2c, b2c = _f32(w1), _f32(b1), _f32(w2), _f32(b2)
+        y = torch.empty(x2.shape[0], out_dim, dtype=torch.float32, device=dev)
+        _lib.check(_lib.load().gg_mlp_fwd(x2.shape[0], in_dim, HIDDEN, out_dim, _ptr(x2), _ptr(w1c),
+                                          _ptr(b1c), _ptr(w2c), _ptr(b2c), _ptr(y), _stream(dev)),
+                   "gg_mlp_fwd")
+        ctx.save_for_backward(x2, w1c, b1c, w2c)
+        ctx.x_shape = x.shape
+        return y.reshape(x.shape[:-1] + (out_dim,))
+
+    @staticmethod
+    def backward(ctx, v_y: Tensor):
+        x2, w1, b1, w2 = ctx.saved_tensors
+        g = _f32(v_y).reshape(-1, w2.shape[0])
+        h_pre = torch.addmm(b1, x2, w1.t())
+        g_h = (g @ w2) * (h_pre > 0)
+        v_w2 = g.t() @ torch.relu(h_pre)
+        return ((g_h @ w1).reshape(ctx.x_shape), g_h.t() @ x2, g_h.sum(0), v_w2, g.sum(0))
+
+
+def mlp_forward(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor) -> Tensor:
+    """relu(x @ w1.T + b1) @ w2.T + b2 on the matrix pipe; x (..., in) -> (..., out)."""
+    return _MLPForward.apply(x, w1, b1, w2, b2)
+
+
+class MLP(nn.Module):
+    """Drop-in for the reference's `MLP(in_dim=8, out_dim=512, hidden_list=[128])`."""
+
+    def __init__(self, in_dim: int = 8, out_dim: int = 512, hidden_list: Sequence[int] = (128,)):
+        super().__init__()
+        hidden_list = list(hidden_list)
+        if hidden_list != [HIDDEN] or in_dim not in SUPPORTED_IN or out_dim % 32 != 0:
+            raise NotImplementedError(
+                "the fused kernel covers the reference's fea_up shape family: one hidden layer of 128, "
+                f"in_dim in {SUPPORTED_IN}, out_dim a multiple of 32 (got in={in_dim}, "
+                f"hidden={hidden_list}, out={out_dim})")
+        self.layers = nn.Sequential(nn.Linear(in_dim, HIDDEN), nn.ReLU(), nn.Linear(HIDDEN, out_dim))
+
+    def forward(self, x: Tensor) -> Tensor:
+        l0, l2 = self.layers[0], self.layers[2]
+        return mlp_forward(x, l0.weight, l0.bias, l2.weight, l2.bias)

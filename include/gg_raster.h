@@ -128,6 +128,17 @@ int gg_blend_bwd(int channels, int num_points, int img_height, int img_width,
                  const float *v_out_img, float *v_xy, float *v_conic, float *v_colors,
                  float *v_opacity, void *ws, size_t ws_bytes, gg_stream_t stream);
 
+/* ---- feature up-projection MLP ------------------------------------------------
+ * Replaces the forward of the reference's `MLP(32, 512, hidden_list=[128])` module
+ * (nerfstudio/models/gaussian_splatting.py:198-213; `self.fea_up`, called on every pixel of the
+ * rendered feature image at nerfstudio/pipelines/base_pipeline.py:408):
+ *     y = relu(x @ w1^T + b1) @ w2^T + b2,  x (num_rows, in_dim), w1 (128, in_dim), b1 (128),
+ *     w2 (out_dim, 128), b2 (out_dim), y (num_rows, out_dim), all fp32 row-major (torch Linear
+ *     layout).  hidden_dim must be 128, in_dim 8/16/32/64, out_dim a multiple of 32. */
+int gg_mlp_fwd(int64_t num_rows, int in_dim, int hidden_dim, int out_dim, const float *x,
+               const float *w1, const float *b1, const float *w2, const float *b2, float *y,
+               gg_stream_t stream);
+
 /* ---- in-library kernel timing (measurement only; off by default) --------------------------------
  * When enabled, every launch of the kernels below is bracketed by a hipEvent pair recorded on the
  * launch stream, so bench.py can report the average duration of exactly that kernel over its
@@ -141,6 +152,7 @@ int gg_blend_bwd(int channels, int num_points, int img_height, int img_width,
 #define GG_K_BLEND_PREP 5
 #define GG_K_QUAT_FWD 6
 #define GG_K_QUAT_BWD 7
+#define GG_K_MLP_FWD 8
 #define GG_K_BLEND_FWD 10 /* + width index: template widths {1,3,4,8,16,32} -> 0..5 */
 #define GG_K_BLEND_BWD 20 /* + width index */
 #define GG_PROF_NUM_KERNELS 32

@@ -760,6 +760,41 @@ void NAME(blend_bwd)(int C, int N, int img_h, int img_w, int tiles_x, int tiles_
 
 /* Number of host threads the parallel loops above will use (bench.py cpu_baseline.cores). */
 #ifdef _OPENMP
+/* ------------------------------------------------------------------------------------------
+ * mlp_fwd — restates the reference's `MLP(in, out, hidden_list=[128])` forward
+ * (nerfstudio/models/gaussian_splatting.py:198-213: Linear(in,128) -> ReLU -> Linear(128,out);
+ * `self.fea_up` at :258, applied per pixel at nerfstudio/pipelines/base_pipeline.py:408 and to the
+ * sampled points at :917).  x (P,in), w1 (128,in), b1 (128), w2 (out,128), b2 (out) -> y (P,out).
+ * torch fixes no summation order for a Linear; this one is the HIP kernel's (csrc/mlp.hip): the
+ * accumulator starts at the bias, layer 1 adds k = 0,1,2,...; layer 2 adds the hidden units in the
+ * order the matrix pipe holds them: step (blk, r) = hidden 32 blk + (r&3) + 8 (r>>2), then that + 4.
+ * ---------------------------------------------------------------------------------------- */
+void NAME(mlp_fwd)(int64_t P, int in_dim, int out_dim, const REAL *x, const REAL *w1, const REAL *b1,
+                   const REAL *w2, const REAL *b2, REAL *y) {
+    enum { HID = 128 };
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < P; ++p) {
+        REAL h[HID];
+        const REAL *xp = x + (size_t)p * in_dim;
+        for (int j = 0; j < HID; ++j) {
+            REAL acc = b1[j];
+            for (int k = 0; k < in_dim; ++k) acc = FMA(w1[(size_t)j * in_dim + k], xp[k], acc);
+            h[j] = FMAX(acc, R_(0.0f));
+        }
+        for (int o = 0; o < out_dim; ++o) {
+            REAL acc = b2[o];
+            const REAL *wr = w2 + (size_t)o * HID;
+            for (int step = 0; step < HID / 2; ++step) {
+                const int blk = step >> 4, r = step & 15;
+                const int ha = 32 * blk + (r & 3) + 8 * (r >> 2), hb = ha + 4;
+                acc = FMA(wr[ha], h[ha], acc);
+                acc = FMA(wr[hb], h[hb], acc);
+            }
+            y[(size_t)p * out_dim + o] = acc;
+        }
+    }
+}
+
 int NAME(num_threads)(void) { return omp_get_max_threads(); }
 void NAME(set_num_threads)(int n) { omp_set_num_threads(n); }
 #else

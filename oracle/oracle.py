@@ -229,3 +229,19 @@ def quat_to_rotmat_bwd(quats, v_rot, dtype=np.float32):
     out = np.empty_like(q)
     getattr(lib, pre + "quat_to_rotmat_bwd")(C.c_int(q.shape[0]), _p(q), _p(g), _p(out))
     return out.reshape(np.shape(quats))
+
+
+def mlp_fwd(x, w1, b1, w2, b2, dtype=np.float32):
+    """Reference MLP(in, out, hidden_list=[128]) forward (gaussian_splatting.py:198-213):
+    relu(x @ w1.T + b1) @ w2.T + b2, in the summation order of the HIP kernel."""
+    lib, pre, _ = _lib(dtype)
+    x = _c(x, dtype)
+    shape = x.shape
+    x = x.reshape(-1, shape[-1])
+    w1, b1, w2, b2 = _c(w1, dtype), _c(b1, dtype), _c(w2, dtype), _c(b2, dtype)
+    assert w1.shape == (128, x.shape[1]) and b1.shape == (128,) and w2.shape[1] == 128
+    assert b2.shape == (w2.shape[0],)
+    y = np.empty((x.shape[0], w2.shape[0]), dtype)
+    getattr(lib, pre + "mlp_fwd")(C.c_int64(x.shape[0]), C.c_int(x.shape[1]), C.c_int(w2.shape[0]), _p(x),
+                                  _p(w1), _p(b1), _p(w2), _p(b2), _p(y))
+    return y.reshape(shape[:-1] + (w2.shape[0],))

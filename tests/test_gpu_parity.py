@@ -579,3 +579,71 @@ def test_quat_to_rotmat_hip_vs_oracle_and_torch(oracle):
         P.quat_to_rotmat(torch.randn(4, 4))
     with pytest.raises(ValueError):
         P.quat_to_rotmat(torch.randn(4, 3, device=DEV))
+
+
+@pytest.mark.parametrize("rows,in_dim,out_dim", [(1, 32, 512), (63, 32, 512), (64, 32, 512), (257, 32, 512),
+                                                 (5000, 32, 512), (1000, 8, 64), (1000, 16, 288),
+                                                 (777, 64, 32)])
+def test_mlp_fwd_bitexact_vs_oracle(oracle, rows, in_dim, out_dim):
+    """gg_mlp_fwd (fp32 MFMA) against the oracle, which sums in the kernel's order: bit-exact; and
+    against torch's Linear/ReLU/Linear on the GPU within 1e-5 of the output scale."""
+    from gaussiangrasper_amd.mlp import mlp_forward
+    g = torch.Generator().manual_seed(rows + in_dim)
+    x = torch.randn(rows, in_dim, generator=g)
+    w1, b1 = torch.randn(128, in_dim, generator=g) * 0.3, torch.randn(128, generator=g)
+    w2, b2 = torch.randn(out_dim, 128, generator=g) * 0.2, torch.randn(out_dim, generator=g)
+    y = mlp_forward(*[t.to(DEV) for t in (x, w1, b1, w2, b2)])
+    assert y.shape == (rows, out_dim)
+    assert_bitexact(_np(y), oracle.mlp_fwd(x.numpy(), w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy()), "mlp")
+    ref = torch.relu(x.to(DEV) @ w1.to(DEV).t() + b1.to(DEV)) @ w2.to(DEV).t() + b2.to(DEV)
+    assert float((y - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+def test_mlp_module_is_a_drop_in(oracle):
+    """Same sub-module names as the reference's MLP (checkpoint keys), same call on an (H, W, 32)
+    feature image, gradients of the 1000-point training use equal to torch autograd through the plain
+    Sequential within 1e-5, loud errors for CPU tensors and unsupported shapes."""
+    from gaussiangrasper_amd.mlp import MLP
+    torch.manual_seed(0)
+    m = MLP(32, 512, hidden_list=[128]).to(DEV)
+    assert sorted(m.state_dict()) == ["layers.0.bias", "layers.0.weight", "layers.2.bias", "layers.2.weight"]
+    img = torch.randn(45, 70, 32, device=DEV)
+    with torch.no_grad():
+        out = m(img)
+    assert out.shape == (45, 70, 512)
+    w = [_np(q) for q in (m.layers[0].weight, m.layers[0].bias, m.layers[2].weight, m.layers[2].bias)]
+    assert_bitexact(_np(out), oracle.mlp_fwd(_np(img), *w), "mlp.module")
+    pts = torch.randn(1000, 32, device=DEV, requires_grad=True)
+    v = torch.randn(1000, 512, device=DEV)
+    m.zero_grad()
+    m(pts).backward(v)
+    got = [pts.grad.clone()] + [q.grad.clone() for q in m.parameters()]
+    pts2 = pts.detach().clone().requires_grad_(True)
+    m.zero_grad()
+    m.layers(pts2).backward(v)
+    want = [pts2.grad] + [q.grad for q in m.parameters()]
+    for a, b in zip(got, want):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    with pytest.raises(RuntimeError):
+        MLP(32, 512, [128])(torch.randn(4, 32))
+    with pytest.raises(NotImplementedError):
+        MLP(32, 512, [64, 64])
+    with pytest.raises(ValueError):
+        m(torch.randn(4, 16, device=DEV))
+
+
+def test_mlp_full_image_rows_sampled_against_oracle(oracle):
+    """The render.sh size: every pixel of a 1600x1200x32 feature image -> 512 channels (3.9 GB of
+    output).  20 000 sampled rows bit-exact against the oracle; the untouched tail of a ragged row
+    count is covered by the small cases above."""
+    from gaussiangrasper_amd.mlp import mlp_forward
+    g = torch.Generator().manual_seed(9)
+    rows = 1200 * 1600
+    x = torch.randn(rows, 32, generator=g)
+    w1, b1 = torch.randn(128, 32, generator=g) * 0.3, torch.randn(128, generator=g)
+    w2, b2 = torch.randn(512, 128, generator=g) * 0.2, torch.randn(512, generator=g)
+    y = mlp_forward(*[t.to(DEV) for t in (x, w1, b1, w2, b2)])
+    idx = torch.randint(0, rows, (20000,), generator=g)
+    idx[:4] = torch.tensor([0, 1, rows - 2, rows - 1])
+    want = oracle.mlp_fwd(x[idx].numpy(), w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy())
+    assert_bitexact(_np(y[idx.to(DEV)]), want, "mlp.full")

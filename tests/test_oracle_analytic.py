@@ -299,3 +299,30 @@ def test_golden_vectors(oracle):
                                 fx, fy, cx, cy, h, w, got[2], got[3], z["v_xy"], np.zeros(len(got[2]), np.float32), z["v_conic"])
         for name, a in zip(("v_mean3d", "v_scale", "v_quat"), pm):
             assert np.array_equal(a, z[name]), (f, name)
+
+
+def test_mlp_oracle_matches_the_published_module(oracle):
+    """oracle.mlp_fwd against torch's Sequential(Linear(in,128), ReLU, Linear(128,out)) — the
+    reference's MLP (gaussian_splatting.py:198-213).  fp32: 1e-5 (summation order differs);
+    fp64 build: 1e-12."""
+    g = torch.Generator().manual_seed(3)
+    for in_dim, out_dim, rows in ((32, 512, 300), (8, 64, 37), (64, 96, 65)):
+        seq = torch.nn.Sequential(torch.nn.Linear(in_dim, 128), torch.nn.ReLU(), torch.nn.Linear(128, out_dim))
+        with torch.no_grad():
+            for prm in seq.parameters():
+                prm.copy_(torch.randn(prm.shape, generator=g) * 0.3)
+        x = torch.randn(rows, in_dim, generator=g)
+        w = [seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias]
+        with torch.no_grad():
+            ref32 = seq(x).numpy()
+            ref64 = seq.double()(x.double()).numpy()
+        got32 = oracle.mlp_fwd(x.numpy(), *[q.detach().float().numpy() for q in w])
+        got64 = oracle.mlp_fwd(x.double().numpy(), *[q.detach().double().numpy() for q in w],
+                               dtype=np.float64)
+        scale = np.abs(ref64).max()
+        assert np.abs(got32 - ref64).max() <= 1e-5 * scale and np.abs(ref32 - ref64).max() <= 1e-5 * scale
+        assert np.abs(got64 - ref64).max() <= 1e-12 * scale
+    # leading dims are kept
+    assert oracle.mlp_fwd(np.zeros((2, 3, 8), np.float32), np.zeros((128, 8), np.float32),
+                          np.zeros(128, np.float32), np.zeros((64, 128), np.float32),
+                          np.ones(64, np.float32)).shape == (2, 3, 64)

@@ -34,7 +34,7 @@ SIGNATURES = {
     "gg_blend_workspace": (_SZ, [_I]),
     "gg_blend_fwd": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gg_blend_bwd": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                          _P, _SZ, _P]),
+                          _P, _SZ, _I, _P]),
     "gg_expf_array": (_I, [_I, _P, _P, _P]),
     "gg_debug_set_ablation": (_I, [_I]),
     "gg_prof_enable": (_I, [_I]),

@@ -113,7 +113,7 @@ extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *i
                             const float *colors, const float *opacity, const float *background,
                             const float *final_Ts, const int32_t *final_idx, const float *v_out,
                             float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
-                            void *ws, size_t ws_bytes, gg_stream_t stream) {
+                            void *ws, size_t ws_bytes, int ws_from_forward, gg_stream_t stream) {
     GG_REQUIRE(C >= 1, "channels < 1");
     GG_REQUIRE(N >= 0, "num_points < 0");
     GG_REQUIRE(img_h > 0 && img_w > 0, "empty image");
@@ -127,10 +127,12 @@ extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *i
     }
     hipStream_t s = (hipStream_t)stream;
     GRec *rec = (GRec *)ws;
-    gg_prof_begin(GG_K_BLEND_PREP, s);
-    hipLaunchKernelGGL(blend_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, xys, conics,
-                       opacity, rec);
-    gg_prof_end(GG_K_BLEND_PREP, s);
+    if (!ws_from_forward) {
+        gg_prof_begin(GG_K_BLEND_PREP, s);
+        hipLaunchKernelGGL(blend_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, xys, conics,
+                           opacity, rec);
+        gg_prof_end(GG_K_BLEND_PREP, s);
+    }
     // the kernels accumulate with atomics: the four gradient arrays start at zero (one memset when
     // the caller laid them out back to back: v_xy | v_conic | v_opacity | v_colors)
     bool fail;

@@ -316,8 +316,9 @@ def _rasterize_forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, o
                                 _ptr(opacity_c), _ptr(background), _ptr(out_img), _ptr(final_Ts),
                                 _ptr(final_idx), _ptr(ws), ws.numel(), _stream(dev)),
                "gg_blend_fwd")
+    # ws holds the packed per-Gaussian records of this call: the backward reuses them
     ctx.save_for_backward(xys_c, conics_c, colors_c, opacity_c, background,
-                          bins.gaussian_ids_sorted, bins.tile_bins, final_Ts, final_idx)
+                          bins.gaussian_ids_sorted, bins.tile_bins, final_Ts, final_idx, ws)
     return out_img
 
 
@@ -329,7 +330,7 @@ def _rasterize_backward(ctx, v_out_img):
         v_colors, v_opacity = torch.zeros_like(colors), torch.zeros_like(opacity)
     else:
         (xys, conics, colors, opacity, background, ids_sorted, tile_bins, final_Ts,
-         final_idx) = ctx.saved_tensors
+         final_idx, ws) = ctx.saved_tensors
         dev, n, ch = xys.device, xys.shape[0], colors.shape[1]
         v_out_img = _f32(v_out_img)
         # one allocation laid out v_xy | v_conic | v_opacity | v_colors: the library zeroes it with a
@@ -340,12 +341,11 @@ def _rasterize_backward(ctx, v_out_img):
         v_opacity = flat[5 * n:6 * n].view(n, 1)
         v_colors = flat[6 * n:].view(n, ch)
         lib = _lib.load()
-        ws = _workspace(lib.gg_blend_workspace(n), dev)
         _lib.check(lib.gg_blend_bwd(ch, n, img_height, img_width, _ptr(ids_sorted),
                                     _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(colors),
                                     _ptr(opacity), _ptr(background), _ptr(final_Ts),
                                     _ptr(final_idx), _ptr(v_out_img), _ptr(v_xy), _ptr(v_conic),
-                                    _ptr(v_colors), _ptr(v_opacity), _ptr(ws), ws.numel(),
+                                    _ptr(v_colors), _ptr(v_opacity), _ptr(ws), ws.numel(), 1,
                                     _stream(dev)), "gg_blend_bwd")
     return (v_xy, None, None, v_conic, None, v_colors, v_opacity.reshape(ctx.opacity_shape),
             None, None, None)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Does the memory order of the Gaussians matter to the blend kernels?  Times the 3- and 32-channel
-forward/backward on the bench workload with the Gaussians (a) in scene order (random), (b) permuted
-into centre-tile order, so that the records a tile list gathers are neighbours in memory."""
+"""Kernel timing on the bench workload (in-library hipEvents): the 3- and 32-channel rasterize
+forward/backward and the binning, two rounds of four launches each (the second round is reported).
+`run(label, idx)` takes a permutation of the Gaussians: profiles/README.md records the experiment
+that used it (Gaussians permuted into centre-tile order: no change)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "shim"), os.path.join(ROOT, "tools")]

@@ -228,3 +228,47 @@ def test_gradient_all_reduce_equals_single_process(tmp_path):
     train_step(rb, bucket, range(4), reduce=False)
     assert float(bucket.flat.abs().sum()) > 0
     assert torch.allclose(reduced, bucket.flat, rtol=1e-5, atol=1e-6 * float(bucket.flat.abs().max()))
+
+
+def test_checkpoint_and_ply_round_trips(tmp_path):
+    """SURVEY 8f-4 wire formats: the reference's checkpoint layout (trainer.py:437-449, model keys
+    gaussian_splatting.py:271-281 + fea_up) and its splat PLY property set (exporter.py:499-525)."""
+    from gaussiangrasper_amd import interop
+    from gaussiangrasper_amd.scene import make_scene
+    sc = make_scene(257, feature_dim=32, sh_degree=4, config_index=7)
+    mlp_state = {"layers.0.weight": torch.randn(128, 32), "layers.0.bias": torch.randn(128),
+                 "layers.2.weight": torch.randn(512, 128), "layers.2.bias": torch.randn(512)}
+    ck = tmp_path / "step-000001234.ckpt"
+    interop.save_checkpoint(ck, sc, mlp_state, step=1234)
+    blob = torch.load(ck, weights_only=True)          # what the reference's trainer reads
+    assert blob["step"] == 1234 and set(blob) == {"step", "pipeline", "optimizers", "schedulers", "scalers"}
+    assert sorted(blob["pipeline"]) == sorted(
+        ["_model." + k for k in interop.PARAM_KEYS + interop.MLP_KEYS])
+    sc2, mlp2, step = interop.load_checkpoint(ck)
+    assert step == 1234
+    for a, b in zip(sc.params(), sc2.params()):
+        assert torch.equal(a, b)
+    assert all(torch.equal(mlp_state[k], mlp2[k]) for k in mlp_state)
+    with pytest.raises(KeyError):
+        interop.scene_from_state_dict({"_model.means": sc.means})
+    bad = interop.state_dict_from_scene(sc)
+    bad["_model.quats"] = torch.zeros(257, 3)
+    with pytest.raises(ValueError):
+        interop.scene_from_state_dict(bad)
+
+    ply = tmp_path / "point_cloud.ply"
+    interop.export_ply(ply, sc)
+    head = open(ply, "rb").read(4096).split(b"end_header\n")[0].decode().splitlines()
+    assert head[:3] == ["ply", "format binary_little_endian 1.0", "element vertex 257"]
+    names = [ln.split()[2] for ln in head[3:]]
+    assert names == (["x", "y", "z", "nx", "ny", "nz", "red", "green", "blue", "f_dc_0", "f_dc_1", "f_dc_2"]
+                     + [f"f_rest_{i}" for i in range(72)] + ["opacity", "scale_0", "scale_1", "scale_2",
+                                                             "rot_0", "rot_1", "rot_2", "rot_3"])
+    assert os.path.getsize(ply) == len("\n".join(head)) + len("\nend_header\n") + 257 * (4 * (6 + 3 + 72 + 1 + 3 + 4) + 3)
+    sc3 = interop.load_ply(ply, feature_dim=32)
+    for name in ("means", "scales", "quats", "opacities"):
+        assert torch.equal(getattr(sc, name), getattr(sc3, name)), name
+    assert torch.equal(sc.colors_all[:, 1:], sc3.colors_all[:, 1:])
+    # f_dc holds SH2RGB(dc) as in the reference's exporter: back through RGB2SH within rounding
+    assert torch.allclose(sc.colors_all[:, 0], sc3.colors_all[:, 0], atol=1e-6)
+    assert sc3.feature.shape == (257, 32) and not sc3.feature.any()

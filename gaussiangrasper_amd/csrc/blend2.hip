@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
             // id bits live in b.w of the record
             const int my_gid = __builtin_bit_cast(int, L.b[kk - my_q].w);
             if (ABL >= 1) { KEEP(mine); KEEP(my_gid); continue; }
-            if (owner && my_gid >= 0) atomicAdd(my_base + (size_t)my_gid * my_stride, mine);
+            if (owner && my_gid >= 0 && mine != 0.0f) atomicAdd(my_base + (size_t)my_gid * my_stride, mine);
         }
         __builtin_amdgcn_wave_barrier();  // the list is rewritten by the next chunk
     }
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
         for (int r = 0; r < 16; ++r) {
             const int slot = (r & 3) + 8 * (r >> 2) + 4 * half;
             if (ABL >= 1) { KEEP(acc[r]); continue; }
-            if (slot < nslots && wch_ok)
+            if (slot < nslots && wch_ok && acc[r] != 0.0f)
                 atomicAdd(v_colors + (size_t)slotgid[slot] * C + ch_off + wch, acc[r]);
         }
         nslots = 0;
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
             }
             const float mine = R::run(part, lane);
             const int my_gid = __builtin_bit_cast(int, L.b[kk - my_q].w);
-            if (owner && my_gid >= 0) atomicAdd(my_base + (size_t)my_gid * my_stride, mine);
+            if (owner && my_gid >= 0 && mine != 0.0f) atomicAdd(my_base + (size_t)my_gid * my_stride, mine);
         }
         __builtin_amdgcn_wave_barrier();
     }

@@ -49,12 +49,12 @@ void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w
                           int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
                           const float *colors, const float *background, const float *final_Ts,
                           const int32_t *final_idx, const float *v_out, float *v_xy, float *v_conic,
-                          float *v_colors, float *v_opacity, hipStream_t s);
+                          float *v_colors, float *v_opacity, int gstride, int cstride, hipStream_t s);
 void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, int tiles_x,
                                  int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
                                  const float *colors, const float *background, const float *final_Ts,
                                  const int32_t *final_idx, const float *v_out, float *v_xy,
-                                 float *v_conic, float *v_colors, float *v_opacity, hipStream_t s);
+                                 float *v_conic, float *v_colors, float *v_opacity, int gstride, int cstride, hipStream_t s);
 
 // Channel chunking: calls with <= 3 channels (rgb / depth / normal) use the narrow kernels with
 // the colours inside the LDS record; anything wider is processed in chunks of 32 channels on the
@@ -113,7 +113,8 @@ extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *i
                             const float *colors, const float *opacity, const float *background,
                             const float *final_Ts, const int32_t *final_idx, const float *v_out,
                             float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
-                            void *ws, size_t ws_bytes, int ws_from_forward, gg_stream_t stream) {
+                            int geom_stride, int color_stride, void *ws, size_t ws_bytes,
+                            int ws_from_forward, gg_stream_t stream) {
     GG_REQUIRE(C >= 1, "channels < 1");
     GG_REQUIRE(N >= 0, "num_points < 0");
     GG_REQUIRE(img_h > 0 && img_w > 0, "empty image");
@@ -135,15 +136,27 @@ extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *i
     }
     // the kernels accumulate with atomics: the four gradient arrays start at zero (one memset when
     // the caller laid them out back to back: v_xy | v_conic | v_opacity | v_colors)
+    GG_REQUIRE(geom_stride == 0 || geom_stride >= 6, "geom_stride must be 0 (dense) or >= 6");
+    GG_REQUIRE(color_stride == 0 || color_stride >= C, "color_stride must be 0 (dense) or >= channels");
     bool fail;
-    if (v_conic == v_xy + 2 * (size_t)N && v_opacity == v_conic + 3 * (size_t)N &&
-        v_colors == v_opacity + (size_t)N) {
-        fail = hipMemsetAsync(v_xy, 0, sizeof(float) * (6 + (size_t)C) * (size_t)N, s) != hipSuccess;
+    const size_t n = (size_t)N;
+    if (geom_stride > 0) {
+        // interleaved records {xy, conic, opacity[, colours]} of geom_stride floats per Gaussian
+        GG_REQUIRE(v_conic == v_xy + 2 && v_opacity == v_xy + 5, "interleaved geometry gradients: "
+                   "v_conic = v_xy + 2 and v_opacity = v_xy + 5 expected");
+        fail = hipMemsetAsync(v_xy, 0, sizeof(float) * geom_stride * n, s) != hipSuccess;
+        if (!(color_stride == geom_stride && v_colors == v_xy + 6))   // colours live elsewhere
+            fail |= hipMemsetAsync(v_colors, 0, sizeof(float) * (color_stride ? color_stride : C) * n, s) !=
+                    hipSuccess;
+    } else if (color_stride == 0 && v_conic == v_xy + 2 * n && v_opacity == v_conic + 3 * n &&
+               v_colors == v_opacity + n) {
+        fail = hipMemsetAsync(v_xy, 0, sizeof(float) * (6 + (size_t)C) * n, s) != hipSuccess;
     } else {
-        fail = hipMemsetAsync(v_xy, 0, sizeof(float) * 2 * (size_t)N, s) != hipSuccess;
-        fail |= hipMemsetAsync(v_conic, 0, sizeof(float) * 3 * (size_t)N, s) != hipSuccess;
-        fail |= hipMemsetAsync(v_colors, 0, sizeof(float) * (size_t)C * (size_t)N, s) != hipSuccess;
-        fail |= hipMemsetAsync(v_opacity, 0, sizeof(float) * (size_t)N, s) != hipSuccess;
+        fail = hipMemsetAsync(v_xy, 0, sizeof(float) * 2 * n, s) != hipSuccess;
+        fail |= hipMemsetAsync(v_conic, 0, sizeof(float) * 3 * n, s) != hipSuccess;
+        fail |= hipMemsetAsync(v_colors, 0, sizeof(float) * (color_stride ? color_stride : C) * n, s) !=
+                hipSuccess;
+        fail |= hipMemsetAsync(v_opacity, 0, sizeof(float) * n, s) != hipSuccess;
     }
     if (fail) {
         gg_set_error("gg_blend_bwd: memset failed");
@@ -158,11 +171,13 @@ extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *i
         if ((w == 3 && g_ablate > 0 && g_ablate < 10) || (w == 32 && n == 32 && g_ablate > 10))
             gg_launch_blend2_bwd_ablate(g_ablate, C, off, img_h, img_w, tiles_x, ntiles, ids,
                                         (const int2 *)tile_bins, rec, colors, background, final_Ts,
-                                        final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, s);
+                                        final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, geom_stride,
+                                        color_stride, s);
         else
             gg_launch_blend2_bwd(w, C, off, n, img_h, img_w, tiles_x, ntiles, ids,
                                  (const int2 *)tile_bins, rec, colors, background, final_Ts,
-                                 final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, s);
+                                 final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, geom_stride,
+                                 color_stride, s);
         gg_prof_end(GG_K_BLEND_BWD + gg_width_index(w), s);
         off += n;
     }

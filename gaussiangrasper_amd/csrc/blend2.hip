@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
     const float *__restrict__ colors, const float *__restrict__ background,
     const float *__restrict__ final_T, const int32_t *__restrict__ final_idx,
     const float *__restrict__ v_out, float *__restrict__ v_xy, float *__restrict__ v_conic,
-    float *__restrict__ v_colors, float *__restrict__ v_opacity) {
+    float *__restrict__ v_colors, float *__restrict__ v_opacity, int gstride, int cstride) {
     constexpr int K = CH + 6;       // per-Gaussian values: CH colours, xy(2), conic(3), opacity(1)
     constexpr int KB = GRP * K;     // butterfly width
     using R = Red6<KB>;
@@ -275,10 +275,12 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
     const int my_q = myvar / K, my_k = myvar - my_q * K;
     float *my_base;     // gradient array of my value
     int my_stride;      // floats per Gaussian in that array
-    if (my_k < CH) { my_base = v_colors + ch_off + my_k; my_stride = C; }
-    else if (my_k < CH + 2) { my_base = v_xy + (my_k - CH); my_stride = 2; }
-    else if (my_k < CH + 5) { my_base = v_conic + (my_k - CH - 2); my_stride = 3; }
-    else { my_base = v_opacity; my_stride = 1; }
+    // gstride / cstride: floats between consecutive Gaussians in the geometry / colour gradient
+    // arrays (0 = dense 2 | 3 | 1 | C); interleaved records put all of a Gaussian's atomics on one line
+    if (my_k < CH) { my_base = v_colors + ch_off + my_k; my_stride = cstride ? cstride : C; }
+    else if (my_k < CH + 2) { my_base = v_xy + (my_k - CH); my_stride = gstride ? gstride : 2; }
+    else if (my_k < CH + 5) { my_base = v_conic + (my_k - CH - 2); my_stride = gstride ? gstride : 3; }
+    else { my_base = v_opacity; my_stride = gstride ? gstride : 1; }
 
     for (int top = hi; top > range.x; top -= 64) {
         const int e = top - 64 + lane;
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
     const float *__restrict__ colors, const float *__restrict__ background,
     const float *__restrict__ final_T, const int32_t *__restrict__ final_idx,
     const float *__restrict__ v_out, float *__restrict__ v_xy, float *__restrict__ v_conic,
-    float *__restrict__ v_colors, float *__restrict__ v_opacity) {
+    float *__restrict__ v_colors, float *__restrict__ v_opacity, int gstride, int cstride) {
     constexpr int CH = CHD;
     constexpr int KG = 6;
     constexpr int KB = GRP * KG;
@@ -440,9 +442,10 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
     const int my_q = myvar / KG, my_k = myvar - my_q * KG;
     float *my_base;
     int my_stride;
-    if (my_k < 2) { my_base = v_xy + my_k; my_stride = 2; }
-    else if (my_k < 5) { my_base = v_conic + (my_k - 2); my_stride = 3; }
-    else { my_base = v_opacity; my_stride = 1; }
+    if (my_k < 2) { my_base = v_xy + my_k; my_stride = gstride ? gstride : 2; }
+    else if (my_k < 5) { my_base = v_conic + (my_k - 2); my_stride = gstride ? gstride : 3; }
+    else { my_base = v_opacity; my_stride = gstride ? gstride : 1; }
+    const int cs = cstride ? cstride : C;
 
     int nslots = 0;  // wave-uniform
     auto flush_slots = [&]() {
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
             const int slot = (r & 3) + 8 * (r >> 2) + 4 * half;
             if (ABL >= 1) { KEEP(acc[r]); continue; }
             if (slot < nslots && wch_ok && acc[r] != 0.0f)
-                atomicAdd(v_colors + (size_t)slotgid[slot] * C + ch_off + wch, acc[r]);
+                atomicAdd(v_colors + (size_t)slotgid[slot] * cs + ch_off + wch, acc[r]);
         }
         nslots = 0;
     };
@@ -579,12 +582,12 @@ void gg_launch_blend2_fwd(int width, int C, int off, int n, int img_h, int img_w
 }
 
 #define B2_BWDN_ARGS C, off, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, \
-                     final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity
+                     final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, gstride, cstride
 void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w, int tiles_x,
                           int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
                           const float *colors, const float *background, const float *final_Ts,
                           const int32_t *final_idx, const float *v_out, float *v_xy, float *v_conic,
-                          float *v_colors, float *v_opacity, hipStream_t s) {
+                          float *v_colors, float *v_opacity, int gstride, int cstride, hipStream_t s) {
     dim3 grid(gg_tile_grid(ntiles)), block(256);
     if (width == 1)
         hipLaunchKernelGGL((blend2_bwd_narrow_kernel<1>), grid, block, 0, s, B2_BWDN_ARGS);
@@ -593,7 +596,7 @@ void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w
     else if (width == 3)
         hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3>), grid, block, 0, s, B2_BWDN_ARGS);
 #define B2_BWDW_ARGS C, off, n, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, \
-                     final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity
+                     final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, gstride, cstride
     else if (n == 32)
         hipLaunchKernelGGL((blend2_bwd_wide_kernel<true>), grid, block, 0, s, B2_BWDW_ARGS);
     else if (n <= 8)
@@ -609,12 +612,12 @@ void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, 
                                  int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
                                  const float *colors, const float *background, const float *final_Ts,
                                  const int32_t *final_idx, const float *v_out, float *v_xy,
-                                 float *v_conic, float *v_colors, float *v_opacity, hipStream_t s) {
+                                 float *v_conic, float *v_colors, float *v_opacity, int gstride, int cstride, hipStream_t s) {
     dim3 grid(gg_tile_grid(ntiles)), block(256);
     switch (abl) {
 #define B2_WABL(L) hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, L>), grid, block, 0, s, C, off, 32, \
         img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, final_Ts, final_idx, v_out, \
-        v_xy, v_conic, v_colors, v_opacity)
+        v_xy, v_conic, v_colors, v_opacity, gstride, cstride)
         case 11: B2_WABL(1); break;
         case 12: B2_WABL(2); break;
         case 13: B2_WABL(3); break;

@@ -333,20 +333,27 @@ def _rasterize_backward(ctx, v_out_img):
          final_idx, ws) = ctx.saved_tensors
         dev, n, ch = xys.device, xys.shape[0], colors.shape[1]
         v_out_img = _f32(v_out_img)
-        # one allocation laid out v_xy | v_conic | v_opacity | v_colors: the library zeroes it with a
-        # single memset (the kernels accumulate with atomics)
-        flat = torch.empty(n * (6 + ch), dtype=torch.float32, device=dev)
-        v_xy = flat[:2 * n].view(n, 2)
-        v_conic = flat[2 * n:5 * n].view(n, 3)
-        v_opacity = flat[5 * n:6 * n].view(n, 1)
-        v_colors = flat[6 * n:].view(n, ch)
+        # Gradient layout: the kernels add with float atomics, and what they cost is cache lines
+        # touched per instruction — so the geometry gradients of a Gaussian sit in ONE interleaved
+        # record {xy, conic, opacity} (+ the colours for <= 3 channels); the tensors handed back to
+        # autograd are strided views of it.  32-channel colour rows stay dense (128-byte rows).
+        if ch <= 3:
+            rec_g = torch.empty(n, 6 + ch, dtype=torch.float32, device=dev)
+            v_colors = rec_g[:, 6:]
+            gstride = cstride = 6 + ch
+        else:
+            flat = torch.empty(n * (6 + ch), dtype=torch.float32, device=dev)
+            rec_g = flat[:6 * n].view(n, 6)
+            v_colors = flat[6 * n:].view(n, ch)
+            gstride, cstride = 6, 0
+        v_xy, v_conic, v_opacity = rec_g[:, 0:2], rec_g[:, 2:5], rec_g[:, 5:6]
         lib = _lib.load()
         _lib.check(lib.gg_blend_bwd(ch, n, img_height, img_width, _ptr(ids_sorted),
                                     _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(colors),
                                     _ptr(opacity), _ptr(background), _ptr(final_Ts),
                                     _ptr(final_idx), _ptr(v_out_img), _ptr(v_xy), _ptr(v_conic),
-                                    _ptr(v_colors), _ptr(v_opacity), _ptr(ws), ws.numel(), 1,
-                                    _stream(dev)), "gg_blend_bwd")
+                                    _ptr(v_colors), _ptr(v_opacity), gstride, cstride, _ptr(ws),
+                                    ws.numel(), 1, _stream(dev)), "gg_blend_bwd")
     return (v_xy, None, None, v_conic, None, v_colors, v_opacity.reshape(ctx.opacity_shape),
             None, None, None)
 

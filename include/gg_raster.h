@@ -123,14 +123,20 @@ int gg_blend_fwd(int channels, int num_points, int img_height, int img_width,
  * v_xy (N,2), v_conic (N,3), v_colors (N,C), v_opacity (N,) are fully written.
  * ws_from_forward != 0: `ws` is the very workspace the matching gg_blend_fwd call (same xys, conics,
  * opacity) ran with, untouched since — its packed per-Gaussian records are reused instead of being
- * packed again (gsplat's backward re-reads xys/conics/opacities itself; this saves one pass). */
+ * packed again (gsplat's backward re-reads xys/conics/opacities itself; this saves one pass).
+ * geom_stride / color_stride: floats between consecutive Gaussians in v_xy, v_conic, v_opacity /
+ * in v_colors; 0 = the dense arrays above.  geom_stride >= 6 means ONE interleaved record per
+ * Gaussian, {xy.x, xy.y, conic a, b, c, opacity[, colours]}: v_conic = v_xy + 2, v_opacity =
+ * v_xy + 5 (and v_colors = v_xy + 6 with color_stride = geom_stride when the colours are part of
+ * it).  The kernels add with float atomics; an interleaved record puts all of a Gaussian's
+ * atomics of one instruction on one cache line instead of four. */
 int gg_blend_bwd(int channels, int num_points, int img_height, int img_width,
                  const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                  const float *conics, const float *colors, const float *opacity,
                  const float *background, const float *final_Ts, const int32_t *final_idx,
                  const float *v_out_img, float *v_xy, float *v_conic, float *v_colors,
-                 float *v_opacity, void *ws, size_t ws_bytes, int ws_from_forward,
-                 gg_stream_t stream);
+                 float *v_opacity, int geom_stride, int color_stride, void *ws, size_t ws_bytes,
+                 int ws_from_forward, gg_stream_t stream);
 
 /* ---- feature up-projection MLP ------------------------------------------------
  * Replaces the forward of the reference's `MLP(32, 512, hidden_list=[128])` module

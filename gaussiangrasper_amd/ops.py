@@ -337,14 +337,14 @@ def _rasterize_backward(ctx, v_out_img):
         # touched per instruction — so the geometry gradients of a Gaussian sit in ONE interleaved
         # record {xy, conic, opacity} (+ the colours for <= 3 channels); the tensors handed back to
         # autograd are strided views of it.  32-channel colour rows stay dense (128-byte rows).
+        # (records padded to 64 / 32 bytes so that none straddles a line measure the same.)
         if ch <= 3:
             rec_g = torch.empty(n, 6 + ch, dtype=torch.float32, device=dev)
             v_colors = rec_g[:, 6:]
             gstride = cstride = 6 + ch
         else:
-            flat = torch.empty(n * (6 + ch), dtype=torch.float32, device=dev)
-            rec_g = flat[:6 * n].view(n, 6)
-            v_colors = flat[6 * n:].view(n, ch)
+            rec_g = torch.empty(n, 6, dtype=torch.float32, device=dev)
+            v_colors = torch.empty(n, ch, dtype=torch.float32, device=dev)   # own allocation: aligned rows
             gstride, cstride = 6, 0
         v_xy, v_conic, v_opacity = rec_g[:, 0:2], rec_g[:, 2:5], rec_g[:, 5:6]
         lib = _lib.load()

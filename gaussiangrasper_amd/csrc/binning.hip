@@ -190,25 +190,51 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    // prefix over waves per digit, folded into this wave's base
+    // Per digit: offsets of the waves inside the block's run of that digit, the block's count, and —
+    // exclusive scan over the digits — where the run starts in the block's locally sorted order.
+    __shared__ uint32_t lstart[256];
+    __shared__ uint32_t skey[RS_TILE], sval[RS_TILE];
     {
-        uint32_t run = digit_base[tid];
+        uint32_t run = 0;
         for (int w = 0; w < RS_WAVES; ++w) {
             uint32_t c = whist[w][tid];
             whist[w][tid] = run;
             run += c;
         }
+        uint32_t incl = run;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t u = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += u;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t wpre = 0;
+        for (int w = 0; w < wave; ++w) wpre += wsum[w];
+        lstart[tid] = wpre + incl - run;
     }
     __syncthreads();
+    // The keys go through LDS in locally sorted order, so that consecutive threads write consecutive
+    // addresses of a digit's run: a store instruction touches a few cache lines instead of one per
+    // lane (the direct scatter moved 85 MB in 63 us at I = 5.3 M).
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
         int64_t idx = wbase + (int64_t)it * GG_WAVE + lane;
         if (idx < n) {
             uint32_t d = (key[it] >> shift) & mask;
-            uint32_t dst = whist[wave][d] + rank[it];
-            keys_out[dst] = key[it];
-            vals_out[dst] = val[it];
+            uint32_t lp = lstart[d] + whist[wave][d] + rank[it];
+            skey[lp] = key[it];
+            sval[lp] = val[it];
         }
+    }
+    __syncthreads();
+    const int64_t left = n - (int64_t)blockIdx.x * RS_TILE;
+    const int count = (int)(left < RS_TILE ? left : RS_TILE);
+    for (int jj = tid; jj < count; jj += RS_THREADS) {
+        const uint32_t k = skey[jj];
+        const uint32_t d = (k >> shift) & mask;
+        const uint32_t dst = digit_base[d] + ((uint32_t)jj - lstart[d]);
+        keys_out[dst] = k;
+        vals_out[dst] = sval[jj];
     }
 }
 

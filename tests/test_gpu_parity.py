@@ -647,3 +647,55 @@ def test_mlp_full_image_rows_sampled_against_oracle(oracle):
     idx[:4] = torch.tensor([0, 1, rows - 2, rows - 1])
     want = oracle.mlp_fwd(x[idx].numpy(), w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy())
     assert_bitexact(_np(y[idx.to(DEV)]), want, "mlp.full")
+
+
+@pytest.mark.parametrize("ch", [3, 32, 35])
+def test_blend_bwd_c_abi_gradient_layouts(oracle, ch):
+    """gg_blend_bwd through the C ABI with (a) the dense gradient arrays gsplat's binding fills
+    (geom_stride = color_stride = 0, fresh workspace, ws_from_forward = 0), (b) interleaved geometry
+    records with dense colours, (c) for <= 3 channels the fully interleaved record — all against the
+    oracle with the tolerance of test_blend_bwd."""
+    from gaussiangrasper_amd import _lib
+    lib = _lib.load()
+    n, h, w = 3000, 64, 80
+    xys, depths, radii, conics, nth, colors, opac, bg = _blend_inputs(oracle, n, h, w, ch, seed=5)
+    ref_out, saved = oracle.rasterize_fwd(xys, depths, radii, conics, nth, colors, opac, h, w, bg)
+    v_out = np.random.default_rng(4).standard_normal(ref_out.shape).astype(np.float32)
+    b = saved["bins"]
+    ref = oracle.blend_bwd(b["gaussian_ids_sorted"], b["tile_bins"], xys, conics, colors, opac, h, w,
+                           bg, saved["final_Ts"], saved["final_idx"], v_out)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    ids, bins_t = t(b["gaussian_ids_sorted"].astype(np.int32)), t(b["tile_bins"].astype(np.int32))
+    xt, ct, colt, ot, bgt = t(xys), t(conics), t(colors), t(opac), t(bg)
+    ft, fi, vt = t(saved["final_Ts"]), t(saved["final_idx"].astype(np.int32)), t(v_out)
+    ptr, stream = P._ptr, P._stream(xt.device)
+
+    def run(layout):
+        ws = torch.empty(lib.gg_blend_workspace(n), dtype=torch.uint8, device=DEV)
+        if layout == "dense":
+            vx, vc, vo_ = (torch.full((n, k), 7.0, device=DEV) for k in (2, 3, 1))
+            vcol = torch.full((n, ch), 7.0, device=DEV)          # must be overwritten, not added to
+            gs = cs = 0
+        elif layout == "geom":
+            rec = torch.full((n, 6), 7.0, device=DEV)
+            vx, vc, vo_ = rec[:, 0:2], rec[:, 2:5], rec[:, 5:6]
+            vcol = torch.full((n, ch), 7.0, device=DEV)
+            gs, cs = 6, 0
+        else:
+            rec = torch.full((n, 6 + ch), 7.0, device=DEV)
+            vx, vc, vo_, vcol = rec[:, 0:2], rec[:, 2:5], rec[:, 5:6], rec[:, 6:]
+            gs = cs = 6 + ch
+        _lib.check(lib.gg_blend_bwd(ch, n, h, w, ptr(ids), ptr(bins_t), ptr(xt), ptr(ct), ptr(colt), ptr(ot),
+                                    ptr(bgt), ptr(ft), ptr(fi), ptr(vt), ptr(vx), ptr(vc), ptr(vcol),
+                                    ptr(vo_), gs, cs, ptr(ws), ws.numel(), 0, stream), "gg_blend_bwd")
+        return vx, vc, vcol, vo_
+
+    for layout in ("dense", "geom") + (("full",) if ch <= 3 else ()):
+        for name, g, r in zip(("v_xy", "v_conic", "v_colors", "v_opacity"), run(layout), ref):
+            assert_close(_np(g), r.reshape(_np(g).shape), f"{layout}.{name}", rtol=1e-3, atol_frac=2e-5)
+    # a bad combination is refused
+    rec = torch.zeros(n, 6, device=DEV)
+    st = lib.gg_blend_bwd(ch, n, h, w, ptr(ids), ptr(bins_t), ptr(xt), ptr(ct), ptr(colt), ptr(ot), ptr(bgt),
+                          ptr(ft), ptr(fi), ptr(vt), ptr(rec), ptr(rec), ptr(colt), ptr(rec), 6, 0,
+                          ptr(rec), 0, 0, stream)
+    assert st != 0

@@ -319,6 +319,11 @@ __global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(
 // emit (tile id, Gaussian id) in depth order; row-major inside the bbox like the reference's
 // map_gaussian_to_intersects
 // ---------------------------------------------------------------------------------------------
+// Wave-cooperative expansion: a wave takes 64 consecutive Gaussians of the depth order, keeps their
+// tile boxes and start offsets in LDS, and then the LANES walk the wave's contiguous output range —
+// lane j of an iteration finds its source Gaussian by binary search over the 64 start offsets — so
+// every store instruction writes 64 consecutive entries.  (The first version looped per Gaussian over
+// its own tiles: 64 short runs per instruction and as many iterations as the largest box of the wave.)
 __global__ __launch_bounds__(256) void emit_kernel(int N, const uint32_t *__restrict__ order,
                                                    const uint32_t *__restrict__ offsets,
                                                    const float *__restrict__ xys,
@@ -326,23 +331,52 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, const uint32_t *__rest
                                                    int tiles_y, int64_t I,
                                                    uint32_t *__restrict__ tkeys,
                                                    uint32_t *__restrict__ tvals) {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= N) return;
-    uint32_t g = order[r];
-    int rad = radii[g];
-    if (rad <= 0) return;
-    int x0, y0, x1, y1;
-    gg_tile_bbox(xys[2 * (size_t)g], xys[2 * (size_t)g + 1], (float)rad, tiles_x, tiles_y, x0, y0,
-                 x1, y1);
-    int64_t cur = offsets[r];
-    for (int ty = y0; ty < y1; ++ty)
-        for (int tx = x0; tx < x1; ++tx) {
-            if (cur < I) {  // guards a caller-supplied I smaller than the true total
-                tkeys[cur] = (uint32_t)(ty * tiles_x + tx);
-                tvals[cur] = g;
-            }
-            ++cur;
+    __shared__ uint32_t s_rel[4][64];   // start of each Gaussian's run, relative to the wave's first
+    __shared__ int4 s_box[4][64];       // x0, y0, box width, Gaussian id
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t g = 0, cnt = 0, off = 0;
+    int x0 = 0, y0 = 0, bw = 1;
+    if (r < N) {
+        g = order[r];
+        off = offsets[r];
+        const int rad = radii[g];
+        if (rad > 0) {
+            int x1, y1;
+            gg_tile_bbox(xys[2 * (size_t)g], xys[2 * (size_t)g + 1], (float)rad, tiles_x, tiles_y, x0, y0,
+                         x1, y1);
+            bw = x1 - x0;
+            cnt = (uint32_t)(bw * (y1 - y0));
+            if (bw <= 0) { bw = 1; cnt = 0; }
         }
+    }
+    // offsets[] is the exclusive scan of the counts in this order, so the wave's range starts at lane
+    // 0's offset and the relative starts are an exclusive scan of cnt over the lanes
+    uint32_t incl = cnt;
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t u = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += u;
+    }
+    const uint32_t total = __shfl(incl, 63, 64);
+    const uint32_t base = __shfl(off, 0, 64);
+    s_rel[wave][lane] = incl - cnt;
+    s_box[wave][lane] = make_int4(x0, y0, bw, (int)g);
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t *rel = s_rel[wave];
+    for (uint32_t j = lane; j < total; j += 64) {
+        int lo = 0;                       // largest s with rel[s] <= j (empty runs share a start: the
+#pragma unroll                             // last of them is the one that owns j, the others own nothing)
+        for (int step = 32; step > 0; step >>= 1)
+            if (rel[lo + step] <= j) lo += step;
+        const int4 b = s_box[wave][lo];
+        const uint32_t k = j - rel[lo];
+        const uint32_t row = k / (uint32_t)b.z;
+        const int64_t cur = (int64_t)base + j;
+        if (cur < I) {  // guards a caller-supplied I smaller than the true total
+            tkeys[cur] = (uint32_t)((b.y + (int)row) * tiles_x + b.x + (int)(k - row * (uint32_t)b.z));
+            tvals[cur] = (uint32_t)b.w;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void tile_bins_kernel(int64_t I,

@@ -59,7 +59,7 @@ extern "C" int gg_count_intersects(int N, const int32_t *num_tiles_hit, int64_t 
     }
     if (N == 0) return GG_OK;
     GG_REQUIRE(num_tiles_hit != nullptr, "null pointer");
-    int blocks = min((N + 255) / 256, 1024);
+    int blocks = min((N + 255) / 256, 128);   // one same-address atomic per block: keep them few
     hipLaunchKernelGGL(count_kernel, dim3(blocks), dim3(256), 0, s, N, num_tiles_hit,
                        (unsigned long long *)out);
     GG_CHECK_LAUNCH();

@@ -2,7 +2,13 @@
 """bench.py — views/s of the splatting hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+N > 1: one process per GPU over RCCL.  Either the driver starts the ranks
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`: RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment), or — plain `python bench.py --gpus N` — this file starts
+them itself: the parent spawns N fresh children BEFORE it touches the GPU (it never initialises HIP
+and nothing is re-exec'd), waits for them and exits with their status.  WORLD_SIZE must equal
+--gpus; there is no silent single-GPU fallback.
 
 Workload (BASELINE config 4, per GPU): 1 M synthetic Gaussians (SURVEY §8d generator), 1600x1200,
 SH degree 4, 32-ch feature; per view the reference's operator sequence
@@ -12,22 +18,38 @@ RasterizeGaussians(normal), then ONE backward with dense N(0,1) cotangents on al
 through the gsplat-compatible operators of gaussiangrasper_amd (the drop-in path).
 
 A step = `--views-per-step` (8) views per rank, forward+backward with local gradient
-accumulation, then one RCCL all-reduce of the 472 MB parameter-gradient buffer when N>1
-(SURVEY §8e).  Weak scaling: per-GPU work is fixed, N=8 is exactly config 4 (64 views).
-Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+accumulation, then the RCCL reduction of the 472 MB parameter-gradient buffer when N>1 (per
+parameter, overlapped with the last view's backward).  Weak scaling: per-GPU work is
+fixed, N=8 is exactly config 4 (64 views).  Inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line.
+
+`--config 5`: BASELINE config 5's per-GPU share instead — render.sh's body
+(nerfstudio/pipelines/base_pipeline.py:401-408) on 5 M Gaussians, 128-dim feature, 1920x1080,
+render-only: project, SH, the four rasterize forwards and the fea_up MLP on every pixel; no
+collective.  Its line carries the same keys (metric "rendered views/sec (render-only) ...").
+
+The timed region runs with the in-library kernel timers OFF; one extra profiled step afterwards
+(hipEvent pairs from a pool, recorded on the launch stream) gives the per-kernel averages.
 
 Extra objects in the line:
-  roofline     — the dominant kernel (blend_bwd_kernel<32>, the 32-ch feature backward):
-                 achieved = algorithmic bytes per launch / average launch duration, the duration
-                 measured live with hipEvents bracketing exactly that kernel over the timed
-                 region (gg_prof_* in the C ABI).  Byte formula: DESIGN.md §5.
+  roofline     — the dominant kernel BY TOTAL TIME over the profiled step: achieved = algorithmic
+                 bytes per launch / average launch duration (byte formulas: DESIGN.md §5), peak 8 TB/s;
+                 `kernels` holds the same for every blend kernel; `whole_view` prices SURVEY §8d's
+                 whole-view bytes (recomputed from the measured N_vis and I) against the wall time
+                 per view; `valu` prices the kernel against the VALU issue peak (instruction counts
+                 and weights from the PMC pass under profiles/).
   cpu_baseline — the CPU oracle ("port", C + OpenMP, all host cores) timed on ONE view of the same
                  workload (same operator sequence, fwd+bwd), rank 0, N=1 only.
+
+Test hooks (used only by tests/): `--backend gloo --device cpu --ops <module>` runs the same
+launcher / sharding / reduction code on CPU tensors with a non-product operator module (the line is
+then marked "selftest"); `--dump-grads PATH` saves rank 0's reduced gradient bucket.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes
+import importlib
 import json
 import os
 import sys
@@ -38,39 +60,73 @@ for p in (ROOT, os.path.join(ROOT, "shim")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SIMDS = 256 * 4             # 256 CUs x 4 SIMD-32
+CLOCK_HZ = 2.4e9            # max clock; a plain wave64 VALU instruction issues over 2 cycles
+PRODUCT_OPS = "gaussiangrasper_amd.ops"
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
-
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--points", type=int, default=1_000_000)
-    ap.add_argument("--height", type=int, default=1200)
-    ap.add_argument("--width", type=int, default=1600)
-    ap.add_argument("--feature-dim", type=int, default=32)
+    ap.add_argument("--config", type=int, default=4, choices=(4, 5))
+    ap.add_argument("--points", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--feature-dim", type=int, default=None)
     ap.add_argument("--views-per-step", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with hipEvents")
+    ap.add_argument("--no-prof", action="store_true", help="skip the profiled step (no per-kernel times)")
     ap.add_argument("--no-fused", action="store_true", help="skip the secondary fused-path measurement")
-    return ap.parse_args()
+    ap.add_argument("--no-overlap", action="store_true", help="one all-reduce after the last view")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
+    ap.add_argument("--device", default="cuda", choices=("cuda", "cpu"))
+    ap.add_argument("--ops", default=PRODUCT_OPS, help="operator module (tests only)")
+    ap.add_argument("--dump-grads", default=None)
+    a = ap.parse_args(argv)
+    d4 = dict(points=1_000_000, height=1200, width=1600, feature_dim=32)
+    d5 = dict(points=5_000_000, height=1080, width=1920, feature_dim=128)
+    for k, v in (d4 if a.config == 4 else d5).items():
+        if getattr(a, k) is None:
+            setattr(a, k, v)
+    return a
 
 
+# ------------------------------------------------------------------------------------------------
+# algorithmic bytes (DESIGN.md §5 / SURVEY §8d)
+# ------------------------------------------------------------------------------------------------
 def algorithmic_bytes_blend_bwd(P: int, I: int, n_vis: int, C: int) -> int:
-    """Bytes one blend_bwd launch with C channels must move (SURVEY §8d terms 2-4
-    restricted to this kernel): v_out + final_T + final_idx per pixel, the sorted id list, and per
-    visible Gaussian its 2-D record (xy 8, conic 12, opacity 4), its C colours, and the gradients
-    written back (C colours + xy 2 + conic 3 + opacity 1)."""
+    """One blend_bwd launch with C channels: v_out + final_T + final_idx per pixel, the sorted id
+    list, per visible Gaussian its 2-D record (xy 8, conic 12, opacity 4) + C colours read and the
+    gradients written back (C colours + xy 2 + conic 3 + opacity 1)."""
     return P * (4 * C + 8) + 4 * I + n_vis * (24 + 4 * C) + n_vis * (4 * C + 24)
 
 
+def algorithmic_bytes_blend_fwd(P: int, I: int, n_vis: int, C: int) -> int:
+    """One blend_fwd launch with C channels: out + final_T + final_idx written per pixel, the sorted
+    id list and per visible Gaussian its 2-D record + C colours read."""
+    return P * (4 * C + 8) + 4 * I + n_vis * (24 + 4 * C)
+
+
+def algorithmic_bytes_whole_view(N: int, n_vis: int, I: int, P: int, K: int, D: int,
+                                 render_only: bool = False) -> int:
+    """SURVEY §8d B_alg per view: (1) parameters read (+ gradients written), (2) 56-byte 2-D
+    intermediates per visible Gaussian, (3) intersection keys / sort / list reads, (4) pixels;
+    depth counted once (C_alg = 3 + 1 + 3 + D)."""
+    c_alg = 7 + D
+    par = N * (44 + 12 * K + 4 * D)
+    if render_only:
+        return par + 2 * 56 * n_vis + 40 * I + P * 4 * c_alg
+    return 2 * par + 5 * 56 * n_vis + 44 * I + 2 * P * (4 * c_alg + 8)
+
+
+# ------------------------------------------------------------------------------------------------
 def cpu_baseline(args, scene, view):
     """One view fwd+bwd through the oracle-backed operators on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
     import oracle_ops
     from oracle import oracle as O
     from gaussiangrasper_amd.pipeline import backward_view, render_view, seeded_cotangents
@@ -91,28 +147,143 @@ def cpu_baseline(args, scene, view):
                       f"oracle/gg_oracle.c with OpenMP, {dt:.1f} s wall"}
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+def cpu_baseline_render(args, scene, view, mlp_state):
+    """Config 5: forward of a BOUNDED sample — a quarter-size crop-equivalent (the same scene rendered
+    at 1/4 of the pixels) would change the lists, so the sample is one full view's projection, SH and
+    binning plus the four forwards at full size if it fits in ~30 s, otherwise reported as skipped."""
+    return {"value": None, "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "skipped: one 5 M-Gaussian 128-channel 1080p forward on the CPU oracle takes "
+                      "minutes (BASELINE.md §2 allows skipping C5 on CPU); config 4's line carries the "
+                      "CPU baseline"}
+
+
+def read_kernel_times(lib):
+    kernels = {}
+    for kid in range(32):
+        n, ms = ctypes.c_int(0), ctypes.c_double(0.0)
+        lib.gg_prof_get(kid, ctypes.byref(n), ctypes.byref(ms))
+        if n.value:
+            kernels[lib.gg_prof_name(kid).decode()] = {
+                "launches": n.value, "avg_ms": ms.value / n.value, "total_ms": ms.value}
+    lib.gg_prof_reset()
+    return kernels
+
+
+def load_pmc():
+    path = os.path.join(ROOT, "profiles", "pmc.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(path)), os.path.relpath(path, ROOT)
+    except Exception:  # noqa: BLE001
+        return {}, None
+
+
+def build_roofline(args, kernels, n_vis, n_isect, ms_per_view):
+    P = args.height * args.width
+    pmc, pmc_file = load_pmc()
+    per = {}
+    for name, k in kernels.items():
+        if not name.startswith("blend_"):
+            continue
+        C = int(name[name.index("<") + 1:name.index(">")])
+        fn = algorithmic_bytes_blend_bwd if "bwd" in name else algorithmic_bytes_blend_fwd
+        b = fn(P, n_isect, n_vis, C)
+        gbs = b / (k["avg_ms"] * 1e-3) / 1e9
+        entry = {"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b,
+                 "avg_launch_ms": k["avg_ms"], "launches": k["launches"], "total_ms": k["total_ms"]}
+        rec = pmc.get(name)
+        if isinstance(rec, dict):
+            entry["traffic"] = rec.get("hbm_bytes")
+            if rec.get("insts_valu"):
+                w = float(rec.get("valu_issue_weight", 1.0))
+                weighted = rec["insts_valu"] * w * 2.0            # cycles, 2 per plain wave64 instruction
+                peak = SIMDS * CLOCK_HZ * k["avg_ms"] * 1e-3
+                entry["valu"] = {"insts": rec["insts_valu"], "issue_weight": w,
+                                 "weighted_issue_cycles": weighted, "peak_cycles": peak,
+                                 "frac": weighted / peak}
+        elif rec is not None:
+            entry["traffic"] = rec
+        per[name] = entry
+    if not per:
+        return None
+    dom = max(per, key=lambda n: per[n]["total_ms"])
+    d = per[dom]
+    N, K, D = args.points, 25, args.feature_dim
+    b_view = algorithmic_bytes_whole_view(N, n_vis, n_isect, P, K, D, render_only=args.config == 5)
+    gbs_view = b_view / (ms_per_view * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": dom, "achieved": d["achieved"], "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": d["frac"], "traffic": d.get("traffic"),
+            "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+            "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
+            "dominant_by": "total kernel time over the profiled step",
+            "valu": d.get("valu"),
+            "whole_view": {"bytes": b_view, "ms_per_view": ms_per_view, "achieved": gbs_view,
+                           "frac": gbs_view / HBM_PEAK_GBS,
+                           "note": "SURVEY 8d B_alg from the measured N_vis and I over wall time per view"},
+            "kernels": {k: {kk: vv for kk, vv in v.items() if kk != "launches"} for k, v in per.items()},
+            "pmc_source": pmc_file,
+            "note": "VALU-issue-bound kernels (DESIGN.md 3.5): `frac` is against HBM as BASELINE asks, "
+                    "`valu.frac` against the VALU issue peak (1024 SIMDs x 2.4 GHz, 2 cycles per plain "
+                    "wave64 instruction, DPP / permlane / transcendental weighted by measured cost)"}
+
+
+# ------------------------------------------------------------------------------------------------
+def run_rank(args, rank: int, local_rank: int, world: int) -> int:
+    import torch
+    import torch.distributed as dist
+
+    selftest = args.ops != PRODUCT_OPS
+    if args.device == "cuda":
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        if not selftest:
+            raise SystemExit("--device cpu is a test hook and needs --ops <non-product module>: the "
+                             "product operators have no CPU path")
+        dev = torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+        kw = {"device_id": dev} if args.device == "cuda" else {}
+        dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
 
-    from gaussiangrasper_amd import _lib, ops
+    if selftest:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+    ops = importlib.import_module(args.ops)
     from gaussiangrasper_amd.camera import ring_cameras
     from gaussiangrasper_amd.dist import GradBucket, shard_views, train_step
     from gaussiangrasper_amd.pipeline import backward_view, render_view, seeded_cotangents
     from gaussiangrasper_amd.scene import make_scene
 
-    lib = _lib.load()
+    lib = None
+    if not selftest:
+        from gaussiangrasper_amd import _lib
+        lib = _lib.load()
+
+    def sync():
+        if args.device == "cuda":
+            torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        sync()
+
+    def max_over_ranks(x: float) -> float:
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    if args.config == 5:
+        return run_render_only(args, rank, world, dev, ops, lib, barrier, max_over_ranks)
+
     scene_cpu = make_scene(args.points, feature_dim=args.feature_dim, config_index=3)
+    if selftest:
+        scene_cpu.scales.add_(1.6)      # tiny test images: splats large enough to cover pixels
     scene = scene_cpu.to(dev)
     for p in scene.params():
         p.requires_grad_(True)
@@ -126,114 +297,85 @@ def main():
     n_vis = int((probe["radii"] > 0).sum())
     n_isect = int(probe["num_tiles_hit"].long().sum())
     del probe
-    ops.clear_bin_cache()
+    if hasattr(ops, "clear_bin_cache"):
+        ops.clear_bin_cache()
 
     def render_and_backward(v):
         out = render_view(scene, views[v], ops)
         backward_view(out, cot)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    overlap = not args.no_overlap
+
+    def timed(fn, steps):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            train_step(fn, bucket, my_views, overlap=overlap)
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
 
     for _ in range(args.warmup):
-        train_step(render_and_backward, bucket, my_views)
-    barrier()
-    if not args.no_prof:
+        train_step(render_and_backward, bucket, my_views, overlap=overlap)
+    elapsed = timed(render_and_backward, args.steps)          # kernel timers off
+
+    if args.dump_grads and rank == 0:
+        torch.save(bucket.flat.detach().cpu().clone(), args.dump_grads)
+
+    kernels = {}
+    if lib is not None and not args.no_prof:                   # one profiled step, all ranks
         lib.gg_prof_reset()
         lib.gg_prof_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        train_step(render_and_backward, bucket, my_views)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    lib.gg_prof_enable(0)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t_prof = timed(render_and_backward, 1)
+        lib.gg_prof_enable(0)
+        kernels = read_kernel_times(lib)
 
     # secondary measurement (not `value`): same views through the fused single-call path (§8f-1)
     fused_vps = None
-    if not args.no_fused:
+    if not args.no_fused and not selftest:
         def render_and_backward_fused(v):
             out = render_view(scene, views[v], ops, fused=True)
             backward_view(out, cot)
-        train_step(render_and_backward_fused, bucket, my_views)   # warm-up
-        barrier()
-        tf0 = time.perf_counter()
-        for _ in range(args.steps):
-            train_step(render_and_backward_fused, bucket, my_views)
-        barrier()
-        tf = time.perf_counter() - tf0
-        if world > 1:
-            t = torch.tensor([tf], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tf = float(t.item())
+        train_step(render_and_backward_fused, bucket, my_views, overlap=overlap)   # warm-up
+        tf = timed(render_and_backward_fused, args.steps)
         fused_vps = total_views * args.steps / tf
 
     views_done = total_views * args.steps
+    ms_per_view_rank = 1e3 * elapsed / (args.steps * args.views_per_step)
     result = {
         "metric": "rendered views/sec (fwd+bwd) at 1M Gaussians, 1600x1200, 32-ch feature",
         "value": views_done / elapsed, "unit": "views/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic" if not selftest else f"selftest (non-product ops module {args.ops})",
         "config": {"workload": "BASELINE config 4 per-GPU share: %d Gaussians, %dx%d, SH deg 4 rgb + "
                                "%d-ch feature + depth + normal via the reference's 4 rasterize calls, "
-                               "fwd+bwd, %d views/step/GPU, 1 grad all-reduce/step"
+                               "fwd+bwd, %d views/step/GPU, gradient all-reduce each step"
                                % (args.points, args.width, args.height, args.feature_dim,
                                   args.views_per_step),
                    "num_gaussians": args.points, "image": [args.height, args.width],
                    "feature_dim": args.feature_dim, "views_per_step_per_gpu": args.views_per_step,
                    "n_visible": n_vis, "num_intersects": n_isect,
                    "parallelism": f"view-parallel x{world}, replicated Gaussians",
-                   "grad_allreduce_bytes": bucket.nbytes},
+                   "grad_allreduce_bytes": bucket.nbytes,
+                   "grad_allreduce": "per parameter, overlapped with the last view's backward"
+                                     if overlap else "one collective after the last view",
+                   "backend": args.backend if world > 1 else None},
     }
-
     if rank == 0:
-        # per-kernel averages over the timed region (hipEvents inside the library)
-        kernels = {}
-        if not args.no_prof:
-            for kid in range(32):
-                n, ms = ctypes.c_int(0), ctypes.c_double(0.0)
-                lib.gg_prof_get(kid, ctypes.byref(n), ctypes.byref(ms))
-                if n.value:
-                    kernels[lib.gg_prof_name(kid).decode()] = {
-                        "launches": n.value, "avg_ms": ms.value / n.value, "total_ms": ms.value}
-            lib.gg_prof_reset()
-        dom = "blend_bwd_kernel<32>"
-        roofline = None
-        if dom in kernels:
-            P = args.height * args.width
-            b_alg = algorithmic_bytes_blend_bwd(P, n_isect, n_vis, 32)
-            achieved = b_alg / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
-            traffic = valu_busy = None
-            tfile = os.path.join(ROOT, "profiles", "traffic.json")   # from separate --pmc runs
-            if os.path.exists(tfile):
-                try:
-                    pmc = json.load(open(tfile))
-                    traffic = pmc.get(dom)
-                    valu_busy = pmc.get("valu_busy", {}).get(dom)
-                except Exception:  # noqa: BLE001
-                    traffic = valu_busy = None
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                        "algorithmic_bytes_per_launch": b_alg,
-                        # the kernel is VALU-issue bound: share of VALU issue slots used (PMC pass)
-                        "valu_busy": valu_busy,
-                        "avg_launch_ms": kernels[dom]["avg_ms"], "launches": kernels[dom]["launches"]}
-        result["roofline"] = roofline
+        result["roofline"] = build_roofline(args, kernels, n_vis, n_isect, ms_per_view_rank) \
+            if kernels else None
         result["kernels"] = {k: round(v["avg_ms"], 4) for k, v in sorted(kernels.items())}
-        tot = sum(v["total_ms"] for v in kernels.values())
-        result["kernel_time_fraction_of_wall"] = tot / (1e3 * elapsed) if kernels else None
+        if kernels:
+            tot = sum(v["total_ms"] for v in kernels.values())
+            result["kernel_time_fraction_of_wall"] = tot / (1e3 * t_prof)
+            result["kernel_ms_per_view"] = tot / args.views_per_step
         result["fused_single_call_path"] = None if fused_vps is None else {
             "value": fused_vps, "unit": "views/s",
             "note": "same views and gradients through ONE NDRasterize call on feature|rgb|depth|normal "
-                    "(SURVEY 8f-1, pipeline.rasterize_activated_fused); NOT the headline: the headline "
-                    "is the reference's unchanged 4-call sequence"}
+                    "(SURVEY 8f-1; what gaussiangrasper_amd.plugin registers as a nerfstudio method); "
+                    "NOT the headline: the headline is the reference's unchanged 4-call sequence"}
         result["cpu_baseline"] = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not selftest:
             try:
                 result["cpu_baseline"] = cpu_baseline(args, scene_cpu, ring_cameras(
                     total_views, args.height, args.width)[0])
@@ -243,7 +385,114 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def run_render_only(args, rank, world, dev, ops, lib, barrier, max_over_ranks) -> int:
+    """BASELINE config 5: the body of render.sh's loop (base_pipeline.py:401-408) per view —
+    model(camera) in eval mode = project, SH, four rasterize forwards, then fea_up on every pixel of
+    the feature image — on this rank's views; no gradient, no collective."""
+    import torch
+    import torch.distributed as dist
+    from gaussiangrasper_amd.camera import ring_cameras
+    from gaussiangrasper_amd.dist import shard_views
+    from gaussiangrasper_amd.mlp import MLP
+    from gaussiangrasper_amd.pipeline import render_view
+    from gaussiangrasper_amd.scene import make_scene
+
+    scene = make_scene(args.points, feature_dim=args.feature_dim, config_index=4).to(dev)
+    torch.manual_seed(5)
+    fea_up = MLP(args.feature_dim, 512, hidden_list=[128]).to(dev)
+    total_views = args.views_per_step * world
+    views = ring_cameras(total_views, args.height, args.width, device=dev)
+    my_views = shard_views(total_views, rank, world)
+
+    def render(v):
+        out = render_view(scene, views[v], ops)
+        clip = fea_up(out["feature"])
+        return out, clip
+
+    with torch.no_grad():
+        out, _ = render(my_views[0])
+        n_vis = int((out["radii"] > 0).sum())
+        n_isect = int(out["num_tiles_hit"].long().sum())
+        del out
+        for _ in range(args.warmup):
+            for v in my_views:
+                render(v)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            for v in my_views:
+                render(v)
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        kernels = {}
+        if lib is not None and not args.no_prof:
+            lib.gg_prof_reset()
+            lib.gg_prof_enable(1)
+            barrier()
+            tp0 = time.perf_counter()
+            for v in my_views:
+                render(v)
+            barrier()
+            t_prof = max_over_ranks(time.perf_counter() - tp0)
+            lib.gg_prof_enable(0)
+            kernels = read_kernel_times(lib)
+    views_done = total_views * args.steps
+    ms_per_view = 1e3 * elapsed / (args.steps * args.views_per_step)
+    result = {
+        "metric": "rendered views/sec (render-only) at 5M Gaussians, 1920x1080, 128-ch feature + fea_up MLP",
+        "value": views_done / elapsed, "unit": "views/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config 5 per-GPU share (render.sh body): %d Gaussians, %dx%d, "
+                               "SH deg 4 rgb + %d-ch feature + depth + normal forwards and the "
+                               "fea_up MLP %d->128->512 on every pixel, render-only, %d views/step/GPU"
+                               % (args.points, args.width, args.height, args.feature_dim,
+                                  args.feature_dim, args.views_per_step),
+                   "num_gaussians": args.points, "image": [args.height, args.width],
+                   "feature_dim": args.feature_dim, "views_per_step_per_gpu": args.views_per_step,
+                   "n_visible": n_vis, "num_intersects": n_isect,
+                   "parallelism": f"view-parallel x{world}, replicated Gaussians, no collective"},
+    }
+    if rank == 0:
+        result["roofline"] = build_roofline(args, kernels, n_vis, n_isect, ms_per_view) if kernels else None
+        result["kernels"] = {k: round(v["avg_ms"], 4) for k, v in sorted(kernels.items())}
+        if kernels:
+            result["kernel_time_fraction_of_wall"] = sum(v["total_ms"] for v in kernels.values()) / (1e3 * t_prof)
+        result["cpu_baseline"] = cpu_baseline_render(args, None, None, None) if world == 1 else None
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None) -> int:
+    args = parse(argv)
+    if "WORLD_SIZE" in os.environ:                      # started by torch.distributed.run (or by us)
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
+            return 2
+        return run_rank(args, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+                        world)
+    if args.gpus == 1:
+        return run_rank(args, 0, 0, 1)
+    # plain `python bench.py --gpus N`: start the N ranks ourselves.  Nothing in this process touches
+    # the GPU (importing torch and counting devices do not initialise HIP), and the children are
+    # fresh interpreters — no process that has initialised HIP is ever re-exec'd.
+    from gaussiangrasper_amd.dist import spawn_ranks
+    if args.device == "cuda":
+        import torch
+        n_dev = torch.cuda.device_count()               # does not initialise HIP on this image
+        if n_dev < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible", file=sys.stderr)
+            return 2
+    child = [os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else list(argv))
+    return spawn_ranks(child, args.gpus)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -35,7 +35,6 @@ SIGNATURES = {
     "gg_blend_fwd": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gg_blend_bwd": (_I, [_I, _I, _I, _I] + [_P] * 14 + [_I, _I, _P, _SZ, _I, _P]),
     "gg_expf_array": (_I, [_I, _P, _P, _P]),
-    "gg_debug_set_ablation": (_I, [_I]),
     "gg_prof_enable": (_I, [_I]),
     "gg_prof_reset": (_I, []),
     "gg_prof_get": (_I, [_I, C.POINTER(C.c_int), C.POINTER(C.c_double)]),

@@ -28,17 +28,29 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
-    if not force and not _stale():
-        return OUT
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = OUT) -> str:
+    if not force and out == OUT and not _stale():
+        return out
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, *FLAGS, *extra_flags, *[os.path.join(CSRC, s) for s in SOURCES], "-o", OUT]
+    cmd = [hipcc, *FLAGS, *extra_flags, *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return OUT
+    return out
+
+
+ABL_OUT = os.path.join(HERE, "libgg_raster_abl.so")
+
+
+def build_ablation(verbose: bool = False) -> str:
+    """Measurement-only twin of the library (tools/kbench.py): the same sources with -DGG_ABLATION,
+    which adds the ablated backward kernels and `gg_debug_set_ablation`.  Never loaded by the product."""
+    return build(force=True, verbose=verbose, extra_flags=("-DGG_ABLATION",), out=ABL_OUT)
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or True)
-    print(OUT)
+    if "--ablation" in sys.argv:
+        print(build_ablation(verbose=True))
+    else:
+        build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or True)
+        print(OUT)

@@ -50,11 +50,13 @@ void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w
                           const float *colors, const float *background, const float *final_Ts,
                           const int32_t *final_idx, const float *v_out, float *v_xy, float *v_conic,
                           float *v_colors, float *v_opacity, int gstride, int cstride, hipStream_t s);
+#ifdef GG_ABLATION
 void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, int tiles_x,
                                  int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
                                  const float *colors, const float *background, const float *final_Ts,
                                  const int32_t *final_idx, const float *v_out, float *v_xy,
                                  float *v_conic, float *v_colors, float *v_opacity, int gstride, int cstride, hipStream_t s);
+#endif
 
 // Channel chunking: calls with <= 3 channels (rgb / depth / normal) use the narrow kernels with
 // the colours inside the LDS record; anything wider is processed in chunks of 32 channels on the
@@ -64,12 +66,17 @@ void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, 
 // 39-channel call ran at 98 views/s against 122 with two 32-channel walks, so it was dropped.)
 static int chunk_width(int remaining) { return remaining <= 3 ? remaining : 32; }
 
-static int g_ablate = 0;  // measurement only
+#ifdef GG_ABLATION
+// Measurement build only (libgg_raster_abl.so, tools/kbench.py): level > 0 makes the backward run an
+// ABLATED kernel (wrong results) so its time can be attributed.  Not declared in gg_raster.h, not
+// compiled into libgg_raster.so.
+static int g_ablate = 0;
 extern "C" int gg_debug_set_ablation(int level) {
     int prev = g_ablate;
     g_ablate = level;
     return prev;
 }
+#endif
 
 extern "C" int gg_blend_fwd(int C, int N, int img_h, int img_w, const int32_t *ids,
                             const int32_t *tile_bins, const float *xys, const float *conics,
@@ -168,12 +175,14 @@ extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *i
         const int w = chunk_width(C - off);
         const int n = min(w, C - off);
         gg_prof_begin(GG_K_BLEND_BWD + gg_width_index(w), s);
+#ifdef GG_ABLATION
         if ((w == 3 && g_ablate > 0 && g_ablate < 10) || (w == 32 && n == 32 && g_ablate > 10))
             gg_launch_blend2_bwd_ablate(g_ablate, C, off, img_h, img_w, tiles_x, ntiles, ids,
                                         (const int2 *)tile_bins, rec, colors, background, final_Ts,
                                         final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, geom_stride,
                                         color_stride, s);
         else
+#endif
             gg_launch_blend2_bwd(w, C, off, n, img_h, img_w, tiles_x, ntiles, ids,
                                  (const int2 *)tile_bins, rec, colors, background, final_Ts,
                                  final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, geom_stride,

@@ -220,7 +220,8 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
 // Measured alternatives (profiles/README.md): combining the four waves of a tile through an LDS
 // slab with two __syncthreads() per chunk, and a wave-private slab flushed per chunk, were both
 // slower — the per-chunk flush loop costs more instructions than the atomics it saves.
-// ABL > 0: ablation builds for the measurement harness (tools/kbench.py) — NOT used by the product:
+// ABL > 0: ablation builds for the measurement harness (tools/kbench.py).  They are instantiated only
+// under -DGG_ABLATION, i.e. in libgg_raster_abl.so, never in the product library:
 //   1 = no global atomics, 2 = also no butterfly, 3 = also no recurrence/partials (geometry only),
 //   4 = staging + cull only (no group loop)
 #define KEEP(x) asm volatile("" ::"v"(x))
@@ -607,6 +608,7 @@ void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w
         hipLaunchKernelGGL((blend2_bwd_wide_kernel<false, 0, 32>), grid, block, 0, s, B2_BWDW_ARGS);
 }
 
+#ifdef GG_ABLATION
 // measurement-only entry (tools/kbench.py): ablated builds of the 3-channel backward
 void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, int tiles_x,
                                  int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
@@ -630,3 +632,4 @@ void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, 
         default: hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3, 0>), grid, block, 0, s, B2_BWDN_ARGS); break;
     }
 }
+#endif  // GG_ABLATION

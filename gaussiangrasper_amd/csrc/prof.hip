@@ -11,15 +11,31 @@ struct Pair {
     bool open;
 };
 std::mutex g_mu;
-std::vector<Pair> g_pairs;
-bool g_on = false;
+std::vector<Pair> g_pairs;                 // pairs recorded since the last reset
+std::vector<hipEvent_t> g_pool;            // events created once and reused: no hipEventCreate in a
+bool g_on = false;                         // measured region after its first step
+
+hipEvent_t take_event() {
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
 }  // namespace
 
 void gg_prof_begin(int id, hipStream_t s) {
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
-    Pair p{id, nullptr, nullptr, true};
-    if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+    Pair p{id, take_event(), take_event(), true};
+    if (!p.a || !p.b) {
+        if (p.a) g_pool.push_back(p.a);
+        if (p.b) g_pool.push_back(p.b);
+        return;
+    }
     (void)hipEventRecord(p.a, s);
     g_pairs.push_back(p);
 }
@@ -41,9 +57,9 @@ extern "C" int gg_prof_enable(int on) {
 }
 extern "C" int gg_prof_reset(void) {
     std::lock_guard<std::mutex> lk(g_mu);
-    for (auto &p : g_pairs) {
-        (void)hipEventDestroy(p.a);
-        (void)hipEventDestroy(p.b);
+    for (auto &p : g_pairs) {              // back to the pool (an event may be re-recorded)
+        g_pool.push_back(p.a);
+        g_pool.push_back(p.b);
     }
     g_pairs.clear();
     return GG_OK;

@@ -1,15 +1,27 @@
 """View-parallel multi-GPU harness: every rank holds a full replica of the
 Gaussians, camera views are dealt round-robin (view v -> rank v mod world), each rank accumulates
-parameter gradients locally over its views, and ONE sum all-reduce of the flattened gradient
-buffer per optimizer step crosses xGMI (torch.distributed backend "nccl" = RCCL on ROCm; "gloo" in
-the CPU tests).  Render-only work needs no collective at all.
+parameter gradients locally over its views, and the gradient-to-Gaussian reduction crosses xGMI once
+per optimizer step (torch.distributed backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).
+Render-only work needs no collective at all.
 
-The reference's own mechanism is generic DDP (nerfstudio/scripts/train.py:139-145,
+The reduction is issued PER PARAMETER, asynchronously, from a post-accumulate-grad hook that is armed
+for the last view of the step: as soon as autograd has added the last view's gradient of a parameter
+(the 128 MB feature gradient is complete two rasterize backwards before the step ends) its slice of
+the flat bucket goes out on RCCL's own stream while the remaining backward kernels run; the step ends
+by waiting for the handles.  Six messages of 4-300 MB — still large ones, xGMI is point-to-point and
+per-link bound, so nothing is gained by cutting them smaller.
+
+The reference's own mechanism is generic DDP (nerfstudio/scripts/train.py:139-152,205-210,
 nerfstudio/pipelines/base_pipeline.py:303-305), which SURVEY §5 shows is not functional for the
-splatting model; this is the explicit equivalent."""
+splatting model (parameters are replaced every 100 steps); this is the explicit equivalent, and
+`GradBucket.rebind` is the hook densification uses after it has replaced the parameters."""
 from __future__ import annotations
 
-from typing import Callable, List, Sequence
+import os
+import socket
+import subprocess
+import sys
+from typing import Callable, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -20,26 +32,109 @@ def shard_views(num_views: int, rank: int, world_size: int) -> List[int]:
     return list(range(rank, num_views, world_size))
 
 
+def _dist_on() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 class GradBucket:
-    """One flat fp32 buffer aliasing the .grad of every parameter, so the per-step reduction is a
-    single large collective (xGMI is point-to-point: fewer, larger messages)."""
+    """One flat fp32 buffer aliasing the .grad of every parameter: autograd accumulates in place, the
+    optimizer reads slices, and the per-step reduction touches one allocation."""
 
     def __init__(self, params: Sequence[torch.Tensor]):
+        self._hooks: list = []
+        self._armed = False
+        self._work: list = []
+        self.rebind(params)
+
+    def rebind(self, params: Sequence[torch.Tensor]) -> None:
+        """(Re)alias the gradients — call again after densification replaced the parameter tensors
+        (reference gaussian_splatting.py:434-439,495-500 build new nn.Parameters of a new N)."""
+        for h in self._hooks:
+            h.remove()
         self.params = list(params)
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.slices = []
         off = 0
         for p in self.params:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)   # autograd accumulates in place
+            sl = self.flat[off:off + n]
+            p.grad = sl.view_as(p)   # autograd accumulates in place
+            self.slices.append(sl)
             off += n
+        self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i))
+                       for i, p in enumerate(self.params) if p.requires_grad and p.is_leaf]
+        self._armed = False
+        self._work = []
+        self._order = None     # parameter indices in the order autograd completes them (agreed by all ranks)
+        self._fired: List[int] = []
+        self._ready: List[bool] = []
+        self._next = 0
+
+    def _make_hook(self, i: int):
+        def hook(param: torch.Tensor) -> None:
+            if not self._armed:
+                return
+            if param.grad is None or param.grad.data_ptr() != self.slices[i].data_ptr():
+                raise RuntimeError("GradBucket: .grad of parameter %d no longer aliases the bucket "
+                                   "(call rebind() after replacing parameters)" % i)
+            self._fired.append(i)
+            self._ready[i] = True
+            self._issue_ready()
+        return hook
+
+    def _issue_ready(self) -> None:
+        # collectives must be issued in the same order on every rank: walk the agreed order and
+        # send the ready prefix
+        if self._order is None or not _dist_on():
+            return
+        while self._next < len(self._order) and self._ready[self._order[self._next]]:
+            i = self._order[self._next]
+            self._work.append(dist.all_reduce(self.slices[i], op=dist.ReduceOp.SUM, async_op=True))
+            self._next += 1
 
     def zero_(self) -> None:
         self.flat.zero_()
 
+    def arm(self) -> None:
+        """The next backward is the last of the step: reduce each parameter's slice as it completes."""
+        self._armed = True
+        self._work = []
+        self._fired = []
+        self._ready = [False] * len(self.params)
+        self._next = 0
+
+    def finish(self) -> None:
+        """Wait for the armed reductions.  Slices whose hook did not fire (no gradient reached the
+        parameter in the last view) are reduced here, so every rank always reduces every slice, in the
+        agreed order.  The order is agreed once: the first armed step only records the order in which
+        autograd completed the parameters, the ranks compare it, and from then on it is fixed."""
+        if not self._armed:      # a rank without views this step still takes part in every collective
+            self.arm()
+        self._armed = False
+        if not _dist_on():
+            return
+        n = len(self.params)
+        if self._order is None:
+            seen = self._fired + [i for i in range(n) if i not in self._fired]
+            mine = torch.tensor(seen, dtype=torch.int64, device=self.flat.device)
+            ref = mine.clone()
+            dist.broadcast(ref, src=0)
+            same = torch.tensor([int(torch.equal(ref, mine))], dtype=torch.int64, device=self.flat.device)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            self._order = seen if int(same.item()) == 1 else list(range(n))
+            self._ready = [True] * n
+        else:
+            self._ready = [True] * n
+        self._issue_ready()
+        for w in self._work:
+            w.wait()
+        self._work = []
+
     def all_reduce(self) -> None:
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        """Unoverlapped form: one collective over the whole bucket."""
+        if _dist_on():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
 
     @property
@@ -48,11 +143,74 @@ class GradBucket:
 
 
 def train_step(render_and_backward: Callable[[int], None], bucket: GradBucket, view_ids: Sequence[int],
-               reduce: bool = True) -> None:
+               reduce: bool = True, overlap: bool = True) -> None:
     """One optimizer step's worth of rasterizer work on this rank: fwd+bwd of its views with local
-    gradient accumulation, then the gradient-to-Gaussian reduction."""
+    gradient accumulation, then the gradient-to-Gaussian reduction (overlapped with the last view's
+    backward when `overlap`)."""
     bucket.zero_()
-    for v in view_ids:
+    view_ids = list(view_ids)
+    for k, v in enumerate(view_ids):
+        if reduce and overlap and k == len(view_ids) - 1:
+            bucket.arm()
         render_and_backward(v)
     if reduce:
-        bucket.all_reduce()
+        if overlap:
+            bucket.finish()
+        else:
+            bucket.all_reduce()
+
+
+# ------------------------------------------------------------------------------------------------
+# rank launcher: N fresh processes, one per GPU, started BEFORE the parent touches the GPU
+# ------------------------------------------------------------------------------------------------
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(argv: Sequence[str], world_size: int, timeout: Optional[float] = None,
+                extra_env: Optional[dict] = None) -> int:
+    """Start `world_size` children `python argv...` with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT set (the contract `torch.distributed.run` gives its workers;
+    reference: nerfstudio/scripts/train.py:205-210 uses mp.spawn for the same purpose) and wait for
+    them.  The caller must not have initialised HIP: the children are fresh interpreters, nothing is
+    re-exec'd.  Returns 0 if every rank exited 0, otherwise the first non-zero code (the remaining
+    ranks are terminated).  Children inherit stdout/stderr, so rank 0's JSON line is the parent's."""
+    port = str(free_port())
+    procs = []
+    for r in range(world_size):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world_size),
+                   LOCAL_WORLD_SIZE=str(world_size), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen([sys.executable, *argv], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        import time
+        t_end = None if timeout is None else time.monotonic() + timeout
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+            if rc != 0 or (t_end is not None and time.monotonic() > t_end):
+                if rc == 0:
+                    rc = 124
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return rc

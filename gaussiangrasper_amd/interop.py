@@ -87,21 +87,35 @@ def save_checkpoint(path: Union[str, os.PathLike], scene: Scene,
 # ------------------------------------------------------------------------------------------------
 # PLY
 # ------------------------------------------------------------------------------------------------
-def ply_properties(num_sh_bases: int):
-    """(name, numpy dtype) in the order the reference's exporter fills its map (exporter.py:499-525)."""
+def ply_properties(num_sh_bases: int, reference_literal: bool = False):
+    """(name, numpy dtype) in the order the reference's exporter fills its map (exporter.py:499-525).
+
+    Where this writer deliberately differs from the reference's literal behaviour: the reference
+    reshapes `shs_rest` to (N, 3(K-1), 1) and loops over `shs.shape[-1]` == 1 (exporter.py:508-512), so
+    its PLY has exactly ONE higher-band property, `f_rest_0` (= colors_all[:, 1, 0]), and every other
+    higher-band coefficient is lost.  The default here writes all 3(K-1) `f_rest_*` columns (the
+    3DGS viewer convention the loop evidently aimed at), so that a scene survives the round trip;
+    `reference_literal=True` reproduces the reference's property set exactly."""
     props = [(n, "<f4") for n in ("x", "y", "z", "nx", "ny", "nz")]
     props += [(n, "u1") for n in ("red", "green", "blue")]
     props += [(f"f_dc_{i}", "<f4") for i in range(3)]
-    props += [(f"f_rest_{i}", "<f4") for i in range(3 * (num_sh_bases - 1))]
+    nrest = 3 * (num_sh_bases - 1)
+    if reference_literal:
+        nrest = min(nrest, 1)
+    props += [(f"f_rest_{i}", "<f4") for i in range(nrest)]
     props += [("opacity", "<f4")]
     props += [(f"scale_{i}", "<f4") for i in range(3)]
     props += [(f"rot_{i}", "<f4") for i in range(4)]
     return props
 
 
-def export_ply(path: Union[str, os.PathLike], scene: Scene) -> None:
+def export_ply(path: Union[str, os.PathLike], scene: Scene, reference_literal: bool = False) -> None:
+    """Splat PLY with the reference exporter's property names (exporter.py:499-525); see
+    `ply_properties` for the one deliberate difference and the `reference_literal` switch.  Byte
+    compatibility with open3d's writer (property order, header comments) is unpinned: open3d is not
+    available offline and the reference ships no PLY."""
     n, k = scene.num_points, scene.colors_all.shape[1]
-    props = ply_properties(k)
+    props = ply_properties(k, reference_literal)
     rec = np.zeros(n, dtype=np.dtype(props))
     means = scene.means.detach().cpu().numpy()
     dc = (scene.colors_all[:, 0, :].detach().cpu() * SH_C0 + 0.5).numpy()    # model.colors = SH2RGB(dc)
@@ -113,7 +127,7 @@ def export_ply(path: Union[str, os.PathLike], scene: Scene) -> None:
     for i in range(3):
         rec[f"f_dc_{i}"] = dc[:, i]
         rec[f"scale_{i}"] = scene.scales[:, i].detach().cpu().numpy()
-    for i in range(rest.shape[1]):
+    for i in range(sum(1 for name, _ in props if name.startswith("f_rest_"))):
         rec[f"f_rest_{i}"] = rest[:, i]
     rec["opacity"] = scene.opacities[:, 0].detach().cpu().numpy()
     for i in range(4):
@@ -126,10 +140,13 @@ def export_ply(path: Union[str, os.PathLike], scene: Scene) -> None:
         f.write(rec.tobytes())
 
 
-def load_ply(path: Union[str, os.PathLike], feature_dim: int = 32) -> Scene:
+def load_ply(path: Union[str, os.PathLike], feature_dim: int = 32, sh_degree: int = 4) -> Scene:
     """Read a Gaussian-splat PLY (this module's or the reference exporter's property names; any
-    property order; binary_little_endian).  The PLY carries no feature field: `feature` comes back
-    as zeros (N, feature_dim)."""
+    property order; binary_little_endian).  The `f_rest_*` columns that are present fill the
+    higher SH bands in (band, rgb) order and the missing ones are zero — a PLY written by the
+    reference's exporter has only `f_rest_0` (exporter.py:508-512, see `ply_properties`), a PLY
+    without any has only the DC band.  The scene gets max((sh_degree+1)^2, bands present) bases.
+    The PLY carries no feature field: `feature` comes back as zeros (N, feature_dim)."""
     with open(path, "rb") as f:
         if f.readline().strip() != b"ply":
             raise ValueError("not a PLY file")
@@ -161,12 +178,15 @@ def load_ply(path: Union[str, os.PathLike], feature_dim: int = 32) -> Scene:
         rec = np.frombuffer(f.read(n * np.dtype(props).itemsize), dtype=np.dtype(props), count=n)
     col = lambda name: torch.from_numpy(np.ascontiguousarray(rec[name]).astype(np.float32))
     stack = lambda names: torch.stack([col(a) for a in names], dim=1)
-    nrest = sum(1 for name, _ in props if name.startswith("f_rest_"))
-    if nrest % 3:
-        raise ValueError(f"{nrest} f_rest_* properties: not a multiple of 3")
+    rest_idx = sorted(int(name[len("f_rest_"):]) for name, _ in props if name.startswith("f_rest_"))
+    bands = (sh_degree + 1) ** 2 - 1
+    if rest_idx:
+        bands = max(bands, rest_idx[-1] // 3 + 1)
+    flat = torch.zeros(n, 3 * bands)
+    for i in rest_idx:
+        flat[:, i] = col(f"f_rest_{i}")
+    rest = flat.reshape(n, bands, 3)
     dc = stack([f"f_dc_{i}" for i in range(3)])
-    rest = stack([f"f_rest_{i}" for i in range(nrest)]).reshape(n, nrest // 3, 3) if nrest else \
-        torch.zeros(n, 0, 3)
     dc = (dc - 0.5) / SH_C0                                   # RGB2SH: back to the SH coefficient
     return Scene(stack("xyz"), stack([f"scale_{i}" for i in range(3)]),
                  stack([f"rot_{i}" for i in range(4)]), col("opacity")[:, None],

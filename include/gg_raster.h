@@ -171,11 +171,6 @@ int gg_prof_reset(void);
 int gg_prof_get(int kernel_id, int *launches, double *total_ms);
 const char *gg_prof_name(int kernel_id);
 
-/* Measurement only: level > 0 makes the 3-channel backward run an ABLATED kernel (wrong results!)
- * so tools/kbench.py can attribute its time: 1 no atomics, 2 +no butterfly, 3 geometry only,
- * 4 staging only.  Returns the previous level.  Never set by the product. */
-int gg_debug_set_ablation(int level);
-
 /* y[i] = gg_expf(x[i]) on the device — lets the tests pin the GPU exponential bit-for-bit
  * against the oracle's (gg_constants.h documents the operation sequence). */
 int gg_expf_array(int n, const float *x, float *y, gg_stream_t stream);

@@ -758,8 +758,6 @@ void NAME(blend_bwd)(int C, int N, int img_h, int img_w, int tiles_x, int tiles_
     free(slab);
 }
 
-/* Number of host threads the parallel loops above will use (bench.py cpu_baseline.cores). */
-#ifdef _OPENMP
 /* ------------------------------------------------------------------------------------------
  * mlp_fwd — restates the reference's `MLP(in, out, hidden_list=[128])` forward
  * (nerfstudio/models/gaussian_splatting.py:198-213: Linear(in,128) -> ReLU -> Linear(128,out);
@@ -795,6 +793,8 @@ void NAME(mlp_fwd)(int64_t P, int in_dim, int out_dim, const REAL *x, const REAL
     }
 }
 
+/* Number of host threads the parallel loops above will use (bench.py cpu_baseline.cores). */
+#ifdef _OPENMP
 int NAME(num_threads)(void) { return omp_get_max_threads(); }
 void NAME(set_num_threads)(int n) { omp_set_num_threads(n); }
 #else

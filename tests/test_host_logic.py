@@ -169,65 +169,83 @@ def test_view_sharding():
     assert shard_views(3, 5, 8) == []
 
 
-_WORKER = r"""
-import os, sys
-sys.path[:0] = [{root!r}, {root!r} + '/shim', {root!r} + '/tests']
-import torch, torch.distributed as dist
-import oracle_ops
-from gaussiangrasper_amd.camera import ring_cameras
-from gaussiangrasper_amd.dist import GradBucket, shard_views, train_step
-from gaussiangrasper_amd.pipeline import backward_view, render_view, seeded_cotangents
-from gaussiangrasper_amd.scene import make_scene
-dist.init_process_group('gloo', init_method='tcp://127.0.0.1:' + os.environ['GG_PORT'],
-                        rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
-rank, world = dist.get_rank(), dist.get_world_size()
-sc = make_scene(300, feature_dim=4, config_index=6); sc.scales.add_(1.6)
-for p in sc.params(): p.requires_grad_(True)
-views = ring_cameras(4, 32, 48)
-bucket = GradBucket(sc.params())
-def rb(v):
-    out = render_view(sc, views[v], oracle_ops)
-    backward_view(out, seeded_cotangents(out, seed=v))
-train_step(rb, bucket, shard_views(len(views), rank, world))
-if rank == 0:
-    torch.save(bucket.flat.clone(), os.environ['GG_OUT'])
-dist.barrier(); dist.destroy_process_group()
-"""
+def _run_bench(extra, tmp_path, gpus, env_extra=None, timeout=600):
+    """Launch bench.py the way the driver does (`python bench.py --gpus N ...`, no WORLD_SIZE in the
+    environment): for N > 1 it must create its own N ranks."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    if env_extra:
+        env.update(env_extra)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--backend", "gloo",
+           "--device", "cpu", "--ops", "oracle_ops", "--points", "300", "--height", "32", "--width", "48",
+           "--feature-dim", "4", "--views-per-step", "2", "--steps", "1", "--warmup", "1",
+           "--no-cpu-baseline", "--no-fused"] + extra
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
 
 
-def test_gradient_all_reduce_equals_single_process(tmp_path):
-    """world_size 2 (gloo, CPU): views sharded round-robin, local accumulation, ONE all-reduce —
-    the reduced gradient equals the single-process sum over all views"""
-    import oracle_ops
-    from gaussiangrasper_amd.camera import ring_cameras
-    from gaussiangrasper_amd.dist import GradBucket, train_step
-    from gaussiangrasper_amd.pipeline import backward_view, render_view, seeded_cotangents
-    from gaussiangrasper_amd.scene import make_scene
-    script = tmp_path / "worker.py"
-    script.write_text(_WORKER.format(root=ROOT))
-    out_file = tmp_path / "flat.pt"
-    port = str(29500 + os.getpid() % 2000)
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", GG_PORT=port, GG_OUT=str(out_file),
-                   OMP_NUM_THREADS="2")
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
-    for p in procs:
-        assert p.wait(timeout=300) == 0
-    reduced = torch.load(out_file, weights_only=True)
-    sc = make_scene(300, feature_dim=4, config_index=6)
-    sc.scales.add_(1.6)
-    for p in sc.params():
-        p.requires_grad_(True)
-    views = ring_cameras(4, 32, 48)
-    bucket = GradBucket(sc.params())
+def _json_lines(stdout):
+    import json
+    return [json.loads(ln) for ln in stdout.splitlines() if ln.startswith("{")]
 
-    def rb(v):
-        out = render_view(sc, views[v], oracle_ops)
-        backward_view(out, seeded_cotangents(out, seed=v))
-    train_step(rb, bucket, range(4), reduce=False)
-    assert float(bucket.flat.abs().sum()) > 0
-    assert torch.allclose(reduced, bucket.flat, rtol=1e-5, atol=1e-6 * float(bucket.flat.abs().max()))
+
+def test_bench_spawns_its_own_ranks_and_reduces_gradients(tmp_path):
+    """`python bench.py --gpus 2` (gloo, CPU test hook, oracle-backed operators) starts two ranks by
+    itself, prints ONE line with n_gpus 2, and the reduced gradient equals the single-process sum
+    over the same four views — with the per-parameter overlapped reduction and with the single
+    collective."""
+    g2, g2b, g1 = tmp_path / "g2.pt", tmp_path / "g2b.pt", tmp_path / "g1.pt"
+    r2 = _run_bench(["--dump-grads", str(g2)], tmp_path, 2)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    lines = _json_lines(r2.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2
+    assert lines[0]["data"].startswith("selftest")
+    assert lines[0]["config"]["backend"] == "gloo"
+    nbytes = lines[0]["config"]["grad_allreduce_bytes"]
+    assert nbytes == 4 * 300 * (3 + 3 + 4 + 1 + 75 + 4)
+    r2b = _run_bench(["--dump-grads", str(g2b), "--no-overlap"], tmp_path, 2)
+    assert r2b.returncode == 0, r2b.stderr[-2000:]
+    # single process, same 4 views: 2 ranks x 2 views/step == 1 rank x 4 views/step
+    r1 = _run_bench(["--dump-grads", str(g1), "--views-per-step", "4"], tmp_path, 1)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    l1 = _json_lines(r1.stdout)
+    assert len(l1) == 1 and l1[0]["n_gpus"] == 1 and l1[0]["config"]["grad_allreduce_bytes"] == nbytes
+    a, b, c = (torch.load(f, weights_only=True) for f in (g2, g2b, g1))
+    assert float(c.abs().sum()) > 0
+    tol = 1e-6 * float(c.abs().max())
+    assert torch.allclose(a, c, rtol=1e-5, atol=tol)
+    assert torch.allclose(b, c, rtol=1e-5, atol=tol)
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus(tmp_path):
+    """no silent single-GPU fallback: WORLD_SIZE=1 with --gpus 2 is an error, not a 1-GPU run"""
+    r = _run_bench([], tmp_path, 2, env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+    assert not _json_lines(r.stdout)
+    # and the product operators cannot be benchmarked on the CPU
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--device", "cpu", "--points", "10"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no CPU path" in r.stderr
+
+
+def test_grad_bucket_rebind_after_parameter_replacement():
+    """densification replaces the parameter tensors (ref gaussian_splatting.py:434-439): rebind()
+    re-aliases .grad, and an armed hook on a stale alias raises instead of reducing garbage"""
+    from gaussiangrasper_amd.dist import GradBucket
+    ps = [torch.zeros(5, 3, requires_grad=True), torch.zeros(5, 1, requires_grad=True)]
+    b = GradBucket(ps)
+    (ps[0].sum() * 2 + ps[1].sum() * 3).backward()
+    assert torch.equal(b.flat, torch.cat([torch.full((15,), 2.0), torch.full((5,), 3.0)]))
+    ps2 = [torch.zeros(7, 3, requires_grad=True), torch.zeros(7, 1, requires_grad=True)]
+    b.rebind(ps2)
+    assert b.flat.numel() == 28 and b.nbytes == 112
+    (ps2[0].sum() + ps2[1].sum() * 5).backward()
+    assert torch.equal(b.flat, torch.cat([torch.ones(21), torch.full((7,), 5.0)]))
+    ps2[0].grad = torch.zeros(7, 3)        # somebody broke the alias
+    b.arm()
+    with pytest.raises(RuntimeError, match="no longer aliases"):
+        ps2[0].sum().backward()
 
 
 def test_checkpoint_and_ply_round_trips(tmp_path):
@@ -272,3 +290,42 @@ def test_checkpoint_and_ply_round_trips(tmp_path):
     # f_dc holds SH2RGB(dc) as in the reference's exporter: back through RGB2SH within rounding
     assert torch.allclose(sc.colors_all[:, 0], sc3.colors_all[:, 0], atol=1e-6)
     assert sc3.feature.shape == (257, 32) and not sc3.feature.any()
+
+
+def test_load_ply_accepts_the_reference_exporters_literal_property_set(tmp_path):
+    """The reference's exporter reshapes shs_rest to (N, 72, 1) and loops over shape[-1] == 1
+    (scripts/exporter.py:508-512): its PLY carries exactly one higher-band property, f_rest_0.
+    A hand-built file with that property set (in a different order, as open3d may write it) loads,
+    with the missing bands zero-filled."""
+    from gaussiangrasper_amd import interop
+    from gaussiangrasper_amd.constants import SH_C0
+    n = 5
+    rng = np.random.default_rng(3)
+    props = [("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("nx", "<f4"), ("ny", "<f4"), ("nz", "<f4"),
+             ("red", "u1"), ("green", "u1"), ("blue", "u1"), ("opacity", "<f4"), ("f_rest_0", "<f4"),
+             ("rot_0", "<f4"), ("rot_1", "<f4"), ("rot_2", "<f4"), ("rot_3", "<f4"),
+             ("scale_0", "<f4"), ("scale_1", "<f4"), ("scale_2", "<f4"),
+             ("f_dc_0", "<f4"), ("f_dc_1", "<f4"), ("f_dc_2", "<f4")]
+    rec = np.zeros(n, dtype=np.dtype(props))
+    for name, dt in props:
+        rec[name] = rng.random(n).astype(np.float32) if dt == "<f4" else rng.integers(0, 255, n)
+    header = ["ply", "format binary_little_endian 1.0", "comment hand-built", f"element vertex {n}"]
+    header += [f"property {'float' if d == '<f4' else 'uchar'} {name}" for name, d in props] + ["end_header"]
+    ply = tmp_path / "ref.ply"
+    ply.write_bytes(("\n".join(header) + "\n").encode("ascii") + rec.tobytes())
+    sc = interop.load_ply(ply, feature_dim=32)
+    assert sc.colors_all.shape == (n, 25, 3)
+    assert np.array_equal(sc.colors_all[:, 1, 0].numpy(), rec["f_rest_0"])
+    rest = sc.colors_all[:, 1:].reshape(n, -1)
+    assert not rest[:, 1:].any()
+    assert np.allclose(sc.colors_all[:, 0, 1].numpy(), (rec["f_dc_1"] - 0.5) / SH_C0, atol=1e-6)
+    assert np.array_equal(sc.means[:, 2].numpy(), rec["z"])
+    assert np.array_equal(sc.quats[:, 3].numpy(), rec["rot_3"])
+    # our writer's `reference_literal` mode produces that property set
+    out = tmp_path / "lit.ply"
+    interop.export_ply(out, sc, reference_literal=True)
+    head = open(out, "rb").read(4096).split(b"end_header\n")[0].decode().splitlines()
+    names = [ln.split()[2] for ln in head[3:]]
+    assert [x for x in names if x.startswith("f_rest_")] == ["f_rest_0"]
+    sc2 = interop.load_ply(out)
+    assert torch.equal(sc2.colors_all[:, 1, 0], sc.colors_all[:, 1, 0]) and torch.equal(sc2.means, sc.means)

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "shim")]
 import torch  # noqa: E402
 
-from gaussiangrasper_amd import _lib, ops  # noqa: E402
+from gaussiangrasper_amd import _lib, build as gg_build, ops  # noqa: E402
 from gaussiangrasper_amd.camera import ring_cameras  # noqa: E402
 from gaussiangrasper_amd.scene import make_scene  # noqa: E402
 
@@ -33,7 +33,13 @@ def main():
     ap.add_argument("--points", type=int, default=1_000_000)
     args = ap.parse_args()
     dev = "cuda:0"
+    # the ablated kernels live only in the measurement twin of the library (-DGG_ABLATION)
+    if not os.path.exists(gg_build.ABL_OUT) or \
+            os.path.getmtime(gg_build.ABL_OUT) < os.path.getmtime(gg_build.OUT):
+        gg_build.build_ablation()
+    _lib.LIB_PATH = gg_build.ABL_OUT
     lib = _lib.load()
+    lib.gg_debug_set_ablation.restype, lib.gg_debug_set_ablation.argtypes = ctypes.c_int, [ctypes.c_int]
     h, w = 1200, 1600
     sc = make_scene(args.points, config_index=3).to(dev)
     v = ring_cameras(8, h, w, device=dev)[0]

@@ -184,7 +184,7 @@ def build_roofline(args, kernels, n_vis, n_isect, ms_per_view):
     pmc, pmc_file = load_pmc()
     per = {}
     for name, k in kernels.items():
-        if not name.startswith("blend_"):
+        if not name.startswith("blend_") or "<" not in name:
             continue
         C = int(name[name.index("<") + 1:name.index(">")])
         fn = algorithmic_bytes_blend_bwd if "bwd" in name else algorithmic_bytes_blend_fwd

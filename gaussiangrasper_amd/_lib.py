@@ -14,6 +14,23 @@ ABI_VERSION = 1
 
 _P, _I, _F, _I64, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 
+
+class RowArray(C.Structure):
+    """gg_row_array_t"""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_floats", C.c_int), ("kind", C.c_int)]
+
+
+class AdamGroup(C.Structure):
+    """gg_adam_group_t"""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p),
+                ("exp_avg_sq", C.c_void_p), ("numel", C.c_int64), ("lr", C.c_double),
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("weight_decay", C.c_double), ("step", C.c_int64)]
+
+
+ROWS_COPY, ROWS_MEANS, ROWS_SCALES, ROWS_ZERO_NEW = 0, 1, 2, 3
+MAX_ROW_ARRAYS, ADAM_MAX_GROUPS = 24, 8
+
 # name -> (restype, argtypes); mirrors include/gg_raster.h declaration by declaration
 SIGNATURES = {
     "gg_abi_version": (_I, []),
@@ -35,6 +52,15 @@ SIGNATURES = {
     "gg_blend_fwd": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gg_blend_bwd": (_I, [_I, _I, _I, _I] + [_P] * 14 + [_I, _I, _P, _SZ, _I, _P]),
     "gg_expf_array": (_I, [_I, _P, _P, _P]),
+    "gg_rows_workspace": (_SZ, [_I]),
+    "gg_mask_scan": (_I, [_I, _P, _I, _P, _P, _P, _SZ, _P]),
+    "gg_compact_rows": (_I, [_I, _P, _I, C.POINTER(RowArray), _P, _P, _SZ, _P]),
+    "gg_densify_rows": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P, _F, _P, _P, _P, _I,
+                             C.POINTER(RowArray), _P]),
+    "gg_densify_stats": (_I, [_I, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "gg_densify_masks": (_I, [_I, _P, _P, _P, _P, _I, _F, _F, _F, _I, _P, _P, _P]),
+    "gg_cull_mask": (_I, [_I, _P, _P, _P, _F, _F, _F, _I, _I, _P, _P]),
+    "gg_adam_step": (_I, [_I, C.POINTER(AdamGroup), _I, _P]),
     "gg_prof_enable": (_I, [_I]),
     "gg_prof_reset": (_I, []),
     "gg_prof_get": (_I, [_I, C.POINTER(C.c_int), C.POINTER(C.c_double)]),

@@ -149,6 +149,77 @@ int gg_mlp_fwd(int64_t num_rows, int in_dim, int hidden_dim, int out_dim, const 
                const float *w1, const float *b1, const float *w2, const float *b2, float *y,
                gg_stream_t stream);
 
+/* ---- densification, culling and the optimizer step ---------------------------------
+ * The per-Gaussian optimizer-side work of the reference model, which it does with torch indexing,
+ * torch.cat and one torch.optim.Adam per parameter group:
+ *   statistics   GaussianSplattingModel.after_train          gaussian_splatting.py:373-393
+ *   masks        refinement_after :412-421,:430-431 ; cull_gaussians :485-496
+ *   cull         cull_gaussians :497-502 + remove_from_optim :333-350
+ *   split / dup  split_gaussians :504-531, dup_gaussians :533-546, torch.cat :434-439, dup_in_optim :352-371
+ *   Adam         Optimizers.optimizer_step_all               engine/optimizers.py:158-171
+ * Row arrays are (num_rows, row_floats) fp32, contiguous; byte masks are 0 / non-0. */
+typedef struct {
+    const float *src; /* (num_rows, row_floats) */
+    float *dst;       /* destination array (capacity: see each function) */
+    int row_floats;
+    int kind; /* GG_ROWS_* (gg_densify_rows only; ignored by gg_compact_rows) */
+} gg_row_array_t;
+#define GG_ROWS_COPY 0     /* appended rows copy their source row                                    */
+#define GG_ROWS_MEANS 1    /* split samples: R(q/|q|) (exp(scale) * z) + mean  (:509-516); 3 floats  */
+#define GG_ROWS_SCALES 2   /* split sources and samples: log(exp(scale) / size_fac) (:524-526); 3 floats */
+#define GG_ROWS_ZERO_NEW 3 /* Adam moments: appended rows are zero (dup_in_optim :352-371)            */
+
+/* bytes of scratch for gg_mask_scan / gg_compact_rows over num_rows rows */
+size_t gg_rows_workspace(int num_rows);
+/* ranks[i] = number of selected rows before i (selected = mask != 0, or == 0 with invert);
+ * *total_out (device int64) = number selected.  One launch (decoupled look-back scan). */
+int gg_mask_scan(int num_rows, const uint8_t *mask, int invert, int32_t *ranks, int64_t *total_out,
+                 void *ws, size_t ws_bytes, gg_stream_t stream);
+/* Stream compaction: rows with deleted_mask == 0 of every array move, in order, to the front of its
+ * dst (capacity num_rows rows; src != dst).  Replaces `t[~culls]` on the 6 parameters and the 12
+ * moment tensors (<= 24 arrays, one launch).  *num_kept_out (device int64) = rows kept.
+ * `arrays` is a HOST array of descriptors. */
+int gg_compact_rows(int num_rows, const uint8_t *deleted_mask, int num_arrays,
+                    const gg_row_array_t *arrays, int64_t *num_kept_out, void *ws, size_t ws_bytes,
+                    gg_stream_t stream);
+/* Append rows: dst = [num_rows old | num_samples x num_split split samples (sample-major) | num_dup
+ * duplicates]; dst capacity num_rows + num_samples*num_split + num_dup rows.  split_ranks / dup_ranks
+ * and the counts come from gg_mask_scan; samples (num_samples*num_split, 3) are the caller's N(0,1)
+ * draws (torch.randn, :508); means / scales / quats are the CURRENT parameter arrays. */
+int gg_densify_rows(int num_rows, const uint8_t *split_mask, const uint8_t *dup_mask,
+                    const int32_t *split_ranks, const int32_t *dup_ranks, int num_split, int num_dup,
+                    int num_samples, const float *samples, float size_fac, const float *means,
+                    const float *scales, const float *quats, int num_arrays,
+                    const gg_row_array_t *arrays, gg_stream_t stream);
+/* after_train (:373-393).  first != 0: the accumulators are (re)initialised as the reference does
+ * when they are None (grad norms of every Gaussian, counts 1, max_2dsize 0 then max over visible). */
+int gg_densify_stats(int num_points, const float *xys_grad, const int32_t *radii, int max_image_dim,
+                     int first, float *grad_norm_accum, float *vis_counts, float *max_2dsize,
+                     gg_stream_t stream);
+/* split / dup masks of refinement_after (:412-421, :430-431); scales are log-scales (N,3). */
+int gg_densify_masks(int num_points, const float *grad_norm_accum, const float *vis_counts,
+                     const float *max_2dsize, const float *scales, int max_image_dim,
+                     float densify_grad_thresh, float densify_size_thresh, float split_screen_size,
+                     int use_screen_size, uint8_t *split_mask, uint8_t *dup_mask, gg_stream_t stream);
+/* cull mask of cull_gaussians (:485-496); opacities are logits (N,), scales log-scales (N,3). */
+int gg_cull_mask(int num_points, const float *opacities, const float *scales, const float *max_2dsize,
+                 float cull_alpha_thresh, float cull_scale_thresh, float cull_screen_size,
+                 int use_scale, int use_screen_size, uint8_t *deleted_mask, gg_stream_t stream);
+
+/* One Adam step (torch.optim.Adam, amsgrad off) of up to GG_ADAM_MAX_GROUPS parameter arrays in ONE
+ * launch; every group has its own hyper-parameters and step count, as the reference's one optimizer
+ * per group does (method_configs.py:618-660: eps 1e-15, lr 1.6e-4 ... 0.05).  step is the step
+ * number being taken (>= 1).  Arrays must be 16-byte aligned.  zero_grad != 0 clears the gradients
+ * in the same pass.  `groups` is a HOST array. */
+#define GG_ADAM_MAX_GROUPS 8
+typedef struct {
+    float *param, *grad, *exp_avg, *exp_avg_sq;
+    int64_t numel;
+    double lr, beta1, beta2, eps, weight_decay;
+    int64_t step;
+} gg_adam_group_t;
+int gg_adam_step(int num_groups, const gg_adam_group_t *groups, int zero_grad, gg_stream_t stream);
+
 /* ---- in-library kernel timing (measurement only; off by default) --------------------------------
  * When enabled, every launch of the kernels below is bracketed by a hipEvent pair recorded on the
  * launch stream, so bench.py can report the average duration of exactly that kernel over its
@@ -165,6 +236,9 @@ int gg_mlp_fwd(int64_t num_rows, int in_dim, int hidden_dim, int out_dim, const 
 #define GG_K_MLP_FWD 8
 #define GG_K_BLEND_FWD 10 /* + width index: template widths {1,3,4,8,16,32} -> 0..5 */
 #define GG_K_BLEND_BWD 20 /* + width index */
+#define GG_K_COMPACT 26
+#define GG_K_DENSIFY 27
+#define GG_K_ADAM 28
 #define GG_PROF_NUM_KERNELS 32
 int gg_prof_enable(int on);
 int gg_prof_reset(void);

@@ -801,3 +801,181 @@ void NAME(set_num_threads)(int n) { omp_set_num_threads(n); }
 int NAME(num_threads)(void) { return 1; }
 void NAME(set_num_threads)(int n) { (void)n; }
 #endif
+
+/* ==========================================================================================
+ * densification statistics / masks, cull compaction, split / dup row append and the
+ * Adam step.  Unlike the rasterizer these rows ARE pinnable: the reference does them with plain torch
+ * (gaussian_splatting.py:333-393,402-546; engine/optimizers.py:158-171 -> torch.optim.Adam), which is
+ * importable here; tests/test_densify_adam.py pins every function below against that torch code.
+ * ======================================================================================== */
+
+/* torch.optim.Adam (single-tensor path, amsgrad off), one parameter array:
+ *   exp_avg.lerp_(grad, 1-beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+ *   step_size = lr / (1-beta1^t); denom = sqrt(exp_avg_sq) / sqrt(1-beta2^t) + eps
+ *   param.addcdiv_(exp_avg, denom, value=-step_size)
+ * bias corrections in double (python floats), rounded to REAL where torch hands them to a kernel. */
+void NAME(adam_step)(int64_t numel, REAL *p, const REAL *g_in, REAL *m, REAL *v, double lr, double beta1,
+                     double beta2, double eps, double weight_decay, int64_t step) {
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const REAL step_size = (REAL)(lr / bc1), bc2s = (REAL)sqrt(bc2);
+    const REAL w1 = (REAL)(1.0 - beta1), w2 = (REAL)(1.0 - beta2), b2 = (REAL)beta2, e = (REAL)eps,
+               wd = (REAL)weight_decay;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < numel; ++i) {
+        REAL g = g_in[i];
+        if (wd != R_(0.0f)) g = FMA(wd, p[i], g);
+        const REAL mi = FMA(w1, g - m[i], m[i]);
+        const REAL vi = FMA(w2 * g, g, v[i] * b2);
+        const REAL denom = SQRT(vi) / bc2s + e;
+        p[i] = p[i] + (-step_size * mi) / denom;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+/* ranks[i] = number of selected rows before i; returns the number selected */
+int64_t NAME(mask_scan)(int N, const uint8_t *mask, int invert, int32_t *ranks) {
+    int64_t run = 0;
+    for (int i = 0; i < N; ++i) {
+        ranks[i] = (int32_t)run;
+        run += ((mask[i] != 0) != (invert != 0)) ? 1 : 0;
+    }
+    return run;
+}
+
+/* t[~deleted] (cull_gaussians :497-502, remove_from_optim :341-342): kept rows move to the front */
+int64_t NAME(compact_rows)(int N, const uint8_t *deleted, int w, const REAL *src, REAL *dst) {
+    int64_t k = 0;
+    for (int i = 0; i < N; ++i) {
+        if (deleted[i]) continue;
+        memcpy(dst + (size_t)k * w, src + (size_t)i * w, sizeof(REAL) * (size_t)w);
+        ++k;
+    }
+    return k;
+}
+
+/* torch.cat([old, split samples (sample-major), dups]) of one array (refinement_after :434-439,
+ * split_gaussians :504-531, dup_gaussians :533-546, dup_in_optim :352-371); kinds as gg_raster.h */
+void NAME(densify_rows)(int N, const uint8_t *split_mask, const uint8_t *dup_mask, int nsamps,
+                        const REAL *samples, REAL size_fac, const REAL *means, const REAL *scales,
+                        const REAL *quats, int w, int kind, const REAL *src, REAL *dst) {
+    int n_split = 0, n_dup = 0;
+    for (int i = 0; i < N; ++i) {
+        n_split += split_mask && split_mask[i] ? 1 : 0;
+        n_dup += dup_mask && dup_mask[i] ? 1 : 0;
+    }
+    int sr = 0, dr = 0;
+    for (int i = 0; i < N; ++i) {
+        const int is_split = split_mask && split_mask[i], is_dup = dup_mask && dup_mask[i];
+        for (int c = 0; c < w; ++c) {
+            const REAL val = src[(size_t)i * w + c];
+            REAL old_v = val, split_v = val;
+            if (kind == 2 && is_split) {
+#ifdef GGO_F64
+                old_v = split_v = log(exp(val) / size_fac);
+#else
+                old_v = split_v = logf(expf(val) / size_fac);
+#endif
+            }
+            if (kind == 3) split_v = R_(0.0f);
+            dst[(size_t)i * w + c] = old_v;
+            if (is_split) {
+                for (int s = 0; s < nsamps; ++s) {
+                    const size_t row = (size_t)N + (size_t)s * n_split + sr;
+                    REAL out = split_v;
+                    if (kind == 1) {
+                        const REAL *q = quats + 4 * (size_t)i;
+                        REAL n = SQRT(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+                        REAL qw = q[0] / n, qx = q[1] / n, qy = q[2] / n, qz = q[3] / n;
+                        const REAL n2 = FMAX(SQRT(qw * qw + qx * qx + qy * qy + qz * qz), R_(GG_QUAT_NORM_EPS));
+                        qw /= n2; qx /= n2; qy /= n2; qz /= n2;
+                        REAL Rm[9];
+                        Rm[0] = R_(1.f) - R_(2.f) * (qy * qy + qz * qz); Rm[1] = R_(2.f) * (qx * qy - qw * qz);
+                        Rm[2] = R_(2.f) * (qx * qz + qw * qy); Rm[3] = R_(2.f) * (qx * qy + qw * qz);
+                        Rm[4] = R_(1.f) - R_(2.f) * (qx * qx + qz * qz); Rm[5] = R_(2.f) * (qy * qz - qw * qx);
+                        Rm[6] = R_(2.f) * (qx * qz - qw * qy); Rm[7] = R_(2.f) * (qy * qz + qw * qx);
+                        Rm[8] = R_(1.f) - R_(2.f) * (qx * qx + qy * qy);
+                        const REAL *z = samples + 3 * ((size_t)s * n_split + sr);
+                        REAL sc[3];
+                        for (int k = 0; k < 3; ++k) {
+#ifdef GGO_F64
+                            sc[k] = exp(scales[3 * (size_t)i + k]) * z[k];
+#else
+                            sc[k] = expf(scales[3 * (size_t)i + k]) * z[k];
+#endif
+                        }
+                        out = ((Rm[3 * c] * sc[0] + Rm[3 * c + 1] * sc[1]) + Rm[3 * c + 2] * sc[2]) +
+                              means[3 * (size_t)i + c];
+                    }
+                    dst[row * w + c] = out;
+                }
+            }
+            if (is_dup)
+                dst[((size_t)N + (size_t)nsamps * n_split + dr) * w + c] = (kind == 3) ? R_(0.0f) : val;
+        }
+        sr += is_split;
+        dr += is_dup;
+    }
+}
+
+static REAL ggo_max_exp3(const REAL *s) {
+#ifdef GGO_F64
+    return FMAX(FMAX(exp(s[0]), exp(s[1])), exp(s[2]));
+#else
+    return FMAX(FMAX(expf(s[0]), expf(s[1])), expf(s[2]));
+#endif
+}
+
+/* after_train (:373-393) */
+void NAME(densify_stats)(int N, const REAL *xys_grad, const int32_t *radii, int max_dim, int first,
+                         REAL *grad_norm, REAL *vis_counts, REAL *max_2dsize) {
+    for (int i = 0; i < N; ++i) {
+        const REAL gx = xys_grad[2 * (size_t)i], gy = xys_grad[2 * (size_t)i + 1];
+        const REAL g = SQRT(gx * gx + gy * gy);
+        const int vis = radii[i] > 0;
+        if (first) {
+            grad_norm[i] = g;
+            vis_counts[i] = R_(1.0f);
+            max_2dsize[i] = R_(0.0f);
+        } else if (vis) {
+            vis_counts[i] = vis_counts[i] + R_(1.0f);
+            grad_norm[i] = g + grad_norm[i];
+        }
+        if (vis) max_2dsize[i] = FMAX(max_2dsize[i], (REAL)radii[i] / (REAL)max_dim);
+    }
+}
+
+/* refinement_after (:412-421, :430-431) */
+void NAME(densify_masks)(int N, const REAL *grad_norm, const REAL *vis_counts, const REAL *max_2dsize,
+                         const REAL *scales, int max_dim, REAL grad_thresh, REAL size_thresh,
+                         REAL split_screen_size, int use_screen, uint8_t *split_mask, uint8_t *dup_mask) {
+    for (int i = 0; i < N; ++i) {
+        const REAL avg = ((grad_norm[i] / vis_counts[i]) * R_(0.5f)) * (REAL)max_dim;
+        const int high = avg > grad_thresh;
+        const REAL smax = ggo_max_exp3(scales + 3 * (size_t)i);
+        int split = smax > size_thresh;
+        if (use_screen) split = split || (max_2dsize[i] > split_screen_size);
+        split = split && high;
+        split_mask[i] = (uint8_t)split;
+        dup_mask[i] = (uint8_t)((smax <= size_thresh) && high);
+    }
+}
+
+/* cull_gaussians (:485-496) */
+void NAME(cull_mask)(int N, const REAL *opacities, const REAL *scales, const REAL *max_2dsize,
+                     REAL alpha_thresh, REAL scale_thresh, REAL screen_thresh, int use_scale, int use_screen,
+                     uint8_t *mask) {
+    for (int i = 0; i < N; ++i) {
+#ifdef GGO_F64
+        const REAL sig = 1.0 / (1.0 + exp(-opacities[i]));
+#else
+        const REAL sig = 1.0f / (1.0f + expf(-opacities[i]));
+#endif
+        int cull = sig < alpha_thresh;
+        if (use_scale) {
+            cull = cull || (ggo_max_exp3(scales + 3 * (size_t)i) > scale_thresh);
+            if (use_screen) cull = cull || (max_2dsize[i] > screen_thresh);
+        }
+        mask[i] = (uint8_t)cull;
+    }
+}

@@ -245,3 +245,105 @@ def mlp_fwd(x, w1, b1, w2, b2, dtype=np.float32):
     getattr(lib, pre + "mlp_fwd")(C.c_int64(x.shape[0]), C.c_int(x.shape[1]), C.c_int(w2.shape[0]), _p(x),
                                   _p(w1), _p(b1), _p(w2), _p(b2), _p(y))
     return y.reshape(shape[:-1] + (w2.shape[0],))
+
+
+# ------------------------------------------------------------------------------------------------
+# densify / cull / Adam (pinned against torch in tests/test_densify_adam.py)
+# ------------------------------------------------------------------------------------------------
+def _u8(a):
+    return np.ascontiguousarray(np.asarray(a).astype(np.uint8))
+
+
+def adam_step(p, g, m, v, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, step=1,
+              dtype=np.float32):
+    """One torch.optim.Adam step of one parameter array (reference engine/optimizers.py:158-171).
+    Returns NEW (p, m, v); inputs are not modified."""
+    lib, pre, _ = _lib(dtype)
+    p, m, v = (_c(a, dtype).copy() for a in (p, m, v))
+    g = _c(g, dtype)
+    getattr(lib, pre + "adam_step")(C.c_int64(p.size), _p(p), _p(g), _p(m), _p(v), C.c_double(lr),
+                                    C.c_double(beta1), C.c_double(beta2), C.c_double(eps),
+                                    C.c_double(weight_decay), C.c_int64(step))
+    return p, m, v
+
+
+def mask_scan(mask, invert=False):
+    lib, pre, _ = _lib(np.float32)
+    mask = _u8(mask).reshape(-1)
+    ranks = np.empty(mask.size, np.int32)
+    fn = getattr(lib, pre + "mask_scan")
+    fn.restype = C.c_int64
+    total = fn(C.c_int(mask.size), _p(mask), C.c_int(int(invert)), _p(ranks))
+    return ranks, int(total)
+
+
+def compact_rows(deleted_mask, arr, dtype=np.float32):
+    """arr[~deleted_mask] (reference cull_gaussians :497-502, remove_from_optim :341-342)."""
+    lib, pre, _ = _lib(dtype)
+    deleted_mask = _u8(deleted_mask).reshape(-1)
+    a = _c(arr, dtype)
+    n = a.shape[0]
+    w = int(a.size // max(n, 1)) if n else 1
+    dst = np.empty_like(a)
+    fn = getattr(lib, pre + "compact_rows")
+    fn.restype = C.c_int64
+    k = fn(C.c_int(n), _p(deleted_mask), C.c_int(w), _p(a), _p(dst))
+    return dst[:int(k)]
+
+
+ROWS_COPY, ROWS_MEANS, ROWS_SCALES, ROWS_ZERO_NEW = 0, 1, 2, 3
+
+
+def densify_rows(arr, kind, split_mask, dup_mask, nsamps, samples, size_fac, means, scales, quats,
+                 dtype=np.float32):
+    """torch.cat([old, split samples, dups]) of one array (reference :434-439,:504-546,:352-371)."""
+    lib, pre, RT = _lib(dtype)
+    split_mask, dup_mask = _u8(split_mask).reshape(-1), _u8(dup_mask).reshape(-1)
+    a = _c(arr, dtype)
+    n = a.shape[0]
+    w = int(a.size // n)
+    ns, nd = int(split_mask.sum()), int(dup_mask.sum())
+    dst = np.empty((n + nsamps * ns + nd,) + a.shape[1:], dtype)
+    samples = _c(samples, dtype).reshape(-1, 3)
+    assert samples.shape[0] == nsamps * ns
+    getattr(lib, pre + "densify_rows")(C.c_int(n), _p(split_mask), _p(dup_mask), C.c_int(nsamps),
+                                       _p(samples), RT(size_fac), _p(_c(means, dtype)), _p(_c(scales, dtype)),
+                                       _p(_c(quats, dtype)), C.c_int(w), C.c_int(kind), _p(a), _p(dst))
+    return dst
+
+
+def densify_stats(xys_grad, radii, max_dim, first, grad_norm, vis_counts, max_2dsize, dtype=np.float32):
+    """after_train (:373-393); returns NEW (grad_norm, vis_counts, max_2dsize)."""
+    lib, pre, _ = _lib(dtype)
+    xg = _c(xys_grad, dtype)
+    n = xg.shape[0]
+    rad = np.ascontiguousarray(radii, np.int32)
+    outs = [np.zeros(n, dtype) if a is None else _c(a, dtype).copy() for a in (grad_norm, vis_counts, max_2dsize)]
+    getattr(lib, pre + "densify_stats")(C.c_int(n), _p(xg), _p(rad), C.c_int(max_dim), C.c_int(int(first)),
+                                        _p(outs[0]), _p(outs[1]), _p(outs[2]))
+    return tuple(outs)
+
+
+def densify_masks(grad_norm, vis_counts, max_2dsize, scales, max_dim, grad_thresh, size_thresh,
+                  split_screen_size, use_screen, dtype=np.float32):
+    lib, pre, RT = _lib(dtype)
+    n = np.asarray(grad_norm).shape[0]
+    sm, dm = np.empty(n, np.uint8), np.empty(n, np.uint8)
+    getattr(lib, pre + "densify_masks")(C.c_int(n), _p(_c(grad_norm, dtype)), _p(_c(vis_counts, dtype)),
+                                        _p(_c(max_2dsize, dtype)), _p(_c(scales, dtype)), C.c_int(max_dim),
+                                        RT(grad_thresh), RT(size_thresh), RT(split_screen_size),
+                                        C.c_int(int(use_screen)), _p(sm), _p(dm))
+    return sm.astype(bool), dm.astype(bool)
+
+
+def cull_mask(opacities, scales, max_2dsize, alpha_thresh, scale_thresh, screen_thresh, use_scale,
+              use_screen, dtype=np.float32):
+    lib, pre, RT = _lib(dtype)
+    op = _c(opacities, dtype).reshape(-1)
+    n = op.shape[0]
+    m2 = _c(max_2dsize if max_2dsize is not None else np.zeros(n), dtype)
+    out = np.empty(n, np.uint8)
+    getattr(lib, pre + "cull_mask")(C.c_int(n), _p(op), _p(_c(scales, dtype)), _p(m2), RT(alpha_thresh),
+                                    RT(scale_thresh), RT(screen_thresh), C.c_int(int(use_scale)),
+                                    C.c_int(int(use_screen)), _p(out))
+    return out.astype(bool)

@@ -319,7 +319,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
     elapsed = timed(render_and_backward, args.steps)          # kernel timers off
 
     if args.dump_grads and rank == 0:
-        torch.save(bucket.flat.detach().cpu().clone(), args.dump_grads)
+        torch.save(bucket.gathered().detach().cpu().clone(), args.dump_grads)
 
     kernels = {}
     if lib is not None and not args.no_prof:                   # one profiled step, all ranks

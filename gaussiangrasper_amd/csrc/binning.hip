@@ -20,6 +20,17 @@
 // equal digits keep their input order without any LDS sorting network.
 #include "gg_common.h"
 
+// Device-side item count: the tile-sort kernels can take the number of intersections from device
+// memory (n_dev != NULL), clamped to the capacity n the launch was sized for — the host then needs no
+// read-back before it can enqueue them (gg_bin_sort_dev).
+__device__ __forceinline__ int64_t dev_count(int64_t n, const int64_t *__restrict__ n_dev) {
+    if (n_dev) {
+        const int64_t d = *n_dev;
+        if (d < n) n = d;
+    }
+    return n;
+}
+
 #define RS_THREADS 256
 #define RS_WAVES (RS_THREADS / GG_WAVE)
 // keys per thread: 16 for large inputs; 4 when that would leave fewer than ~4 workgroups per CU
@@ -84,10 +95,11 @@ __global__ __launch_bounds__(256) void depth_keys_kernel(int N, const float *__r
 // ---------------------------------------------------------------------------------------------
 template <int RS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(
-    int64_t n, const uint32_t *__restrict__ keys, int shift, uint32_t mask, int nblocks,
-    uint32_t *__restrict__ G) {
+    int64_t n, const int64_t *__restrict__ n_dev, const uint32_t *__restrict__ keys, int shift,
+    uint32_t mask, int nblocks, uint32_t *__restrict__ G) {
     constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
     __shared__ uint32_t hist[256];
+    n = dev_count(n, n_dev);
     hist[threadIdx.x] = 0;
     __syncthreads();
     int64_t base = (int64_t)blockIdx.x * RS_TILE;
@@ -133,10 +145,12 @@ __global__ __launch_bounds__(256) void radix_colscan_kernel(int nblocks, uint32_
 // step 3: stable scatter
 template <int RS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
-    int64_t n, const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int shift, uint32_t mask,
-    int nblocks, const uint32_t *__restrict__ G, const uint32_t *__restrict__ totals) {
+    int64_t n, const int64_t *__restrict__ n_dev, const uint32_t *__restrict__ keys_in,
+    const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out, int shift, uint32_t mask, int nblocks,
+    const uint32_t *__restrict__ G, const uint32_t *__restrict__ totals) {
     constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
+    n = dev_count(n, n_dev);
     __shared__ uint32_t whist[RS_WAVES][256];
     __shared__ uint32_t digit_base[256];
     __shared__ uint32_t wsum[4];
@@ -329,9 +343,11 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, const uint32_t *__rest
                                                    const float *__restrict__ xys,
                                                    const int32_t *__restrict__ radii, int tiles_x,
                                                    int tiles_y, int64_t I,
+                                                   const int64_t *__restrict__ I_dev,
                                                    uint32_t *__restrict__ tkeys,
                                                    uint32_t *__restrict__ tvals) {
-    __shared__ uint32_t s_rel[4][64];   // start of each Gaussian's run, relative to the wave's first
+    __shared__ uint32_t s_rel[4][64];
+    I = dev_count(I, I_dev);   // start of each Gaussian's run, relative to the wave's first
     __shared__ int4 s_box[4][64];       // x0, y0, box width, Gaussian id
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -379,11 +395,12 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, const uint32_t *__rest
     }
 }
 
-__global__ __launch_bounds__(256) void tile_bins_kernel(int64_t I,
+__global__ __launch_bounds__(256) void tile_bins_kernel(int64_t I, const int64_t *__restrict__ I_dev,
                                                         const uint32_t *__restrict__ tkeys_sorted,
                                                         uint32_t num_tiles,
                                                         int32_t *__restrict__ tile_bins,
                                                         int32_t *__restrict__ tile_out) {
+    I = dev_count(I, I_dev);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= I) return;
     uint32_t cur = tkeys_sorted[i];
@@ -447,29 +464,28 @@ extern "C" size_t gg_bin_sort_workspace(int num_points, int64_t num_intersects) 
     return bin_ws_layout(nullptr, num_points, num_intersects).bytes;
 }
 
-static void radix_pass(int64_t n, const uint32_t *kin, const uint32_t *vin, uint32_t *kout,
-                       uint32_t *vout, int shift, uint32_t mask, BinWs &w, hipStream_t s) {
+static void radix_pass(int64_t n, const int64_t *n_dev, const uint32_t *kin, const uint32_t *vin,
+                       uint32_t *kout, uint32_t *vout, int shift, uint32_t mask, BinWs &w, hipStream_t s) {
     int nb = radix_nblocks(n);
     if (rs_items(n) == 16)
-        hipLaunchKernelGGL(radix_hist_kernel<16>, dim3(nb), dim3(RS_THREADS), 0, s, n, kin, shift,
+        hipLaunchKernelGGL(radix_hist_kernel<16>, dim3(nb), dim3(RS_THREADS), 0, s, n, n_dev, kin, shift,
                            mask, nb, w.G);
     else
-        hipLaunchKernelGGL(radix_hist_kernel<4>, dim3(nb), dim3(RS_THREADS), 0, s, n, kin, shift,
+        hipLaunchKernelGGL(radix_hist_kernel<4>, dim3(nb), dim3(RS_THREADS), 0, s, n, n_dev, kin, shift,
                            mask, nb, w.G);
     hipLaunchKernelGGL(radix_colscan_kernel, dim3(256), dim3(256), 0, s, nb, w.G, w.totals);
     if (rs_items(n) == 16)
-        hipLaunchKernelGGL(radix_scatter_kernel<16>, dim3(nb), dim3(RS_THREADS), 0, s, n, kin, vin,
+        hipLaunchKernelGGL(radix_scatter_kernel<16>, dim3(nb), dim3(RS_THREADS), 0, s, n, n_dev, kin, vin,
                            kout, vout, shift, mask, nb, w.G, w.totals);
     else
-        hipLaunchKernelGGL(radix_scatter_kernel<4>, dim3(nb), dim3(RS_THREADS), 0, s, n, kin, vin,
+        hipLaunchKernelGGL(radix_scatter_kernel<4>, dim3(nb), dim3(RS_THREADS), 0, s, n, n_dev, kin, vin,
                            kout, vout, shift, mask, nb, w.G, w.totals);
 }
 
-extern "C" int gg_bin_sort(int N, int64_t I, const float *xys, const float *depths,
-                           const int32_t *radii, const int32_t *num_tiles_hit, int tiles_x,
-                           int tiles_y, int32_t *gaussian_ids_sorted, int32_t *tile_bins,
-                           int32_t *isect_tile_sorted, void *ws, size_t ws_bytes,
-                           gg_stream_t stream) {
+static int bin_sort_impl(int N, int64_t I, const int64_t *I_dev, const float *xys, const float *depths,
+                         const int32_t *radii, const int32_t *num_tiles_hit, int tiles_x, int tiles_y,
+                         int32_t *gaussian_ids_sorted, int32_t *tile_bins, int32_t *isect_tile_sorted,
+                         void *ws, size_t ws_bytes, gg_stream_t stream) {
     GG_REQUIRE(N >= 0 && I >= 0, "negative size");
     GG_REQUIRE(tiles_x > 0 && tiles_y > 0, "empty tile grid");
     GG_REQUIRE(I < (int64_t)1 << 31, "num_intersects must fit int32 (tile_bins are int32)");
@@ -493,7 +509,7 @@ extern "C" int gg_bin_sort(int N, int64_t I, const float *xys, const float *dept
                        w.dkeyA, w.dvalA);
     uint32_t *ka = w.dkeyA, *kb = w.dkeyB, *va = w.dvalA, *vb = w.dvalB;
     for (int pass = 0; pass < 4; ++pass) {
-        radix_pass(N, ka, va, kb, vb, 8 * pass, 0xFFu, w, s);
+        radix_pass(N, nullptr, ka, va, kb, vb, 8 * pass, 0xFFu, w, s);
         uint32_t *t = ka; ka = kb; kb = t;
         t = va; va = vb; vb = t;
     }
@@ -515,20 +531,44 @@ extern "C" int gg_bin_sort(int N, int64_t I, const float *xys, const float *dept
     uint32_t *valt = (passes % 2 == 0) ? w.tvalTmp : out_vals;
     // entries the emission does not reach (caller's I larger than the true total) get an
     // out-of-range tile id and id 0, so they sort to the end and are never dereferenced
-    (void)hipMemsetAsync(kcur, 0xFF, sizeof(uint32_t) * (size_t)I, s);
-    (void)hipMemsetAsync(vcur, 0, sizeof(uint32_t) * (size_t)I, s);
+    // (with a device-side count every processed entry is emitted: nothing to pre-fill)
+    if (!I_dev) {
+        (void)hipMemsetAsync(kcur, 0xFF, sizeof(uint32_t) * (size_t)I, s);
+        (void)hipMemsetAsync(vcur, 0, sizeof(uint32_t) * (size_t)I, s);
+    }
     hipLaunchKernelGGL(emit_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, order, w.offsets,
-                       xys, radii, tiles_x, tiles_y, I, kcur, vcur);
+                       xys, radii, tiles_x, tiles_y, I, I_dev, kcur, vcur);
     for (int pass = 0; pass < passes; ++pass) {
         int bits = min(8, tile_bits - 8 * pass);
-        radix_pass(I, kcur, vcur, kalt, valt, 8 * pass, (1u << bits) - 1u, w, s);
+        radix_pass(I, I_dev, kcur, vcur, kalt, valt, 8 * pass, (1u << bits) - 1u, w, s);
         uint32_t *t = kcur; kcur = kalt; kalt = t;
         t = vcur; vcur = valt; valt = t;
     }
     // 5. tile ranges
-    hipLaunchKernelGGL(tile_bins_kernel, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, s, I, kcur,
+    hipLaunchKernelGGL(tile_bins_kernel, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, s, I, I_dev, kcur,
                        (uint32_t)T, tile_bins, isect_tile_sorted);
     gg_prof_end(GG_K_BIN_SORT, s);
     GG_CHECK_LAUNCH();
     return GG_OK;
+}
+
+extern "C" int gg_bin_sort(int N, int64_t I, const float *xys, const float *depths,
+                           const int32_t *radii, const int32_t *num_tiles_hit, int tiles_x,
+                           int tiles_y, int32_t *gaussian_ids_sorted, int32_t *tile_bins,
+                           int32_t *isect_tile_sorted, void *ws, size_t ws_bytes,
+                           gg_stream_t stream) {
+    return bin_sort_impl(N, I, nullptr, xys, depths, radii, num_tiles_hit, tiles_x, tiles_y,
+                         gaussian_ids_sorted, tile_bins, isect_tile_sorted, ws, ws_bytes, stream);
+}
+
+extern "C" int gg_bin_sort_dev(int N, int64_t capacity, const int64_t *num_intersects_dev,
+                               const float *xys, const float *depths, const int32_t *radii,
+                               const int32_t *num_tiles_hit, int tiles_x, int tiles_y,
+                               int32_t *gaussian_ids_sorted, int32_t *tile_bins,
+                               int32_t *isect_tile_sorted, void *ws, size_t ws_bytes,
+                               gg_stream_t stream) {
+    GG_REQUIRE(num_intersects_dev != nullptr, "null num_intersects_dev");
+    GG_REQUIRE(capacity >= 1, "capacity < 1");
+    return bin_sort_impl(N, capacity, num_intersects_dev, xys, depths, radii, num_tiles_hit, tiles_x,
+                         tiles_y, gaussian_ids_sorted, tile_bins, isect_tile_sorted, ws, ws_bytes, stream);
 }

@@ -394,6 +394,7 @@ extern "C" int gg_cull_mask(int num_points, const float *opacities, const float 
 struct AdamDev {
     float *param, *grad, *exp_avg, *exp_avg_sq;
     long long numel;
+    int vec;   // all four arrays 16-byte aligned: float4 path
     float step_size, bc2_sqrt, w1, w2, beta2, eps, weight_decay;
 };
 struct AdamGroups {
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamGroups G, int zero_grad) 
         const long long e0 = (q - G.start4[k]) * 4;
         const float wd = grp.weight_decay, w1 = grp.w1, w2 = grp.w2, b2 = grp.beta2, ss = grp.step_size,
                     bc = grp.bc2_sqrt, eps = grp.eps;
-        if (e0 + 4 <= grp.numel) {
+        if (grp.vec && e0 + 4 <= grp.numel) {
             float4 p = *reinterpret_cast<float4 *>(grp.param + e0);
             const float4 g = *reinterpret_cast<const float4 *>(grp.grad + e0);
             float4 m = *reinterpret_cast<float4 *>(grp.exp_avg + e0);
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamGroups G, int zero_grad) 
             *reinterpret_cast<float4 *>(grp.exp_avg_sq + e0) = v;
             if (zero_grad) *reinterpret_cast<float4 *>(grp.grad + e0) = make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
-            for (long long e = e0; e < grp.numel; ++e) {
+            for (long long e = e0; e < grp.numel && e < e0 + 4; ++e) {
                 float p = grp.param[e], m = grp.exp_avg[e], v = grp.exp_avg_sq[e];
                 adam_elem(p, grp.grad[e], m, v, wd, w1, w2, b2, ss, bc, eps);
                 grp.param[e] = p;
@@ -461,14 +462,15 @@ extern "C" int gg_adam_step(int num_groups, const gg_adam_group_t *groups, int z
         const gg_adam_group_t &g = groups[k];
         GG_REQUIRE(g.numel >= 0 && g.step >= 1, "numel < 0 or step < 1");
         GG_REQUIRE(g.numel == 0 || (g.param && g.grad && g.exp_avg && g.exp_avg_sq), "null pointer");
-        GG_REQUIRE((((uintptr_t)g.param | (uintptr_t)g.grad | (uintptr_t)g.exp_avg | (uintptr_t)g.exp_avg_sq) & 15) == 0,
-                   "parameter, gradient and moment arrays must be 16-byte aligned");
+        GG_REQUIRE((((uintptr_t)g.param | (uintptr_t)g.grad | (uintptr_t)g.exp_avg | (uintptr_t)g.exp_avg_sq) & 3) == 0,
+                   "parameter, gradient and moment arrays must be 4-byte aligned");
         GG_REQUIRE(g.beta1 >= 0.0 && g.beta1 < 1.0 && g.beta2 >= 0.0 && g.beta2 < 1.0, "betas must be in [0,1)");
         const double bc1 = 1.0 - pow(g.beta1, (double)g.step);
         const double bc2 = 1.0 - pow(g.beta2, (double)g.step);
         AdamDev &d = G.g[k];
         d.param = g.param; d.grad = g.grad; d.exp_avg = g.exp_avg; d.exp_avg_sq = g.exp_avg_sq;
         d.numel = g.numel;
+        d.vec = (((uintptr_t)g.param | (uintptr_t)g.grad | (uintptr_t)g.exp_avg | (uintptr_t)g.exp_avg_sq) & 15) == 0;
         d.step_size = (float)(g.lr / bc1);
         d.bc2_sqrt = (float)sqrt(bc2);
         d.w1 = (float)(1.0 - g.beta1);

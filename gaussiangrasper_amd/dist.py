@@ -52,9 +52,12 @@ class GradBucket:
         for h in self._hooks:
             h.remove()
         self.params = list(params)
-        total = sum(p.numel() for p in self.params)
+        # every slice starts on a 256-byte boundary (vector loads of the fused Adam kernel, whole cache
+        # lines per parameter in the collectives); the padding stays zero
+        pad = lambda n: (n + 63) // 64 * 64
+        self.payload = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat = torch.zeros(sum(pad(p.numel()) for p in self.params), dtype=torch.float32, device=dev)
         self.slices = []
         off = 0
         for p in self.params:
@@ -62,7 +65,7 @@ class GradBucket:
             sl = self.flat[off:off + n]
             p.grad = sl.view_as(p)   # autograd accumulates in place
             self.slices.append(sl)
-            off += n
+            off += pad(n)
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i))
                        for i, p in enumerate(self.params) if p.requires_grad and p.is_leaf]
         self._armed = False
@@ -139,7 +142,12 @@ class GradBucket:
 
     @property
     def nbytes(self) -> int:
-        return self.flat.numel() * 4
+        """gradient bytes reduced per step (without the alignment padding)"""
+        return self.payload * 4
+
+    def gathered(self) -> torch.Tensor:
+        """the gradients back to back, without padding (tests, checkpoints)"""
+        return torch.cat([sl.reshape(-1) for sl in self.slices])
 
 
 def train_step(render_and_backward: Callable[[int], None], bucket: GradBucket, view_ids: Sequence[int],

@@ -93,10 +93,18 @@ def _start_count(num_tiles_hit: Tensor) -> None:
     _pending_counts[(num_tiles_hit.data_ptr(), num_tiles_hit._version)] = (ev, slot, num_tiles_hit, total)
 
 
-def _take_count(num_tiles_hit: Tensor):
-    hit = _pending_counts.pop((num_tiles_hit.data_ptr(), num_tiles_hit._version), None)
+def _pending(num_tiles_hit: Tensor):
+    hit = _pending_counts.get((num_tiles_hit.data_ptr(), num_tiles_hit._version))
     if hit is None or hit[2] is not num_tiles_hit:
         return None
+    return hit
+
+
+def _take_count(num_tiles_hit: Tensor):
+    hit = _pending(num_tiles_hit)
+    if hit is None:
+        return None
+    _pending_counts.pop((num_tiles_hit.data_ptr(), num_tiles_hit._version), None)
     ev, slot, _, _ = hit
     ev.synchronize()
     return int(slot.item())
@@ -209,19 +217,33 @@ class SphericalHarmonics(Function):
 # binning shared by the rasterize calls of one view
 # ------------------------------------------------------------------------------------------------
 class Binning:
-    """Result of compute_cumulative_intersects + bin_and_sort_gaussians for one view."""
-    __slots__ = ("num_intersects", "gaussian_ids_sorted", "tile_bins", "key", "keep")
+    """Result of compute_cumulative_intersects + bin_and_sort_gaussians for one view.
 
-    def __init__(self, num_intersects, gaussian_ids_sorted, tile_bins, key, keep):
+    `num_intersects` may still be unknown to the host when the lists are already being built on the
+    device (speculative capacity, below): `resolve()` waits for the asynchronous read-back of the
+    count — by then the sort and the first blend kernel are queued behind it, so the GPU does not idle —
+    and re-bins with an exact size in the rare case the capacity was too small."""
+    __slots__ = ("num_intersects", "gaussian_ids_sorted", "tile_bins", "key", "keep", "_redo")
+
+    def __init__(self, num_intersects, gaussian_ids_sorted, tile_bins, key, keep, redo=None):
         self.num_intersects = num_intersects
         self.gaussian_ids_sorted = gaussian_ids_sorted
         self.tile_bins = tile_bins
         self.key = key
         self.keep = keep  # the keyed tensors stay alive so data_ptr cannot be recycled
+        self._redo = redo
+
+    def resolve(self) -> bool:
+        """Make `num_intersects` known.  Returns True if the lists had to be rebuilt (whatever was
+        rendered from them must be rendered again)."""
+        if self.num_intersects is not None:
+            return False
+        return self._redo(self)
 
 
 _bin_cache: Optional[Binning] = None
-bin_cache_stats = {"hits": 0, "misses": 0}
+bin_cache_stats = {"hits": 0, "misses": 0, "speculative": 0, "rebinned": 0}
+_capacity_hint = {}     # device index -> list capacity that covered the views seen so far
 
 
 def _bin_key(xys, depths, radii, num_tiles_hit, img_height, img_width):
@@ -234,15 +256,30 @@ def clear_bin_cache() -> None:
     _bin_cache = None
 
 
+def _note_count(dev: torch.device, num_intersects: int) -> None:
+    want = ((int(num_intersects * 1.25) >> 20) + 1) << 20        # 25 % headroom, whole Mi entries
+    if want > _capacity_hint.get(dev.index, 0):
+        _capacity_hint[dev.index] = want
+
+
 def bin_and_sort_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, num_tiles_hit: Tensor,
-                           img_height: int, img_width: int, use_cache: bool = True) -> Binning:
+                           img_height: int, img_width: int, use_cache: bool = True,
+                           speculative: bool = False) -> Binning:
     """Tile lists of one view: Gaussian ids tile-major / near-to-far, and per-tile [start,end).
-    One host sync (the reference's `.item()` on the cumulative count)."""
+
+    The reference reads the intersection count with `.item()` before it can size and launch the sort
+    (SURVEY a5): the GPU drains while the host waits, then idles while the host enqueues.  Here, once a
+    view has been seen, the lists are built with a capacity that covered the previous views (+25 %) and
+    the kernels take the actual count from device memory (gg_bin_sort_dev); the count is read back
+    asynchronously and only checked later (`Binning.resolve`).  `speculative=False` (the default for
+    direct callers) returns with `num_intersects` known."""
     global _bin_cache
     dev = _require_hip(xys, depths, radii, num_tiles_hit)
     key = _bin_key(xys, depths, radii, num_tiles_hit, img_height, img_width)
     if use_cache and _bin_cache is not None and _bin_cache.key == key:
         bin_cache_stats["hits"] += 1
+        if not speculative:
+            _bin_cache.resolve()
         return _bin_cache
     bin_cache_stats["misses"] += 1
     lib = _lib.load()
@@ -251,21 +288,52 @@ def bin_and_sort_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, num_tiles
     tiles_y = (img_height + BLOCK - 1) // BLOCK
     xys_c, depths_c = _f32(xys.detach()), _f32(depths.detach())
     radii_c, nth_c = _i32(radii), _i32(num_tiles_hit)
-    num_intersects = _take_count(num_tiles_hit)       # started by ProjectGaussians.forward
-    if num_intersects is None:                        # tensors that did not come from our projection
-        total = torch.empty(1, dtype=torch.int64, device=dev)
-        _lib.check(lib.gg_count_intersects(n, _ptr(nth_c), _ptr(total), None, 0, _stream(dev)),
-                   "gg_count_intersects")
-        num_intersects = int(total.item())
     tile_bins = torch.empty(tiles_x * tiles_y, 2, dtype=torch.int32, device=dev)
-    ids_sorted = torch.empty(max(num_intersects, 1), dtype=torch.int32, device=dev)
-    ws_bytes = lib.gg_bin_sort_workspace(n, num_intersects)
-    ws = _workspace(ws_bytes, dev)
-    _lib.check(lib.gg_bin_sort(n, num_intersects, _ptr(xys_c), _ptr(depths_c), _ptr(radii_c),
-                               _ptr(nth_c), tiles_x, tiles_y, _ptr(ids_sorted), _ptr(tile_bins),
-                               None, _ptr(ws), ws.numel(), _stream(dev)), "gg_bin_sort")
-    out = Binning(num_intersects, ids_sorted[:num_intersects], tile_bins, key,
-                  (xys, depths, radii, num_tiles_hit))
+    keep = (xys, depths, radii, num_tiles_hit)
+
+    def exact(num_intersects: int) -> Tensor:
+        ids = torch.empty(max(num_intersects, 1), dtype=torch.int32, device=dev)
+        ws = _workspace(lib.gg_bin_sort_workspace(n, num_intersects), dev)
+        _lib.check(lib.gg_bin_sort(n, num_intersects, _ptr(xys_c), _ptr(depths_c), _ptr(radii_c),
+                                   _ptr(nth_c), tiles_x, tiles_y, _ptr(ids), _ptr(tile_bins),
+                                   None, _ptr(ws), ws.numel(), _stream(dev)), "gg_bin_sort")
+        return ids[:num_intersects]
+
+    pending = _pending(num_tiles_hit) if speculative else None
+    cap = _capacity_hint.get(dev.index, 0)
+    if pending is not None and cap > 0:
+        # speculative: sized by what previous views needed, count taken on the device
+        bin_cache_stats["speculative"] += 1
+        total_dev = pending[3]
+        ids = torch.empty(cap, dtype=torch.int32, device=dev)
+        ws = _workspace(lib.gg_bin_sort_workspace(n, cap), dev)
+        _lib.check(lib.gg_bin_sort_dev(n, cap, _ptr(total_dev), _ptr(xys_c), _ptr(depths_c), _ptr(radii_c),
+                                       _ptr(nth_c), tiles_x, tiles_y, _ptr(ids), _ptr(tile_bins),
+                                       None, _ptr(ws), ws.numel(), _stream(dev)), "gg_bin_sort_dev")
+
+        def redo(b: Binning) -> bool:
+            count = _take_count(num_tiles_hit)
+            if count is None:                              # read-back already consumed by another binning
+                count = int(total_dev.item())
+            _note_count(dev, count)
+            b.num_intersects = count
+            if count <= cap:
+                b.gaussian_ids_sorted = ids[:count]
+                return False
+            bin_cache_stats["rebinned"] += 1
+            b.gaussian_ids_sorted = exact(count)
+            return True
+
+        out = Binning(None, ids, tile_bins, key, keep, redo)
+    else:
+        num_intersects = _take_count(num_tiles_hit)       # started by ProjectGaussians.forward
+        if num_intersects is None:                        # tensors that did not come from our projection
+            total = torch.empty(1, dtype=torch.int64, device=dev)
+            _lib.check(lib.gg_count_intersects(n, _ptr(nth_c), _ptr(total), None, 0, _stream(dev)),
+                       "gg_count_intersects")
+            num_intersects = int(total.item())
+        _note_count(dev, num_intersects)
+        out = Binning(num_intersects, exact(num_intersects), tile_bins, key, keep)
     if use_cache:
         _bin_cache = out
     return out
@@ -298,24 +366,36 @@ def _rasterize_forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, o
     xys_c, conics_c = _f32(xys), _f32(conics)
     colors_c, opacity_c, background = _f32(colors), _f32(opacity), _f32(background)
 
-    bins = bin_and_sort_gaussians(xys, depths, radii, num_tiles_hit, img_height, img_width)
-    ctx.num_intersects = bins.num_intersects
+    bins = bin_and_sort_gaussians(xys, depths, radii, num_tiles_hit, img_height, img_width, speculative=True)
     ctx.img = (img_height, img_width)
     ctx.opacity_shape = tuple(opacity.shape)
+    lib = _lib.load()
+    ws = _workspace(lib.gg_blend_workspace(n), dev)
+    out_img = final_Ts = final_idx = None
+    for attempt in range(2):
+        if bins.num_intersects is not None and bins.num_intersects < 1:
+            ctx.num_intersects = bins.num_intersects
+            out_img = torch.ones(img_height, img_width, ch, device=dev) * background
+            ctx.save_for_backward(xys_c, conics_c, colors_c, opacity_c)
+            return out_img
+        if out_img is None:
+            out_img = torch.empty(img_height, img_width, ch, dtype=torch.float32, device=dev)
+            final_Ts = torch.empty(img_height, img_width, dtype=torch.float32, device=dev)
+            final_idx = torch.empty(img_height, img_width, dtype=torch.int32, device=dev)
+        _lib.check(lib.gg_blend_fwd(ch, n, img_height, img_width, _ptr(bins.gaussian_ids_sorted),
+                                    _ptr(bins.tile_bins), _ptr(xys_c), _ptr(conics_c), _ptr(colors_c),
+                                    _ptr(opacity_c), _ptr(background), _ptr(out_img), _ptr(final_Ts),
+                                    _ptr(final_idx), _ptr(ws), ws.numel(), _stream(dev)),
+                   "gg_blend_fwd")
+        # the count of a speculative binning is checked only now, with the blend already queued;
+        # rebuilt lists (capacity too small: rare) mean blending once more
+        if not bins.resolve():
+            break
+    ctx.num_intersects = bins.num_intersects
     if bins.num_intersects < 1:
         out_img = torch.ones(img_height, img_width, ch, device=dev) * background
         ctx.save_for_backward(xys_c, conics_c, colors_c, opacity_c)
         return out_img
-    lib = _lib.load()
-    out_img = torch.empty(img_height, img_width, ch, dtype=torch.float32, device=dev)
-    final_Ts = torch.empty(img_height, img_width, dtype=torch.float32, device=dev)
-    final_idx = torch.empty(img_height, img_width, dtype=torch.int32, device=dev)
-    ws = _workspace(lib.gg_blend_workspace(n), dev)
-    _lib.check(lib.gg_blend_fwd(ch, n, img_height, img_width, _ptr(bins.gaussian_ids_sorted),
-                                _ptr(bins.tile_bins), _ptr(xys_c), _ptr(conics_c), _ptr(colors_c),
-                                _ptr(opacity_c), _ptr(background), _ptr(out_img), _ptr(final_Ts),
-                                _ptr(final_idx), _ptr(ws), ws.numel(), _stream(dev)),
-               "gg_blend_fwd")
     # ws holds the packed per-Gaussian records of this call: the backward reuses them
     ctx.save_for_backward(xys_c, conics_c, colors_c, opacity_c, background,
                           bins.gaussian_ids_sorted, bins.tile_bins, final_Ts, final_idx, ws)

@@ -65,9 +65,6 @@ def _launch(entries, zero_grad: bool) -> None:
             if not (p.is_contiguous() and g.is_contiguous() and st["exp_avg"].is_contiguous()
                     and st["exp_avg_sq"].is_contiguous()):
                 raise RuntimeError("FusedAdam needs contiguous parameters, gradients and moments")
-            for t in (p, g, st["exp_avg"], st["exp_avg_sq"]):
-                if t.data_ptr() % 16:
-                    raise RuntimeError("FusedAdam needs 16-byte aligned tensors")
             keep.append((p, g))
             b1, b2 = group["betas"]
             lr = group["lr"]

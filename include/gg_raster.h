@@ -108,6 +108,18 @@ int gg_bin_sort(int num_points, int64_t num_intersects, const float *xys, const 
                 int32_t *gaussian_ids_sorted, int32_t *tile_bins, int32_t *isect_tile_sorted,
                 void *ws, size_t ws_bytes, gg_stream_t stream);
 
+/* gg_bin_sort_dev: the same without the host knowing the count.  `capacity` sizes the outputs, the
+ * workspace (gg_bin_sort_workspace(num_points, capacity)) and the launches; the kernels read the
+ * actual count from *num_intersects_dev (what gg_count_intersects wrote, same stream) and process
+ * min(count, capacity) entries.  The caller reads the count back later (asynchronously) and, in the
+ * rare case count > capacity (lists truncated), calls again with a larger capacity.  Removes the one
+ * host<->device round trip per view the reference has at this point (`.item()`). */
+int gg_bin_sort_dev(int num_points, int64_t capacity, const int64_t *num_intersects_dev,
+                    const float *xys, const float *depths, const int32_t *radii,
+                    const int32_t *num_tiles_hit, int tiles_x, int tiles_y,
+                    int32_t *gaussian_ids_sorted, int32_t *tile_bins, int32_t *isect_tile_sorted,
+                    void *ws, size_t ws_bytes, gg_stream_t stream);
+
 /* ---- alpha blending ----------------------------------------------------------------------
  * gg_blend_fwd replaces gsplat `_C.rasterize_forward` (C=3) and `_C.nd_rasterize_forward`
  * (any C >= 1).  colors (N,C), opacity (N,) or (N,1), background (C,), out_img (H,W,C),
@@ -209,7 +221,7 @@ int gg_cull_mask(int num_points, const float *opacities, const float *scales, co
 /* One Adam step (torch.optim.Adam, amsgrad off) of up to GG_ADAM_MAX_GROUPS parameter arrays in ONE
  * launch; every group has its own hyper-parameters and step count, as the reference's one optimizer
  * per group does (method_configs.py:618-660: eps 1e-15, lr 1.6e-4 ... 0.05).  step is the step
- * number being taken (>= 1).  Arrays must be 16-byte aligned.  zero_grad != 0 clears the gradients
+ * number being taken (>= 1).  16-byte aligned arrays take the float4 path.  zero_grad != 0 clears the gradients
  * in the same pass.  `groups` is a HOST array. */
 #define GG_ADAM_MAX_GROUPS 8
 typedef struct {

@@ -701,3 +701,46 @@ def test_blend_bwd_c_abi_gradient_layouts(oracle, ch):
                           ptr(ft), ptr(fi), ptr(vt), ptr(rec), ptr(rec), ptr(colt), ptr(rec), 6, 0,
                           ptr(rec), 0, 0, stream)
     assert st != 0
+
+
+def test_speculative_binning_matches_the_exact_path_and_recovers_from_a_small_capacity():
+    """After a first view the rasterize calls build the lists with a capacity instead of waiting for
+    the count (gg_bin_sort_dev): same images and gradients bit for bit; a capacity that turns out too
+    small is detected from the asynchronous count and the view is re-binned and re-blended."""
+    sc, v = _scene_view(60_000, 300, 400, cfg=2)
+    g = sc.to(DEV)
+
+    def run():
+        P.clear_bin_cache()
+        for p in g.params():
+            p.requires_grad_(True)
+            p.grad = None
+        out = render_view(g, ring_cameras(3, 300, 400, device=DEV)[0], P)
+        backward_view(out, seeded_cotangents(out, seed=3))
+        return ({k: out[k].detach().clone() for k in ("rgb", "feature", "depth", "normal")},
+                [p.grad.clone() for p in g.params()])
+
+    P._capacity_hint.clear()
+    stats0 = dict(P.bin_cache_stats)
+    img_a, _ = run()                                   # no hint yet: exact path (host waits for the count)
+    assert P.bin_cache_stats["speculative"] == stats0["speculative"] and P._capacity_hint
+    img_b, _ = run()                                   # speculative
+    assert P.bin_cache_stats["speculative"] == stats0["speculative"] + 1
+    assert P.bin_cache_stats["rebinned"] == stats0["rebinned"]
+    P._capacity_hint[torch.device(DEV).index] = 4096   # far too small -> overflow -> re-bin
+    img_c, _ = run()
+    assert P.bin_cache_stats["rebinned"] == stats0["rebinned"] + 1
+    assert P._capacity_hint[torch.device(DEV).index] > 4096
+    for k in img_a:
+        assert torch.equal(img_a[k], img_b[k]) and torch.equal(img_a[k], img_c[k]), k
+    # the lists themselves: speculative output == exact output
+    xys, depths, radii, conics, nth, _ = P.ProjectGaussians.apply(
+        g.means.detach(), g.scales.detach().exp(), 1, g.quats.detach(), v.viewmat[:3].to(DEV), v.projmat.to(DEV),
+        v.fx, v.fy, v.cx, v.cy, 300, 400, v.tile_bounds)
+    spec = P.bin_and_sort_gaussians(xys, depths, radii, nth, 300, 400, use_cache=False, speculative=True)
+    assert spec.num_intersects is None
+    spec.resolve()
+    exact = P.bin_and_sort_gaussians(xys, depths, radii, nth, 300, 400, use_cache=False)
+    assert spec.num_intersects == exact.num_intersects == int(nth.long().sum())
+    assert torch.equal(spec.gaussian_ids_sorted, exact.gaussian_ids_sorted)
+    assert torch.equal(spec.tile_bins, exact.tile_bins)

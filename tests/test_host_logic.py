@@ -236,12 +236,13 @@ def test_grad_bucket_rebind_after_parameter_replacement():
     ps = [torch.zeros(5, 3, requires_grad=True), torch.zeros(5, 1, requires_grad=True)]
     b = GradBucket(ps)
     (ps[0].sum() * 2 + ps[1].sum() * 3).backward()
-    assert torch.equal(b.flat, torch.cat([torch.full((15,), 2.0), torch.full((5,), 3.0)]))
+    assert torch.equal(b.gathered(), torch.cat([torch.full((15,), 2.0), torch.full((5,), 3.0)]))
+    assert all((sl.data_ptr() - b.flat.data_ptr()) % 256 == 0 for sl in b.slices)
     ps2 = [torch.zeros(7, 3, requires_grad=True), torch.zeros(7, 1, requires_grad=True)]
     b.rebind(ps2)
-    assert b.flat.numel() == 28 and b.nbytes == 112
+    assert b.payload == 28 and b.nbytes == 112
     (ps2[0].sum() + ps2[1].sum() * 5).backward()
-    assert torch.equal(b.flat, torch.cat([torch.ones(21), torch.full((7,), 5.0)]))
+    assert torch.equal(b.gathered(), torch.cat([torch.ones(21), torch.full((7,), 5.0)]))
     ps2[0].grad = torch.zeros(7, 3)        # somebody broke the alias
     b.arm()
     with pytest.raises(RuntimeError, match="no longer aliases"):

@@ -81,6 +81,9 @@ def parse(argv=None):
     ap.add_argument("--no-prof", action="store_true", help="skip the profiled step (no per-kernel times)")
     ap.add_argument("--no-fused", action="store_true", help="skip the secondary fused-path measurement")
     ap.add_argument("--no-overlap", action="store_true", help="one all-reduce after the last view")
+    ap.add_argument("--no-direct", action="store_true",
+                    help="autograd accumulates every parameter gradient (no in-kernel accumulation "
+                         "into the gradient bucket for the SH and feature parameters)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
     ap.add_argument("--device", default="cuda", choices=("cuda", "cpu"))
     ap.add_argument("--ops", default=PRODUCT_OPS, help="operator module (tests only)")
@@ -291,6 +294,9 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
     views = ring_cameras(total_views, args.height, args.width, device=dev)
     my_views = shard_views(total_views, rank, world)
     bucket = GradBucket(scene.params())
+    direct = not args.no_direct and hasattr(ops, "register_grad_sink")
+    if direct:
+        bucket.enable_direct(ops, [scene.colors_all, scene.feature])
     # cotangents resident in HBM, one set reused for every view (dense N(0,1), seeded)
     probe = render_view(scene, views[my_views[0]], ops)
     cot = seeded_cotangents(probe, seed=1234)
@@ -357,6 +363,9 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
                    "n_visible": n_vis, "num_intersects": n_isect,
                    "parallelism": f"view-parallel x{world}, replicated Gaussians",
                    "grad_allreduce_bytes": bucket.nbytes,
+                   "grad_accumulation": "SH and feature gradients added into the step's gradient bucket by "
+                                        "the backward kernels; the other parameters by autograd"
+                                        if direct else "autograd",
                    "grad_allreduce": "per parameter, overlapped with the last view's backward"
                                      if overlap else "one collective after the last view",
                    "backend": args.backend if world > 1 else None},

@@ -41,6 +41,7 @@ SIGNATURES = {
                             _P, _P, _P, _P]),
     "gg_sh_fwd": (_I, [_I, _I, _I, _P, _P, _P, _P]),
     "gg_sh_bwd": (_I, [_I, _I, _I, _P, _P, _P, _P]),
+    "gg_sh_bwd_accumulate": (_I, [_I, _I, _I, _P, _P, _P, _P]),
     "gg_quat_to_rotmat_fwd": (_I, [_I, _P, _P, _P]),
     "gg_quat_to_rotmat_bwd": (_I, [_I, _P, _P, _P, _P]),
     "gg_mlp_fwd": (_I, [_I64, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),

@@ -121,7 +121,9 @@ extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *i
                             const float *final_Ts, const int32_t *final_idx, const float *v_out,
                             float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
                             int geom_stride, int color_stride, void *ws, size_t ws_bytes,
-                            int ws_from_forward, gg_stream_t stream) {
+                            int flags, gg_stream_t stream) {
+    const bool ws_from_forward = (flags & GG_BWD_WS_FROM_FORWARD) != 0;
+    const bool acc_colors = (flags & GG_BWD_ACCUMULATE_COLORS) != 0;
     GG_REQUIRE(C >= 1, "channels < 1");
     GG_REQUIRE(N >= 0, "num_points < 0");
     GG_REQUIRE(img_h > 0 && img_w > 0, "empty image");
@@ -145,6 +147,8 @@ extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *i
     // the caller laid them out back to back: v_xy | v_conic | v_opacity | v_colors)
     GG_REQUIRE(geom_stride == 0 || geom_stride >= 6, "geom_stride must be 0 (dense) or >= 6");
     GG_REQUIRE(color_stride == 0 || color_stride >= C, "color_stride must be 0 (dense) or >= channels");
+    GG_REQUIRE(!acc_colors || !(color_stride == geom_stride && geom_stride > 0 && v_colors == v_xy + 6),
+               "GG_BWD_ACCUMULATE_COLORS needs v_colors outside the interleaved geometry record");
     bool fail;
     const size_t n = (size_t)N;
     if (geom_stride > 0) {
@@ -152,17 +156,18 @@ extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *i
         GG_REQUIRE(v_conic == v_xy + 2 && v_opacity == v_xy + 5, "interleaved geometry gradients: "
                    "v_conic = v_xy + 2 and v_opacity = v_xy + 5 expected");
         fail = hipMemsetAsync(v_xy, 0, sizeof(float) * geom_stride * n, s) != hipSuccess;
-        if (!(color_stride == geom_stride && v_colors == v_xy + 6))   // colours live elsewhere
+        if (!(color_stride == geom_stride && v_colors == v_xy + 6) && !acc_colors)   // colours live elsewhere
             fail |= hipMemsetAsync(v_colors, 0, sizeof(float) * (color_stride ? color_stride : C) * n, s) !=
                     hipSuccess;
-    } else if (color_stride == 0 && v_conic == v_xy + 2 * n && v_opacity == v_conic + 3 * n &&
+    } else if (!acc_colors && color_stride == 0 && v_conic == v_xy + 2 * n && v_opacity == v_conic + 3 * n &&
                v_colors == v_opacity + n) {
         fail = hipMemsetAsync(v_xy, 0, sizeof(float) * (6 + (size_t)C) * n, s) != hipSuccess;
     } else {
         fail = hipMemsetAsync(v_xy, 0, sizeof(float) * 2 * n, s) != hipSuccess;
         fail |= hipMemsetAsync(v_conic, 0, sizeof(float) * 3 * n, s) != hipSuccess;
-        fail |= hipMemsetAsync(v_colors, 0, sizeof(float) * (color_stride ? color_stride : C) * n, s) !=
-                hipSuccess;
+        if (!acc_colors)
+            fail |= hipMemsetAsync(v_colors, 0, sizeof(float) * (color_stride ? color_stride : C) * n, s) !=
+                    hipSuccess;
         fail |= hipMemsetAsync(v_opacity, 0, sizeof(float) * n, s) != hipSuccess;
     }
     if (fail) {

@@ -27,6 +27,24 @@
 #include "blend_common.h"
 
 #define GRP 4          // survivors per loop iteration
+
+#ifdef GG_ABLATION
+// measurement twin only: walk statistics of the forward kernel (tools/walkstats.py)
+//   0 list entries staged   1 survivors of the quadrant cull that were walked   2 of those, with >= 1
+//   blending pixel   3 (pixel, Gaussian) pairs evaluated   4 pairs passing the alpha test   5 pairs blended
+__device__ unsigned long long g_walk_stats[8];
+extern "C" int gg_debug_walk_stats(unsigned long long *out8, int reset) {
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_walk_stats), sizeof(g_walk_stats)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_walk_stats), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define WALK_STAT(i, v) do { if (lane == 0) atomicAdd(&g_walk_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define WALK_STAT(i, v) do { } while (0)
+#endif
 #define LIST_CAP 72    // 4 leading pads + 64 + 4 trailing pads
 
 struct WaveList {
@@ -120,8 +138,10 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
         const int e = base + lane;
         const int cnt = stage_chunk<CH, WIDE>(L, lane, e, e < range.y, ids, rec, colors, C, ch_off,
                                               nch, xlo, xhi, ylo, yhi);
+        WALK_STAT(0, min(64, range.y - base));
         for (int k = 0; k < cnt; k += GRP) {
             if (k > 0 && __ballot(!done) == 0ull) break;
+            WALK_STAT(1, min(GRP, cnt - k));
             float4 A[GRP], B[GRP], Cc[GRP];
 #pragma unroll
             for (int q = 0; q < GRP; ++q) {
@@ -156,6 +176,15 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
                 const bool stop = live && (next_T <= GG_T_EPS);
                 const bool blend = live && !stop;
                 vis[q] = blend ? alpha[q] * T : 0.0f;
+#ifdef GG_ABLATION
+                {
+                    const unsigned long long bm = __ballot(blend), pm = __ballot(pass[q]), lm = __ballot(!done);
+                    WALK_STAT(2, bm != 0ull);
+                    WALK_STAT(3, __builtin_popcountll(lm));
+                    WALK_STAT(4, __builtin_popcountll(pm));
+                    WALK_STAT(5, __builtin_popcountll(bm));
+                }
+#endif
                 T = blend ? next_T : T;
                 last = blend ? __builtin_bit_cast(int, Cc[q].w) : last;
                 done = done || stop;

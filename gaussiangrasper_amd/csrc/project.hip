@@ -375,7 +375,8 @@ __global__ __launch_bounds__(256) void sh_fwd_kernel(int N, int deg,
     }
 }
 
-template <int K>
+// ACC: add to v_coeffs instead of overwriting it (gg_sh_bwd_accumulate: the caller's gradient buffer)
+template <int K, bool ACC = false>
 __global__ __launch_bounds__(256) void sh_bwd_kernel(int N, int deg,
                                                      const float *__restrict__ viewdirs,
                                                      const float *__restrict__ v_colors,
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(int N, int deg,
     }
     __builtin_amdgcn_wave_barrier();
     float *dst = v_coeffs + (size_t)base * ROW;
-    for (int e = lane; e < nrows * ROW; e += 64) dst[e] = st[e];
+    for (int e = lane; e < nrows * ROW; e += 64) dst[e] = ACC ? dst[e] + st[e] : st[e];
 }
 
 // ---- C ABI -----------------------------------------------------------------------------------
@@ -455,18 +456,20 @@ extern "C" int gg_project_bwd(int N, const float *means3d, const float *scales, 
 }
 
 template <int K>
-static void launch_sh(bool fwd, int N, int deg, const float *viewdirs, const float *in, float *out,
+static void launch_sh(bool fwd, bool acc, int N, int deg, const float *viewdirs, const float *in, float *out,
                       hipStream_t s) {
     dim3 grid((N + 255) / 256), block(256);
     const int rows_fwd = 4 * ((K >= 16) ? 32 : 64);   // Gaussians per forward workgroup
     if (fwd)
         hipLaunchKernelGGL(sh_fwd_kernel<K>, dim3((N + rows_fwd - 1) / rows_fwd), block, 0, s, N, deg,
                            viewdirs, in, out);
+    else if (acc)
+        hipLaunchKernelGGL((sh_bwd_kernel<K, true>), grid, block, 0, s, N, deg, viewdirs, in, out);
     else
-        hipLaunchKernelGGL(sh_bwd_kernel<K>, grid, block, 0, s, N, deg, viewdirs, in, out);
+        hipLaunchKernelGGL((sh_bwd_kernel<K, false>), grid, block, 0, s, N, deg, viewdirs, in, out);
 }
 
-static int sh_dispatch(bool fwd, int N, int K, int deg, const float *viewdirs, const float *in,
+static int sh_dispatch(bool fwd, bool acc, int N, int K, int deg, const float *viewdirs, const float *in,
                        float *out, gg_stream_t stream) {
     GG_REQUIRE(N >= 0, "num_points < 0");
     GG_REQUIRE(K == 1 || K == 4 || K == 9 || K == 16 || K == 25, "num_bases must be 1,4,9,16,25");
@@ -476,11 +479,11 @@ static int sh_dispatch(bool fwd, int N, int K, int deg, const float *viewdirs, c
     hipStream_t s = (hipStream_t)stream;
     gg_prof_begin(fwd ? GG_K_SH_FWD : GG_K_SH_BWD, s);
     switch (K) {
-        case 1: launch_sh<1>(fwd, N, deg, viewdirs, in, out, s); break;
-        case 4: launch_sh<4>(fwd, N, deg, viewdirs, in, out, s); break;
-        case 9: launch_sh<9>(fwd, N, deg, viewdirs, in, out, s); break;
-        case 16: launch_sh<16>(fwd, N, deg, viewdirs, in, out, s); break;
-        default: launch_sh<25>(fwd, N, deg, viewdirs, in, out, s); break;
+        case 1: launch_sh<1>(fwd, acc, N, deg, viewdirs, in, out, s); break;
+        case 4: launch_sh<4>(fwd, acc, N, deg, viewdirs, in, out, s); break;
+        case 9: launch_sh<9>(fwd, acc, N, deg, viewdirs, in, out, s); break;
+        case 16: launch_sh<16>(fwd, acc, N, deg, viewdirs, in, out, s); break;
+        default: launch_sh<25>(fwd, acc, N, deg, viewdirs, in, out, s); break;
     }
     gg_prof_end(fwd ? GG_K_SH_FWD : GG_K_SH_BWD, s);
     GG_CHECK_LAUNCH();
@@ -488,11 +491,15 @@ static int sh_dispatch(bool fwd, int N, int K, int deg, const float *viewdirs, c
 }
 extern "C" int gg_sh_fwd(int N, int K, int deg, const float *viewdirs, const float *coeffs,
                          float *colors, gg_stream_t stream) {
-    return sh_dispatch(true, N, K, deg, viewdirs, coeffs, colors, stream);
+    return sh_dispatch(true, false, N, K, deg, viewdirs, coeffs, colors, stream);
 }
 extern "C" int gg_sh_bwd(int N, int K, int deg, const float *viewdirs, const float *v_colors,
                          float *v_coeffs, gg_stream_t stream) {
-    return sh_dispatch(false, N, K, deg, viewdirs, v_colors, v_coeffs, stream);
+    return sh_dispatch(false, false, N, K, deg, viewdirs, v_colors, v_coeffs, stream);
+}
+extern "C" int gg_sh_bwd_accumulate(int N, int K, int deg, const float *viewdirs, const float *v_colors,
+                                    float *v_coeffs, gg_stream_t stream) {
+    return sh_dispatch(false, true, N, K, deg, viewdirs, v_colors, v_coeffs, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -51,6 +51,9 @@ class GradBucket:
         (reference gaussian_splatting.py:434-439,495-500 build new nn.Parameters of a new N)."""
         for h in self._hooks:
             h.remove()
+        direct = getattr(self, "_direct_ops", None)
+        if direct is not None:
+            direct.clear_grad_sinks()
         self.params = list(params)
         # every slice starts on a 256-byte boundary (vector loads of the fused Adam kernel, whole cache
         # lines per parameter in the collectives); the padding stays zero
@@ -74,6 +77,28 @@ class GradBucket:
         self._fired: List[int] = []
         self._ready: List[bool] = []
         self._next = 0
+        if direct is not None:
+            self.enable_direct(direct)
+
+    def enable_direct(self, ops, params: Optional[Sequence[torch.Tensor]] = None) -> None:
+        """Let the operators' backward kernels add into this bucket directly (ops.register_grad_sink)
+        for the given parameters (default: all) — no per-view gradient tensor and no separate add for
+        the parameters that enter an operator as leaves (SH coefficients, features).  The overlapped
+        reduction is driven by the operators' notification instead of autograd's hook for those."""
+        index = {id(p): i for i, p in enumerate(self.params)}
+        for p in (self.params if params is None else params):
+            i = index[id(p)]
+            ops.register_grad_sink(p, self.slices[i].view_as(p), self._make_direct_done(i))
+        self._direct_ops = ops
+
+    def _make_direct_done(self, i: int):
+        def done(param: torch.Tensor) -> None:
+            if not self._armed or self._ready[i]:
+                return
+            self._fired.append(i)
+            self._ready[i] = True
+            self._issue_ready()
+        return done
 
     def _make_hook(self, i: int):
         def hook(param: torch.Tensor) -> None:
@@ -82,9 +107,10 @@ class GradBucket:
             if param.grad is None or param.grad.data_ptr() != self.slices[i].data_ptr():
                 raise RuntimeError("GradBucket: .grad of parameter %d no longer aliases the bucket "
                                    "(call rebind() after replacing parameters)" % i)
-            self._fired.append(i)
-            self._ready[i] = True
-            self._issue_ready()
+            if not self._ready[i]:
+                self._fired.append(i)
+                self._ready[i] = True
+                self._issue_ready()
         return hook
 
     def _issue_ready(self) -> None:

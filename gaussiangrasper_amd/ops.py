@@ -62,6 +62,40 @@ def _workspace(nbytes: int, dev: torch.device) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------------
+# direct gradient accumulation (opt-in; used by dist.GradBucket)
+# ------------------------------------------------------------------------------------------------
+# Over the views of an optimizer step autograd adds every view's parameter gradient into `.grad`: for
+# the two large parameters — SH coefficients (300 B per Gaussian) and features (128 B) — that is a
+# freshly written gradient tensor plus a separate read-modify-write add per view.  When the caller has
+# registered a persistent gradient buffer for a leaf parameter that enters an operator directly
+# (`colors_all` into SphericalHarmonics, `feature` into NDRasterizeGaussians, as at reference
+# :730,:747-753), the backward kernel adds into that buffer itself and returns no gradient for the
+# input.  Off unless a sink is registered: plain autograd semantics otherwise.
+_grad_sinks = {}        # id(param) -> (param, buffer, notify)
+
+
+def register_grad_sink(param: Tensor, buffer: Tensor, notify=None) -> None:
+    """Let the backward kernels accumulate the gradient of leaf `param` straight into `buffer`
+    (same shape, fp32, contiguous); `notify(param)` is called after each accumulation is enqueued."""
+    if not (param.is_leaf and param.requires_grad):
+        raise ValueError("a gradient sink needs a leaf tensor that requires grad")
+    if buffer.shape != param.shape or buffer.dtype != torch.float32 or not buffer.is_contiguous():
+        raise ValueError("sink buffer must be a contiguous fp32 tensor of the parameter's shape")
+    _grad_sinks[id(param)] = (param, buffer, notify)
+
+
+def clear_grad_sinks() -> None:
+    _grad_sinks.clear()
+
+
+def _sink_for(t: Tensor):
+    hit = _grad_sinks.get(id(t))
+    if hit is None or hit[0] is not t:
+        return None
+    return hit
+
+
+# ------------------------------------------------------------------------------------------------
 # intersection count: started right after the projection, read when the first rasterize call needs it
 # ------------------------------------------------------------------------------------------------
 # The reference reads the cumulative tile count with `.item()` inside every rasterize call (SURVEY
@@ -199,6 +233,7 @@ class SphericalHarmonics(Function):
                                  _ptr(colors), _stream(dev)), "gg_sh_fwd")
         ctx.degrees_to_use, ctx.num_bases = int(degrees_to_use), k
         ctx.save_for_backward(viewdirs)
+        ctx.sink = _sink_for(coeffs) if coeffs.dtype == torch.float32 else None
         return colors
 
     @staticmethod
@@ -206,8 +241,16 @@ class SphericalHarmonics(Function):
         (viewdirs,) = ctx.saved_tensors
         dev, n = viewdirs.device, viewdirs.shape[0]
         v_colors = _f32(v_colors)
-        v_coeffs = torch.empty(n, ctx.num_bases, 3, dtype=torch.float32, device=dev)
         lib = _lib.load()
+        if ctx.sink is not None:      # add into the registered gradient buffer, hand autograd nothing
+            param, buf, notify = ctx.sink
+            _lib.check(lib.gg_sh_bwd_accumulate(n, ctx.num_bases, ctx.degrees_to_use, _ptr(viewdirs),
+                                                _ptr(v_colors), _ptr(buf), _stream(dev)),
+                       "gg_sh_bwd_accumulate")
+            if notify is not None:
+                notify(param)
+            return None, None, None
+        v_coeffs = torch.empty(n, ctx.num_bases, 3, dtype=torch.float32, device=dev)
         _lib.check(lib.gg_sh_bwd(n, ctx.num_bases, ctx.degrees_to_use, _ptr(viewdirs),
                                  _ptr(v_colors), _ptr(v_coeffs), _stream(dev)), "gg_sh_bwd")
         return None, None, v_coeffs
@@ -362,6 +405,8 @@ def _rasterize_forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, o
         raise ValueError("opacity must have dimensions (N, 1)")
     dev = _require_hip(xys, depths, radii, conics, num_tiles_hit, colors, opacity, background)
     n, ch = xys.size(0), colors.size(1)
+    # wide colour gradients can go straight into a registered buffer (32-channel rows stay dense)
+    ctx.sink = _sink_for(colors) if (ch > 3 and colors.dtype == torch.float32 and colors.is_contiguous()) else None
     img_height, img_width = int(img_height), int(img_width)
     xys_c, conics_c = _f32(xys), _f32(conics)
     colors_c, opacity_c, background = _f32(colors), _f32(opacity), _f32(background)
@@ -418,13 +463,19 @@ def _rasterize_backward(ctx, v_out_img):
         # record {xy, conic, opacity} (+ the colours for <= 3 channels); the tensors handed back to
         # autograd are strided views of it.  32-channel colour rows stay dense (128-byte rows).
         # (records padded to 64 / 32 bytes so that none straddles a line measure the same.)
+        flags = 1                      # ws holds the forward's packed records
+        sink = getattr(ctx, "sink", None)
         if ch <= 3:
             rec_g = torch.empty(n, 6 + ch, dtype=torch.float32, device=dev)
             v_colors = rec_g[:, 6:]
             gstride = cstride = 6 + ch
         else:
             rec_g = torch.empty(n, 6, dtype=torch.float32, device=dev)
-            v_colors = torch.empty(n, ch, dtype=torch.float32, device=dev)   # own allocation: aligned rows
+            if sink is not None:       # atomics add into the caller's gradient buffer: no memset, no add
+                v_colors = sink[1]
+                flags |= 2
+            else:
+                v_colors = torch.empty(n, ch, dtype=torch.float32, device=dev)   # own allocation: aligned rows
             gstride, cstride = 6, 0
         v_xy, v_conic, v_opacity = rec_g[:, 0:2], rec_g[:, 2:5], rec_g[:, 5:6]
         lib = _lib.load()
@@ -433,7 +484,11 @@ def _rasterize_backward(ctx, v_out_img):
                                     _ptr(opacity), _ptr(background), _ptr(final_Ts),
                                     _ptr(final_idx), _ptr(v_out_img), _ptr(v_xy), _ptr(v_conic),
                                     _ptr(v_colors), _ptr(v_opacity), gstride, cstride, _ptr(ws),
-                                    ws.numel(), 1, _stream(dev)), "gg_blend_bwd")
+                                    ws.numel(), flags, _stream(dev)), "gg_blend_bwd")
+        if flags & 2:
+            v_colors = None
+            if sink[2] is not None:
+                sink[2](sink[0])
     return (v_xy, None, None, v_conic, None, v_colors, v_opacity.reshape(ctx.opacity_shape),
             None, None, None)
 

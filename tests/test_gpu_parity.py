@@ -747,9 +747,9 @@ def test_speculative_binning_matches_the_exact_path_and_recovers_from_a_small_ca
 
 
 def test_direct_gradient_accumulation_equals_autograd_accumulation():
-    """GradBucket.enable_direct: the SH backward adds into the bucket itself (bit-identical to autograd's
-    add, same order of views) and the 32-channel colour atomics land in the bucket (same sums up to
-    the order of the float atomics); hooks / notifications still see every parameter once per backward."""
+    """GradBucket.enable_direct: the SH backward adds into the bucket itself and the 32-channel colour
+    atomics land in the bucket: the same sums as autograd's accumulation, up to the order of the float
+    atomics"""
     from gaussiangrasper_amd.dist import GradBucket, train_step
     views = ring_cameras(3, 200, 300, device=DEV)
     res = []
@@ -771,7 +771,6 @@ def test_direct_gradient_accumulation_equals_autograd_accumulation():
     names = ("means", "scales", "quats", "opacities", "colors_all", "feature")
     for name, a, b in zip(names, res[0], res[1]):
         assert float(a.abs().sum()) > 0, name
-        if name == "colors_all":
-            assert torch.equal(a, b), name
-        else:
-            assert_close(_np(b), _np(a), name, rtol=1e-4, atol_frac=2e-6)
+        # (not bit-equal even for the SH coefficients: their cotangent comes out of the rgb blend
+        # backward, whose float atomics sum in a different order from run to run)
+        assert_close(_np(b), _np(a), name, rtol=1e-4, atol_frac=2e-6)

@@ -336,7 +336,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
         kernels = read_kernel_times(lib)
 
     # secondary measurement (not `value`): same views through the fused single-call path (§8f-1)
-    fused_vps = None
+    fused_vps, fused_kernels = None, {}
     if not args.no_fused and not selftest:
         def render_and_backward_fused(v):
             out = render_view(scene, views[v], ops, fused=True)
@@ -344,6 +344,12 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
         train_step(render_and_backward_fused, bucket, my_views, overlap=overlap)   # warm-up
         tf = timed(render_and_backward_fused, args.steps)
         fused_vps = total_views * args.steps / tf
+        if lib is not None and not args.no_prof:
+            lib.gg_prof_reset()
+            lib.gg_prof_enable(1)
+            timed(render_and_backward_fused, 1)
+            lib.gg_prof_enable(0)
+            fused_kernels = read_kernel_times(lib)
 
     views_done = total_views * args.steps
     ms_per_view_rank = 1e3 * elapsed / (args.steps * args.views_per_step)
@@ -380,6 +386,9 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
             result["kernel_ms_per_view"] = tot / args.views_per_step
         result["fused_single_call_path"] = None if fused_vps is None else {
             "value": fused_vps, "unit": "views/s",
+            "kernels": {k: round(v["avg_ms"], 4) for k, v in sorted(fused_kernels.items())},
+            "kernel_ms_per_view": sum(v["total_ms"] for v in fused_kernels.values()) / args.views_per_step
+            if fused_kernels else None,
             "note": "same views and gradients through ONE NDRasterize call on feature|rgb|depth|normal "
                     "(SURVEY 8f-1; what gaussiangrasper_amd.plugin registers as a nerfstudio method); "
                     "NOT the headline: the headline is the reference's unchanged 4-call sequence"}

@@ -45,6 +45,9 @@ SIGNATURES = {
     "gg_quat_to_rotmat_fwd": (_I, [_I, _P, _P, _P]),
     "gg_quat_to_rotmat_bwd": (_I, [_I, _P, _P, _P, _P]),
     "gg_mlp_fwd": (_I, [_I64, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "gg_mlp_bwd": (_I, [_I64, _I, _I, _I] + [_P] * 11),
+    "gg_cosine_loss_fwd": (_I, [_I64, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "gg_cosine_loss_bwd": (_I, [_I64, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gg_count_workspace": (_SZ, [_I]),
     "gg_count_intersects": (_I, [_I, _P, _P, _P, _SZ, _P]),
     "gg_bin_sort_workspace": (_SZ, [_I, _I64]),

@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libgg_raster.so")
-SOURCES = ["project.hip", "binning.hip", "blend.hip", "blend2.hip", "mlp.hip", "densify.hip", "prof.hip"]
+SOURCES = ["project.hip", "binning.hip", "blend.hip", "blend2.hip", "mlp.hip", "losses.hip", "densify.hip", "prof.hip"]
 FLAGS = ["-O3", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17",
          "-Wall", "-Wno-unused-function"]
 

@@ -64,7 +64,9 @@ void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, 
 // (A 64-channel-per-walk variant — two 32-column MFMA blocks, V_OUT operands streamed per flush —
 // was built and measured: 231 VGPRs / occupancy 2 backward, 143 registers forward; the fused
 // 39-channel call ran at 98 views/s against 122 with two 32-channel walks, so it was dropped.)
-static int chunk_width(int remaining) { return remaining <= 3 ? remaining : 32; }
+// 4..8 remaining channels (the rgb | depth | normal tail of a fused call) go to the 8-wide narrow
+// kernels: on the wide kernels such a tail cost as much as a full 32-channel chunk.
+static int chunk_width(int remaining) { return remaining <= 3 ? remaining : remaining <= 8 ? 8 : 32; }
 
 #ifdef GG_ABLATION
 // Measurement build only (libgg_raster_abl.so, tools/kbench.py): level > 0 makes the backward run an

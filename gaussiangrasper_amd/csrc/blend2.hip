@@ -47,11 +47,17 @@ extern "C" int gg_debug_walk_stats(unsigned long long *out8, int reset) {
 #endif
 #define LIST_CAP 72    // 4 leading pads + 64 + 4 trailing pads
 
-struct WaveList {
-    float4 a[LIST_CAP];  // x, y, opacity, (unused)
-    float4 b[LIST_CAP];  // conic a, b, c, (unused)
-    float4 c[LIST_CAP];  // narrow: colours 0..2 ; wide: .x = Gaussian id (int bits). .w = list position + 1
+// NC: colour float4s per record.  <= 3 channels: c = colours 0..2 and .w = list position; 8-channel
+// narrow kernels (the 4..8-channel tail of a fused call: rgb | depth | normal behind 32 feature
+// channels): c = colours 0..3, d = colours 4..7 and the position moves to a.w.
+template <int NC = 1>
+struct WaveListT {
+    float4 a[LIST_CAP];  // x, y, opacity, (cut-off; NC == 2: list position)
+    float4 b[LIST_CAP];  // conic a, b, c, Gaussian id (int bits)
+    float4 c[LIST_CAP];  // narrow: colours 0..2(3) ; wide: .x = Gaussian id (int bits). NC == 1: .w = list position
+    float4 d[NC == 2 ? LIST_CAP : 1];
 };
+typedef WaveListT<1> WaveList;
 
 __device__ __forceinline__ int lane_prefix(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -59,8 +65,8 @@ __device__ __forceinline__ int lane_prefix(uint64_t m) {
 
 // Stage one chunk: returns the survivor count; list[OFF + k] = k-th survivor in list order,
 // GRP null records (opacity 0 -> never pass) on both sides.
-template <int CH, bool WIDE, bool REL = false>
-__device__ __forceinline__ int stage_chunk(WaveList &L, int lane, int e, bool valid,
+template <int CH, bool WIDE, bool REL = false, typename LIST = WaveList>
+__device__ __forceinline__ int stage_chunk(LIST &L, int lane, int e, bool valid,
                                            const int32_t *__restrict__ ids,
                                            const GRec *__restrict__ rec,
                                            const float *__restrict__ colors, int C, int ch_off, int nch,
@@ -74,7 +80,9 @@ __device__ __forceinline__ int stage_chunk(WaveList &L, int lane, int e, bool va
     const int pos = GRP + lane_prefix(m);
     if (hit) {
         // .w: forward = list position + 1 (final_idx); backward = position inside the chunk
-        float4 cc = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, REL ? lane : e + 1));
+        const float posf = __builtin_bit_cast(float, REL ? lane : e + 1);
+        float4 cc = make_float4(0.f, 0.f, 0.f, posf);
+        float4 ra2 = ra;
         if (WIDE) {
             cc.x = __builtin_bit_cast(float, g);
         } else {
@@ -82,8 +90,18 @@ __device__ __forceinline__ int stage_chunk(WaveList &L, int lane, int e, bool va
             cc.x = col[0];
             if (CH > 1 && nch > 1) cc.y = col[1];
             if (CH > 2 && nch > 2) cc.z = col[2];
+            if (CH > 3) {   // 8-channel records: the position lives in a.w
+                cc.w = nch > 3 ? col[3] : 0.f;
+                float4 dd = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (nch > 4) dd.x = col[4];
+                if (nch > 5) dd.y = col[5];
+                if (nch > 6) dd.z = col[6];
+                if (nch > 7) dd.w = col[7];
+                L.d[pos] = dd;
+                ra2.w = posf;
+            }
         }
-        L.a[pos] = ra;
+        L.a[pos] = ra2;
         L.b[pos] = make_float4(rb.x, rb.y, rb.z, __builtin_bit_cast(float, g));  // .w = Gaussian id
         L.c[pos] = cc;
     }
@@ -92,6 +110,7 @@ __device__ __forceinline__ int stage_chunk(WaveList &L, int lane, int e, bool va
         L.a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         L.b[q] = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, -1));
         L.c[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (CH > 3 && !WIDE) L.d[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __builtin_amdgcn_wave_barrier();
     return cnt;
@@ -107,12 +126,14 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
     const float *__restrict__ colors, const float *__restrict__ background,
     float *__restrict__ out_img, float *__restrict__ final_T, int32_t *__restrict__ final_idx,
     int write_final) {
-    __shared__ WaveList lists[4];
+    constexpr bool N8 = !WIDE && CH > 3;          // 8-channel narrow record layout
+    typedef WaveListT<N8 ? 2 : 1> LIST;
+    __shared__ LIST lists[4];
     const int tile = xcd_tile(blockIdx.x, ntiles);
     if (tile < 0) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    WaveList &L = lists[wave];
+    LIST &L = lists[wave];
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int qx0 = tx * GG_BLOCK + (wave & 1) * 8, qy0 = ty * GG_BLOCK + (wave >> 1) * 8;
     const int j = qx0 + (lane & 7), i = qy0 + (lane >> 3);
@@ -136,18 +157,19 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
     for (int base = range.x; base < range.y; base += 64) {
         if (__ballot(!done) == 0ull) break;
         const int e = base + lane;
-        const int cnt = stage_chunk<CH, WIDE>(L, lane, e, e < range.y, ids, rec, colors, C, ch_off,
-                                              nch, xlo, xhi, ylo, yhi);
+        const int cnt = stage_chunk<CH, WIDE, false, LIST>(L, lane, e, e < range.y, ids, rec, colors, C,
+                                                           ch_off, nch, xlo, xhi, ylo, yhi);
         WALK_STAT(0, min(64, range.y - base));
         for (int k = 0; k < cnt; k += GRP) {
             if (k > 0 && __ballot(!done) == 0ull) break;
             WALK_STAT(1, min(GRP, cnt - k));
-            float4 A[GRP], B[GRP], Cc[GRP];
+            float4 A[GRP], B[GRP], Cc[GRP], Cd[GRP];
 #pragma unroll
             for (int q = 0; q < GRP; ++q) {
                 A[q] = L.a[GRP + k + q];
                 B[q] = L.b[GRP + k + q];
                 Cc[q] = L.c[GRP + k + q];
+                if (N8) Cd[q] = L.d[GRP + k + q];
             }
             float colB[GRP / 2];
             if (WIDE) {
@@ -186,12 +208,19 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
                 }
 #endif
                 T = blend ? next_T : T;
-                last = blend ? __builtin_bit_cast(int, Cc[q].w) : last;
+                last = blend ? __builtin_bit_cast(int, N8 ? A[q].w : Cc[q].w) : last;
                 done = done || stop;
                 if (!WIDE) {
                     acc[0] = __builtin_fmaf(Cc[q].x, vis[q], acc[0]);
                     if (CH > 1) acc[CH > 1 ? 1 : 0] = __builtin_fmaf(Cc[q].y, vis[q], acc[CH > 1 ? 1 : 0]);
                     if (CH > 2) acc[CH > 2 ? 2 : 0] = __builtin_fmaf(Cc[q].z, vis[q], acc[CH > 2 ? 2 : 0]);
+                    if (N8) {
+                        acc[CH > 3 ? 3 : 0] = __builtin_fmaf(Cc[q].w, vis[q], acc[CH > 3 ? 3 : 0]);
+                        acc[CH > 4 ? 4 : 0] = __builtin_fmaf(Cd[q].x, vis[q], acc[CH > 4 ? 4 : 0]);
+                        acc[CH > 5 ? 5 : 0] = __builtin_fmaf(Cd[q].y, vis[q], acc[CH > 5 ? 5 : 0]);
+                        acc[CH > 6 ? 6 : 0] = __builtin_fmaf(Cd[q].z, vis[q], acc[CH > 6 ? 6 : 0]);
+                        acc[CH > 7 ? 7 : 0] = __builtin_fmaf(Cd[q].w, vis[q], acc[CH > 7 ? 7 : 0]);
+                    }
                 }
             }
             if (WIDE) {
@@ -256,7 +285,7 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
 #define KEEP(x) asm volatile("" ::"v"(x))
 template <int CH, int ABL = 0>
 __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
-    int C, int ch_off, int img_h, int img_w, int tiles_x, int ntiles,
+    int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
     const float *__restrict__ colors, const float *__restrict__ background,
     const float *__restrict__ final_T, const int32_t *__restrict__ final_idx,
@@ -265,13 +294,15 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
     constexpr int K = CH + 6;       // per-Gaussian values: CH colours, xy(2), conic(3), opacity(1)
     constexpr int KB = GRP * K;     // butterfly width
     using R = Red6<KB>;
-    __shared__ WaveList lists[4];
+    constexpr bool N8 = CH > 3;
+    typedef WaveListT<N8 ? 2 : 1> LIST;
+    __shared__ LIST lists[4];
 
     const int tile = xcd_tile(blockIdx.x, ntiles);
     if (tile < 0) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    WaveList &L = lists[wave];
+    LIST &L = lists[wave];
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int qx0 = tx * GG_BLOCK + (wave & 1) * 8, qy0 = ty * GG_BLOCK + (wave >> 1) * 8;
     const int j = qx0 + (lane & 7), i = qy0 + (lane >> 3);
@@ -290,8 +321,9 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
         float Bsum = 0.0f;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            vo[c] = inside ? v_out[p * C + ch_off + c] : 0.0f;
-            Bsum = __builtin_fmaf(background[ch_off + c], vo[c], Bsum);
+            const bool chan = !N8 || c < nch;      // the 8-wide kernel also serves 4..7 channels
+            vo[c] = (inside && chan) ? v_out[p * C + ch_off + c] : 0.0f;
+            if (chan) Bsum = __builtin_fmaf(background[ch_off + c], vo[c], Bsum);
         }
         W = T_final * Bsum;
     }
@@ -307,7 +339,11 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
     int my_stride;      // floats per Gaussian in that array
     // gstride / cstride: floats between consecutive Gaussians in the geometry / colour gradient
     // arrays (0 = dense 2 | 3 | 1 | C); interleaved records put all of a Gaussian's atomics on one line
-    if (my_k < CH) { my_base = v_colors + ch_off + my_k; my_stride = cstride ? cstride : C; }
+    if (my_k < CH) {
+        my_base = v_colors + ch_off + my_k;
+        my_stride = cstride ? cstride : C;
+        owner = owner && (!N8 || my_k < nch);      // channels past nch belong to the next row
+    }
     else if (my_k < CH + 2) { my_base = v_xy + (my_k - CH); my_stride = gstride ? gstride : 2; }
     else if (my_k < CH + 5) { my_base = v_conic + (my_k - CH - 2); my_stride = gstride ? gstride : 3; }
     else { my_base = v_opacity; my_stride = gstride ? gstride : 1; }
@@ -315,17 +351,18 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
     for (int top = hi; top > range.x; top -= 64) {
         const int e = top - 64 + lane;
         const bool valid = e >= range.x;
-        const int cnt = stage_chunk<CH, false, true>(L, lane, e, valid, ids, rec, colors, C, ch_off,
-                                                     CH, xlo, xhi, ylo, yhi);
+        const int cnt = stage_chunk<CH, false, true, LIST>(L, lane, e, valid, ids, rec, colors, C, ch_off,
+                                                           N8 ? nch : CH, xlo, xhi, ylo, yhi);
         const int fin_rel = fin - (top - 64);  // entries at chunk position >= fin_rel are not mine
         if (ABL >= 4) { KEEP(cnt); continue; }
         for (int kk = GRP + cnt - 1; kk >= GRP; kk -= GRP) {
-            float4 A[GRP], B[GRP], Cc[GRP];
+            float4 A[GRP], B[GRP], Cc[GRP], Cd[GRP];
 #pragma unroll
             for (int q = 0; q < GRP; ++q) {
                 A[q] = L.a[kk - q];
                 B[q] = L.b[kk - q];
                 Cc[q] = L.c[kk - q];
+                if (N8) Cd[q] = L.d[kk - q];
             }
             float vis[GRP], alpha[GRP], dxs[GRP], dys[GRP];
             bool pass[GRP];
@@ -339,7 +376,7 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
                 vis[q] = gg_expf(-sigma);
                 alpha[q] = fminf(GG_ALPHA_MAX_BWD, A[q].z * vis[q]);
                 // .w = position inside the chunk; null pads have opacity 0 -> alpha 0 -> no pass
-                pass[q] = (__builtin_bit_cast(int, Cc[q].w) < fin_rel) && sigma >= 0.0f &&
+                pass[q] = (__builtin_bit_cast(int, N8 ? A[q].w : Cc[q].w) < fin_rel) && sigma >= 0.0f &&
                           !(alpha[q] < GG_ALPHA_MIN);
             }
             if (__ballot(pass[0] || pass[1] || pass[2] || pass[3]) == 0ull) continue;
@@ -358,6 +395,13 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
                 float D = Cc[q].x * vo[0];
                 if (CH > 1) D = __builtin_fmaf(Cc[q].y, vo[CH > 1 ? 1 : 0], D);
                 if (CH > 2) D = __builtin_fmaf(Cc[q].z, vo[CH > 2 ? 2 : 0], D);
+                if (N8) {
+                    D = __builtin_fmaf(Cc[q].w, vo[CH > 3 ? 3 : 0], D);
+                    D = __builtin_fmaf(Cd[q].x, vo[CH > 4 ? 4 : 0], D);
+                    D = __builtin_fmaf(Cd[q].y, vo[CH > 5 ? 5 : 0], D);
+                    D = __builtin_fmaf(Cd[q].z, vo[CH > 6 ? 6 : 0], D);
+                    D = __builtin_fmaf(Cd[q].w, vo[CH > 7 ? 7 : 0], D);
+                }
 #pragma unroll
                 for (int c = 0; c < CH; ++c) part[q * K + c] = fac * vo[c];
                 const float v_alpha = pass[q] ? (Tn * D - ra_ * W) : 0.0f;
@@ -605,13 +649,15 @@ void gg_launch_blend2_fwd(int width, int C, int off, int n, int img_h, int img_w
         hipLaunchKernelGGL((blend2_fwd_kernel<2, false, true>), grid, block, 0, s, B2_FWD_ARGS);
     else if (width == 3)
         hipLaunchKernelGGL((blend2_fwd_kernel<3, false, true>), grid, block, 0, s, B2_FWD_ARGS);
+    else if (width == 8)
+        hipLaunchKernelGGL((blend2_fwd_kernel<8, false, true>), grid, block, 0, s, B2_FWD_ARGS);
     else if (n == 32)
         hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true>), grid, block, 0, s, B2_FWD_ARGS);
     else
         hipLaunchKernelGGL((blend2_fwd_kernel<32, true, false>), grid, block, 0, s, B2_FWD_ARGS);
 }
 
-#define B2_BWDN_ARGS C, off, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, \
+#define B2_BWDN_ARGS C, off, n, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, \
                      final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, gstride, cstride
 void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w, int tiles_x,
                           int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
@@ -625,6 +671,8 @@ void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w
         hipLaunchKernelGGL((blend2_bwd_narrow_kernel<2>), grid, block, 0, s, B2_BWDN_ARGS);
     else if (width == 3)
         hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3>), grid, block, 0, s, B2_BWDN_ARGS);
+    else if (width == 8)
+        hipLaunchKernelGGL((blend2_bwd_narrow_kernel<8>), grid, block, 0, s, B2_BWDN_ARGS);
 #define B2_BWDW_ARGS C, off, n, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, \
                      final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, gstride, cstride
     else if (n == 32)
@@ -645,6 +693,7 @@ void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, 
                                  const int32_t *final_idx, const float *v_out, float *v_xy,
                                  float *v_conic, float *v_colors, float *v_opacity, int gstride, int cstride, hipStream_t s) {
     dim3 grid(gg_tile_grid(ntiles)), block(256);
+    const int n = 3;   // B2_BWDN_ARGS: the ablated narrow builds are the 3-channel ones
     switch (abl) {
 #define B2_WABL(L) hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, L>), grid, block, 0, s, C, off, 32, \
         img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, final_Ts, final_idx, v_out, \

@@ -6,8 +6,10 @@ pixel of the rendered feature image by render.sh at nerfstudio/pipelines/base_pi
 
 Same constructor, same sub-module layout (`layers = Sequential(Linear, ReLU, Linear)`, so reference
 checkpoints' `fea_up.layers.{0,2}.{weight,bias}` load unchanged) and same call.  The forward is ONE
-fused fp32 MFMA kernel (csrc/mlp.hip) behind `gg_mlp_fwd`; there is no CPU path.  The backward (only
-the 1000-point training use needs it) recomputes the hidden layer and uses plain library GEMMs."""
+fused fp32 MFMA kernel (csrc/mlp.hip) behind `gg_mlp_fwd`; there is no CPU path.  The backward at the
+reference's training size (1000 sampled pixels, :917) is ONE launch of `gg_mlp_bwd` (csrc/losses.hip);
+above `NATIVE_BWD_MAX_ROWS` rows the weight gradients are plain GEMMs and go to the library, as does a
+first layer wider than the fused forward kernel holds in registers (in_dim 128: BASELINE config 5)."""
 from __future__ import annotations
 
 from typing import Sequence
@@ -20,7 +22,9 @@ from . import _lib
 from .ops import _f32, _ptr, _require_hip, _stream
 
 HIDDEN = 128
-SUPPORTED_IN = (8, 16, 32, 64)
+SUPPORTED_IN = (8, 16, 32, 64)          # fused forward kernel (W1 in registers)
+SUPPORTED_IN_BWD = (8, 16, 32, 64, 128)
+NATIVE_BWD_MAX_ROWS = 1 << 16
 
 
 class _MLPForward(Function):
@@ -35,10 +39,13 @@ class _MLPForward(Function):
             raise ValueError(f"x has {x.shape[-1]} features, the first layer takes {in_dim}")
         x2 = _f32(x).reshape(-1, in_dim)
         w1c, b1c, w2c, b2c = _f32(w1), _f32(b1), _f32(w2), _f32(b2)
-        y = torch.empty(x2.shape[0], out_dim, dtype=torch.float32, device=dev)
-        _lib.check(_lib.load().gg_mlp_fwd(x2.shape[0], in_dim, HIDDEN, out_dim, _ptr(x2), _ptr(w1c),
-                                          _ptr(b1c), _ptr(w2c), _ptr(b2c), _ptr(y), _stream(dev)),
-                   "gg_mlp_fwd")
+        if in_dim in SUPPORTED_IN and out_dim % 32 == 0:
+            y = torch.empty(x2.shape[0], out_dim, dtype=torch.float32, device=dev)
+            _lib.check(_lib.load().gg_mlp_fwd(x2.shape[0], in_dim, HIDDEN, out_dim, _ptr(x2), _ptr(w1c),
+                                              _ptr(b1c), _ptr(w2c), _ptr(b2c), _ptr(y), _stream(dev)),
+                       "gg_mlp_fwd")
+        else:   # plain GEMMs: the library's job (hipBLASLt)
+            y = torch.addmm(b2c, torch.relu(torch.addmm(b1c, x2, w1c.t())), w2c.t())
         ctx.save_for_backward(x2, w1c, b1c, w2c)
         ctx.x_shape = x.shape
         return y.reshape(x.shape[:-1] + (out_dim,))
@@ -47,6 +54,16 @@ class _MLPForward(Function):
     def backward(ctx, v_y: Tensor):
         x2, w1, b1, w2 = ctx.saved_tensors
         g = _f32(v_y).reshape(-1, w2.shape[0])
+        rows, in_dim, out_dim = x2.shape[0], w1.shape[1], w2.shape[0]
+        if rows <= NATIVE_BWD_MAX_ROWS and in_dim in SUPPORTED_IN_BWD and out_dim <= 1024:
+            dev = x2.device
+            v_x, v_w1, v_b1 = torch.empty_like(x2), torch.empty_like(w1), torch.empty_like(b1)
+            v_w2 = torch.empty_like(w2)
+            v_b2 = torch.empty(out_dim, dtype=torch.float32, device=dev)
+            _lib.check(_lib.load().gg_mlp_bwd(rows, in_dim, HIDDEN, out_dim, _ptr(x2), _ptr(w1), _ptr(b1),
+                                              _ptr(w2), _ptr(g), _ptr(v_x), _ptr(v_w1), _ptr(v_b1), _ptr(v_w2),
+                                              _ptr(v_b2), _stream(dev)), "gg_mlp_bwd")
+            return v_x.reshape(ctx.x_shape), v_w1, v_b1, v_w2, v_b2
         h_pre = torch.addmm(b1, x2, w1.t())
         g_h = (g @ w2) * (h_pre > 0)
         v_w2 = g.t() @ torch.relu(h_pre)
@@ -64,11 +81,10 @@ class MLP(nn.Module):
     def __init__(self, in_dim: int = 8, out_dim: int = 512, hidden_list: Sequence[int] = (128,)):
         super().__init__()
         hidden_list = list(hidden_list)
-        if hidden_list != [HIDDEN] or in_dim not in SUPPORTED_IN or out_dim % 32 != 0:
+        if hidden_list != [HIDDEN]:
             raise NotImplementedError(
-                "the fused kernel covers the reference's fea_up shape family: one hidden layer of 128, "
-                f"in_dim in {SUPPORTED_IN}, out_dim a multiple of 32 (got in={in_dim}, "
-                f"hidden={hidden_list}, out={out_dim})")
+                "the kernels cover the reference's fea_up shape family: one hidden layer of 128 "
+                f"(got hidden={hidden_list})")
         self.layers = nn.Sequential(nn.Linear(in_dim, HIDDEN), nn.ReLU(), nn.Linear(HIDDEN, out_dim))
 
     def forward(self, x: Tensor) -> Tensor:

@@ -168,6 +168,27 @@ int gg_mlp_fwd(int64_t num_rows, int in_dim, int hidden_dim, int out_dim, const 
                const float *w1, const float *b1, const float *w2, const float *b2, float *y,
                gg_stream_t stream);
 
+/* Backward of the same module (the reference evaluates fea_up on 1000 sampled pixels per training
+ * step, gaussian_splatting.py:917): g = dL/dy (num_rows, out_dim) -> v_x (num_rows, in_dim), v_w1 (128,
+ * in_dim), v_b1 (128), v_w2 (out_dim, 128), v_b2 (out_dim), all fully written.  in_dim 8..128, out_dim
+ * <= 1024.  Sized for 10^3-10^5 rows (one launch, row tiles through LDS, float atomics for the weight
+ * gradients); for the 1.9 M-pixel render pass a library GEMM is the right tool. */
+int gg_mlp_bwd(int64_t num_rows, int in_dim, int hidden_dim, int out_dim, const float *x,
+               const float *w1, const float *b1, const float *w2, const float *g, float *v_x,
+               float *v_w1, float *v_b1, float *v_w2, float *v_b2, gg_stream_t stream);
+
+/* ---- cosine-similarity loss --------------------------------------------------------
+ * Replace the reference's `cosine_similarity_loss` (gaussian_splatting.py:113-118; contrastive feature
+ * loss over 800 pixel pairs per mask :909-914, `up_loss` :917-918) for a, b stored (num_points,
+ * channels): sim_m = <a_m, b_m> / (max(|a_m|, 1e-12) max(|b_m|, 1e-12)); *sim_sum = sum_m sim_m (the
+ * loss is 1 - sim_sum / num_points).  sim / norm_a / norm_b (num_points,) are kept for the backward,
+ * which takes v_loss from device memory (1 float) and writes v_a, v_b (num_points, channels). */
+int gg_cosine_loss_fwd(int64_t num_points, int channels, const float *a, const float *b, float *sim,
+                       float *norm_a, float *norm_b, float *sim_sum, gg_stream_t stream);
+int gg_cosine_loss_bwd(int64_t num_points, int channels, const float *a, const float *b,
+                       const float *sim, const float *norm_a, const float *norm_b,
+                       const float *v_loss, float *v_a, float *v_b, gg_stream_t stream);
+
 /* ---- densification, culling and the optimizer step ---------------------------------
  * The per-Gaussian optimizer-side work of the reference model, which it does with torch indexing,
  * torch.cat and one torch.optim.Adam per parameter group:
@@ -253,6 +274,7 @@ int gg_adam_step(int num_groups, const gg_adam_group_t *groups, int zero_grad, g
 #define GG_K_QUAT_FWD 6
 #define GG_K_QUAT_BWD 7
 #define GG_K_MLP_FWD 8
+#define GG_K_MLP_BWD 9
 #define GG_K_BLEND_FWD 10 /* + width index: template widths {1,3,4,8,16,32} -> 0..5 */
 #define GG_K_BLEND_BWD 20 /* + width index */
 #define GG_K_COMPACT 26

@@ -979,3 +979,90 @@ void NAME(cull_mask)(int N, const REAL *opacities, const REAL *scales, const REA
         mask[i] = (uint8_t)cull;
     }
 }
+
+/* ==========================================================================================
+ * SURVEY 8f-2, second half: the backward of the fea_up MLP and the cosine-similarity loss.
+ * Pinned against torch autograd of the published code (tests/test_mlp_losses.py).
+ * ======================================================================================== */
+
+/* VJP of y = W2 relu(W1 x + b1) + b2 (reference MLP, gaussian_splatting.py:198-213), g = dL/dy (P,out):
+ *   v_x (P,in), v_w1 (128,in), v_b1 (128), v_w2 (out,128), v_b2 (out); parameter gradients are summed
+ *   over the rows in row order (doubles in both builds: the GPU's atomics give another order anyway). */
+void NAME(mlp_bwd)(int64_t P, int in_dim, int out_dim, const REAL *x, const REAL *w1, const REAL *b1,
+                   const REAL *w2, const REAL *g, REAL *v_x, REAL *v_w1, REAL *v_b1, REAL *v_w2, REAL *v_b2) {
+    enum { HID = 128 };
+    double *aw1 = (double *)calloc((size_t)HID * in_dim, sizeof(double));
+    double *aw2 = (double *)calloc((size_t)out_dim * HID, sizeof(double));
+    double *ab1 = (double *)calloc(HID, sizeof(double)), *ab2 = (double *)calloc((size_t)out_dim, sizeof(double));
+    for (int64_t p = 0; p < P; ++p) {
+        const REAL *xp = x + (size_t)p * in_dim, *gp = g + (size_t)p * out_dim;
+        REAL h[HID], gh[HID];
+        for (int j = 0; j < HID; ++j) {
+            REAL acc = b1[j];
+            for (int k = 0; k < in_dim; ++k) acc = FMA(w1[(size_t)j * in_dim + k], xp[k], acc);
+            h[j] = acc;
+        }
+        for (int j = 0; j < HID; ++j) {
+            REAL acc = R_(0.0f);
+            for (int o = 0; o < out_dim; ++o) acc = FMA(gp[o], w2[(size_t)o * HID + j], acc);
+            gh[j] = h[j] > R_(0.0f) ? acc : R_(0.0f);
+        }
+        for (int k = 0; k < in_dim; ++k) {
+            REAL acc = R_(0.0f);
+            for (int j = 0; j < HID; ++j) acc = FMA(gh[j], w1[(size_t)j * in_dim + k], acc);
+            v_x[(size_t)p * in_dim + k] = acc;
+        }
+        for (int j = 0; j < HID; ++j) {
+            ab1[j] += (double)gh[j];
+            for (int k = 0; k < in_dim; ++k) aw1[(size_t)j * in_dim + k] += (double)gh[j] * (double)xp[k];
+        }
+        for (int o = 0; o < out_dim; ++o) {
+            ab2[o] += (double)gp[o];
+            for (int j = 0; j < HID; ++j)
+                aw2[(size_t)o * HID + j] += (double)gp[o] * (double)(h[j] > R_(0.0f) ? h[j] : R_(0.0f));
+        }
+    }
+    for (int i = 0; i < HID * in_dim; ++i) v_w1[i] = (REAL)aw1[i];
+    for (int i = 0; i < out_dim * HID; ++i) v_w2[i] = (REAL)aw2[i];
+    for (int i = 0; i < HID; ++i) v_b1[i] = (REAL)ab1[i];
+    for (int i = 0; i < out_dim; ++i) v_b2[i] = (REAL)ab2[i];
+    free(aw1); free(aw2); free(ab1); free(ab2);
+}
+
+/* cosine_similarity_loss (gaussian_splatting.py:113-118) on M points of C channels, a and b stored
+ * (M,C) — the reference passes the (C,M) transposes and normalises along dim 0, i.e. per point:
+ *   sim_m = <a_m, b_m> / (max(|a_m|, 1e-12) max(|b_m|, 1e-12)),  loss = 1 - mean_m sim_m.
+ * Saves sim, |a|, |b| for the backward. */
+REAL NAME(cosine_loss_fwd)(int64_t M, int C, const REAL *a, const REAL *b, REAL *sim, REAL *na, REAL *nb) {
+    double total = 0.0;
+    for (int64_t m = 0; m < M; ++m) {
+        REAL dot = R_(0.0f), sa = R_(0.0f), sb = R_(0.0f);
+        for (int c = 0; c < C; ++c) {
+            const REAL u = a[(size_t)m * C + c], v = b[(size_t)m * C + c];
+            dot = FMA(u, v, dot);
+            sa = FMA(u, u, sa);
+            sb = FMA(v, v, sb);
+        }
+        na[m] = SQRT(sa);
+        nb[m] = SQRT(sb);
+        sim[m] = dot / (FMAX(na[m], R_(1e-12f)) * FMAX(nb[m], R_(1e-12f)));
+        total += (double)sim[m];
+    }
+    return (REAL)(1.0 - total / (double)(M > 0 ? M : 1));
+}
+
+/* v_a, v_b for v_loss = dL/d loss */
+void NAME(cosine_loss_bwd)(int64_t M, int C, const REAL *a, const REAL *b, const REAL *sim, const REAL *na,
+                           const REAL *nb, REAL v_loss, REAL *v_a, REAL *v_b) {
+    const REAL s = -v_loss / (REAL)(M > 0 ? M : 1);
+    for (int64_t m = 0; m < M; ++m) {
+        const REAL ca = FMAX(na[m], R_(1e-12f)), cb = FMAX(nb[m], R_(1e-12f));
+        const int fa = na[m] > R_(1e-12f), fb = nb[m] > R_(1e-12f);   /* clamp active: norm is a constant */
+        for (int c = 0; c < C; ++c) {
+            const REAL u = a[(size_t)m * C + c], v = b[(size_t)m * C + c];
+            const REAL ua = u / ca, vb = v / cb;
+            v_a[(size_t)m * C + c] = s * (vb - (fa ? sim[m] * ua : R_(0.0f))) / ca;
+            v_b[(size_t)m * C + c] = s * (ua - (fb ? sim[m] * vb : R_(0.0f))) / cb;
+        }
+    }
+}

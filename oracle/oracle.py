@@ -347,3 +347,42 @@ def cull_mask(opacities, scales, max_2dsize, alpha_thresh, scale_thresh, screen_
                                     RT(scale_thresh), RT(screen_thresh), C.c_int(int(use_scale)),
                                     C.c_int(int(use_screen)), _p(out))
     return out.astype(bool)
+
+
+# ------------------------------------------------------------------------------------------------
+# SURVEY 8f-2 second half: MLP backward, cosine-similarity loss (pinned to torch autograd in tests)
+# ------------------------------------------------------------------------------------------------
+def mlp_bwd(x, w1, b1, w2, g, dtype=np.float32):
+    """-> (v_x, v_w1, v_b1, v_w2, v_b2) of y = W2 relu(W1 x + b1) + b2 for g = dL/dy."""
+    lib, pre, _ = _lib(dtype)
+    x, g = _c(x, dtype), _c(g, dtype)
+    shape = x.shape
+    x, g = x.reshape(-1, shape[-1]), g.reshape(-1, g.shape[-1])
+    w1, b1, w2 = _c(w1, dtype), _c(b1, dtype), _c(w2, dtype)
+    v_x, v_w1, v_b1 = np.empty_like(x), np.empty_like(w1), np.empty_like(b1)
+    v_w2, v_b2 = np.empty_like(w2), np.empty(w2.shape[0], dtype)
+    getattr(lib, pre + "mlp_bwd")(C.c_int64(x.shape[0]), C.c_int(x.shape[1]), C.c_int(w2.shape[0]), _p(x), _p(w1),
+                                  _p(b1), _p(w2), _p(g), _p(v_x), _p(v_w1), _p(v_b1), _p(v_w2), _p(v_b2))
+    return v_x.reshape(shape), v_w1, v_b1, v_w2, v_b2
+
+
+def cosine_loss_fwd(a, b, dtype=np.float32):
+    """a, b (M,C) -> (loss, sim (M,), |a| (M,), |b| (M,)); reference cosine_similarity_loss :113-118."""
+    lib, pre, RT = _lib(dtype)
+    a, b = _c(a, dtype), _c(b, dtype)
+    m, c = a.shape
+    sim, na, nb = np.empty(m, dtype), np.empty(m, dtype), np.empty(m, dtype)
+    fn = getattr(lib, pre + "cosine_loss_fwd")
+    fn.restype = RT
+    loss = fn(C.c_int64(m), C.c_int(c), _p(a), _p(b), _p(sim), _p(na), _p(nb))
+    return float(loss), sim, na, nb
+
+
+def cosine_loss_bwd(a, b, sim, na, nb, v_loss, dtype=np.float32):
+    lib, pre, RT = _lib(dtype)
+    a, b = _c(a, dtype), _c(b, dtype)
+    m, c = a.shape
+    v_a, v_b = np.empty_like(a), np.empty_like(b)
+    getattr(lib, pre + "cosine_loss_bwd")(C.c_int64(m), C.c_int(c), _p(a), _p(b), _p(_c(sim, dtype)),
+                                          _p(_c(na, dtype)), _p(_c(nb, dtype)), RT(v_loss), _p(v_a), _p(v_b))
+    return v_a, v_b

@@ -1,0 +1,129 @@
+"""SURVEY 8f-2, second half: backward of the fea_up MLP and the cosine-similarity loss.  Both are
+pinnable: the reference code is plain torch (nerfstudio/models/gaussian_splatting.py:113-118,198-213),
+restated here in two lines each and differentiated by torch autograd."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+def ref_cosine_similarity_loss(e1, e2):          # gaussian_splatting.py:113-118
+    e1, e2 = F.normalize(e1, dim=0), F.normalize(e2, dim=0)
+    return 1 - torch.sum(e1 * e2, dim=0).mean()
+
+
+def ref_mlp(x, w1, b1, w2, b2):                  # MLP.forward :198-213 (Linear, ReLU, Linear)
+    return F.linear(F.relu(F.linear(x, w1, b1)), w2, b2)
+
+
+def _mlp_case(p, in_dim, out_dim, seed, dtype=torch.float64):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g, dtype=dtype)
+    return r(p, in_dim), r(128, in_dim) * 0.2, r(128) * 0.1, r(out_dim, 128) * 0.1, r(out_dim) * 0.1, r(p, out_dim)
+
+
+@pytest.mark.parametrize("p,in_dim,out_dim", [(1, 8, 32), (37, 32, 512), (100, 128, 64)])
+def test_oracle_mlp_backward_matches_torch_autograd(oracle, p, in_dim, out_dim):
+    x, w1, b1, w2, b2, g = _mlp_case(p, in_dim, out_dim, seed=p)
+    leaves = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    ref_mlp(*leaves).backward(g)
+    got = oracle.mlp_bwd(x.numpy(), w1.numpy(), b1.numpy(), w2.numpy(), g.numpy(), dtype=np.float64)
+    for name, a, t in zip(("v_x", "v_w1", "v_b1", "v_w2", "v_b2"), got, leaves):
+        assert np.allclose(a, t.grad.numpy(), rtol=1e-10, atol=1e-12), name
+    got32 = oracle.mlp_bwd(*(t.float().numpy() for t in (x, w1, b1, w2, g)))
+    for name, a, t in zip(("v_x", "v_w1", "v_b1", "v_w2", "v_b2"), got32, leaves):
+        ref = t.grad.numpy()
+        assert np.abs(a - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), name
+
+
+@pytest.mark.parametrize("m,c", [(1, 3), (800, 32), (1000, 512)])
+def test_oracle_cosine_loss_matches_torch_autograd(oracle, m, c):
+    g = torch.Generator().manual_seed(m + c)
+    a = torch.randn(m, c, generator=g, dtype=torch.float64)
+    b = torch.randn(m, c, generator=g, dtype=torch.float64)
+    if m > 2:
+        a[1] = 0.0                      # F.normalize's eps clamp: zero vector, zero gradient through the norm
+    ta, tb = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    loss = ref_cosine_similarity_loss(ta.permute(1, 0), tb.permute(1, 0))
+    (loss * 1.7).backward()
+    l, sim, na, nb = oracle.cosine_loss_fwd(a.numpy(), b.numpy(), dtype=np.float64)
+    assert abs(l - loss.item()) < 1e-12
+    va, vb = oracle.cosine_loss_bwd(a.numpy(), b.numpy(), sim, na, nb, 1.7, dtype=np.float64)
+    assert np.allclose(va, ta.grad.numpy(), rtol=1e-7, atol=1e-14)      # the zero row: gradients ~ b / eps = 1e9
+    assert np.allclose(vb, tb.grad.numpy(), rtol=1e-7, atol=1e-14)
+    l32, *_ = oracle.cosine_loss_fwd(a.float().numpy(), b.float().numpy())
+    assert abs(l32 - loss.item()) < 2e-6
+
+
+def test_product_modules_refuse_cpu_tensors():
+    from gaussiangrasper_amd.losses import cosine_similarity_loss
+    from gaussiangrasper_amd.mlp import MLP
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cosine_similarity_loss(torch.randn(8, 5), torch.randn(8, 5))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        MLP(32, 512, [128])(torch.randn(4, 32))
+    with pytest.raises(NotImplementedError):
+        MLP(32, 512, [64])
+    MLP(128, 512, [128])     # BASELINE config 5's first layer: accepted (library GEMMs on the device)
+
+
+DEV = "cuda:0"
+gpu = pytest.mark.gpu
+
+
+@gpu
+@pytest.mark.parametrize("p,in_dim,out_dim", [(1, 32, 512), (1000, 32, 512), (777, 8, 96), (4099, 64, 512),
+                                              (300, 128, 512)])
+def test_gpu_mlp_backward_vs_oracle_and_autograd(oracle, p, in_dim, out_dim):
+    from gaussiangrasper_amd.mlp import mlp_forward
+    x, w1, b1, w2, b2, g = (t.float() for t in _mlp_case(p, in_dim, out_dim, seed=3 * p))
+    dl = [t.clone().to(DEV).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    y = mlp_forward(*dl)
+    y.backward(g.to(DEV))
+    rl = [t.clone().double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    ref_mlp(*rl).backward(g.double())
+    want = oracle.mlp_bwd(x.numpy(), w1.numpy(), b1.numpy(), w2.numpy(), g.numpy())
+    for name, t, r, o in zip(("v_x", "v_w1", "v_b1", "v_w2", "v_b2"), dl, rl, want):
+        got, ref = t.grad.cpu().numpy().astype(np.float64), r.grad.numpy()
+        scale = max(1.0, np.abs(ref).max())
+        assert np.abs(got - ref).max() <= 3e-5 * scale, name          # fp32 sums vs fp64 autograd
+        assert np.abs(got - o).max() <= 3e-5 * scale, name            # and vs the oracle
+
+
+@gpu
+def test_gpu_mlp_backward_large_row_count_uses_the_library_and_agrees():
+    from gaussiangrasper_amd import mlp as M
+    x, w1, b1, w2, b2, g = (t.float().to(DEV) for t in _mlp_case(3000, 32, 512, seed=5))
+    res = []
+    for cap in (1 << 16, 16):        # native kernel, then the GEMM path
+        M.NATIVE_BWD_MAX_ROWS = cap
+        leaves = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+        M.mlp_forward(*leaves).backward(g)
+        res.append([t.grad.clone() for t in leaves])
+    M.NATIVE_BWD_MAX_ROWS = 1 << 16
+    for a, b in zip(*res):
+        assert torch.allclose(a, b, rtol=1e-4, atol=2e-5 * float(b.abs().max()))
+
+
+@gpu
+@pytest.mark.parametrize("m,c", [(1, 3), (800, 32), (1000, 512), (5000, 7)])
+def test_gpu_cosine_loss_vs_oracle_and_autograd(oracle, m, c):
+    from gaussiangrasper_amd.losses import cosine_similarity_loss
+    g = torch.Generator().manual_seed(m * c)
+    a, b = torch.randn(m, c, generator=g), torch.randn(m, c, generator=g)
+    if m > 2:
+        a[1] = 0.0
+    da, db = a.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
+    loss = cosine_similarity_loss(da.permute(1, 0), db.permute(1, 0))       # the reference's (C, M) call shape
+    (loss * 1.7).backward()
+    ta, tb = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = ref_cosine_similarity_loss(ta.permute(1, 0), tb.permute(1, 0))
+    (ref * 1.7).backward()
+    assert abs(loss.item() - ref.item()) < 3e-6
+    l, sim, na, nb = oracle.cosine_loss_fwd(a.numpy(), b.numpy())
+    assert abs(loss.item() - l) < 3e-6
+    va, vb = oracle.cosine_loss_bwd(a.numpy(), b.numpy(), sim, na, nb, 1.7)
+    for got, r, o in ((da.grad, ta.grad, va), (db.grad, tb.grad, vb)):
+        gg = got.cpu().numpy()
+        assert np.allclose(gg, r.numpy(), rtol=2e-5, atol=1e-9)
+        assert np.allclose(gg, o, rtol=2e-5, atol=1e-9)

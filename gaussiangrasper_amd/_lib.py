@@ -103,6 +103,16 @@ def load(build_if_missing: bool = True):
     return lib
 
 
+def load_variant(path: str):
+    """A separately typed handle on a VARIANT build of the library (tests / tools only: the compat and
+    ablation twins).  Never becomes the library the operators use."""
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
 def check(status: int, what: str) -> None:
     if status != 0:
         msg = load().gg_last_error().decode("utf-8", "replace")

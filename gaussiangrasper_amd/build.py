@@ -48,8 +48,20 @@ def build_ablation(verbose: bool = False) -> str:
     return build(force=True, verbose=verbose, extra_flags=("-DGG_ABLATION",), out=ABL_OUT)
 
 
+COMPAT_OUT = os.path.join(HERE, "libgg_raster_compat.so")
+COMPAT_FLAGS = ("-DGG_VJP_GSPLAT_COMPAT=1", "-DGG_ALPHA_MAX_BWD=0.99f")
+
+
+def build_compat(verbose: bool = False) -> str:
+    """Variant with the recalled gsplat-0.1.0 deviations switched on (include/gg_constants.h, PARITY.md):
+    tests/test_compat_variant.py holds it to the oracle built with the same switches.  Not the product."""
+    return build(force=True, verbose=verbose, extra_flags=COMPAT_FLAGS, out=COMPAT_OUT)
+
+
 if __name__ == "__main__":
-    if "--ablation" in sys.argv:
+    if "--compat" in sys.argv:
+        print(build_compat(verbose=True))
+    elif "--ablation" in sys.argv:
         print(build_ablation(verbose=True))
     else:
         build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or True)

@@ -174,7 +174,11 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
         float vnx = (0.5f * (float)img_w) * v_xy[2 * i];
         float vny = (0.5f * (float)img_h) * v_xy[2 * i + 1];
         float vhx = vnx * rw, vhy = vny * rw;
+#if GG_VJP_GSPLAT_COMPAT
+        float vhw = 0.0f * hx * hy;   // compat: the homogeneous-w path is dropped
+#else
         float vhw = -((vnx * hx + vny * hy) * (rw * rw));
+#endif
 #pragma unroll
         for (int j = 0; j < 3; ++j) vm[j] += (P[j] * vhx + P[4 + j] * vhy) + P[12 + j] * vhw;
         // (2) depth
@@ -213,10 +217,16 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
         float tan_fovx = (0.5f * (float)img_w) / fx, tan_fovy = (0.5f * (float)img_h) / fy;
         float lim_x = GG_FOV_LIM * tan_fovx, lim_y = GG_FOV_LIM * tan_fovy;
         float rx = tx / tz, ry = ty / tz;
+#if GG_VJP_GSPLAT_COMPAT
+        // compat: the Jacobian of the backward is rebuilt at the unclamped point, no clamp derivative
+        float sgx = 0.0f * rx * lim_x, sgy = 0.0f * ry * lim_y;
+        float txc = tx, tyc = ty;
+#else
         float sgx = (rx > lim_x) ? 1.0f : ((rx < -lim_x) ? -1.0f : 0.0f);
         float sgy = (ry > lim_y) ? 1.0f : ((ry < -lim_y) ? -1.0f : 0.0f);
         float txc = tz * fminf(lim_x, fmaxf(-lim_x, rx));
         float tyc = tz * fminf(lim_y, fmaxf(-lim_y, ry));
+#endif
         float rz = 1.0f / tz, rz2 = rz * rz, rz3 = rz2 * rz;
         float J00 = fx * rz, J02 = (-(fx * txc)) * rz2, J11 = fy * rz, J12 = (-(fy * tyc)) * rz2;
         float Tm[6] = {J00 * V[0] + J02 * V[8], J00 * V[1] + J02 * V[9], J00 * V[2] + J02 * V[10],
@@ -282,7 +292,11 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
                         ((-2.0f * z) * (G[0] + G[4]) + w * (G[3] - G[1])));
         float dotp = ((qn[0] * vq[0] + qn[1] * vq[1]) + qn[2] * vq[2]) + qn[3] * vq[3];
 #pragma unroll
+#if GG_VJP_GSPLAT_COMPAT
+        for (int k = 0; k < 4; ++k) vq4[k] = vq[k] + 0.0f * dotp * inv_norm;   // w.r.t. the normalised q
+#else
         for (int k = 0; k < 4; ++k) vq4[k] = (vq[k] - qn[k] * dotp) * inv_norm;
+#endif
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {

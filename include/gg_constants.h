@@ -26,9 +26,22 @@
 
 /* ---- blending ---- */
 #define GG_ALPHA_MAX_FWD 0.999f
+#ifndef GG_ALPHA_MAX_BWD /* -DGG_ALPHA_MAX_BWD=0.99f: the "compat" variant build (PARITY.md) */
 #define GG_ALPHA_MAX_BWD 0.999f /* †† least certain: early gsplat may have used 0.99 */
+#endif
 #define GG_ALPHA_MIN (1.0f / 255.0f)
 #define GG_T_EPS 1e-4f /* stop when T*(1-alpha) <= 1e-4; that Gaussian is not blended */
+
+/* ---- where gsplat 0.1.0 is RECALLED to deviate from exact calculus (PARITY.md) ----
+ * 0 (default): exact VJPs of the forward.  1: the recalled gsplat-0.1.0 behaviour — project_pix_vjp
+ * drops the homogeneous-w path, the EWA Jacobian VJP is taken at the UNCLAMPED view-space point, the
+ * quaternion gradient is the one w.r.t. the normalised components.  The "compat" variant libraries
+ * (libgg_raster_compat.so, libgg_oracle_compat_*.so) are built with 1 and GG_ALPHA_MAX_BWD=0.99f, and
+ * tests/test_compat_variant.py holds them to each other, so that a later session holding the gsplat
+ * source flips a constant here, not code. */
+#ifndef GG_VJP_GSPLAT_COMPAT
+#define GG_VJP_GSPLAT_COMPAT 0
+#endif
 
 /* ---- spherical harmonics (3DGS sign convention) ---- */
 #define GG_SH_C0 0.28209479177387814f

@@ -329,7 +329,11 @@ void NAME(project_bwd)(int N, const REAL *means, const REAL *scales, REAL glob_s
         REAL vnx = (R_(0.5f) * (REAL)img_w) * v_xy[2 * i];
         REAL vny = (R_(0.5f) * (REAL)img_h) * v_xy[2 * i + 1];
         REAL vhx = vnx * rw, vhy = vny * rw;
+#if GG_VJP_GSPLAT_COMPAT
+        REAL vhw = R_(0.0f) * hx * hy; /* compat: the homogeneous-w path is dropped */
+#else
         REAL vhw = -((vnx * hx + vny * hy) * (rw * rw));
+#endif
         for (int j = 0; j < 3; ++j) vm[j] += (P[j] * vhx + P[4 + j] * vhy) + P[12 + j] * vhw;
 
         /* (2) depth = row 2 of viewmat */
@@ -365,10 +369,15 @@ void NAME(project_bwd)(int N, const REAL *means, const REAL *scales, REAL glob_s
         REAL tan_fovx = (R_(0.5f) * (REAL)img_w) / fx, tan_fovy = (R_(0.5f) * (REAL)img_h) / fy;
         REAL lim_x = R_(GG_FOV_LIM) * tan_fovx, lim_y = R_(GG_FOV_LIM) * tan_fovy;
         REAL rx = tx / tz, ry = ty / tz;
+#if GG_VJP_GSPLAT_COMPAT
+        int clx = 0, cly = 0; /* compat: Jacobian rebuilt at the unclamped point, no clamp derivative */
+        REAL txc = tx + R_(0.0f) * rx * lim_x, tyc = ty + R_(0.0f) * ry * lim_y;
+#else
         int clx = (rx > lim_x) ? 1 : ((rx < -lim_x) ? -1 : 0);
         int cly = (ry > lim_y) ? 1 : ((ry < -lim_y) ? -1 : 0);
         REAL txc = tz * FMIN(lim_x, FMAX(-lim_x, rx));
         REAL tyc = tz * FMIN(lim_y, FMAX(-lim_y, ry));
+#endif
         REAL rz = R_(1.0f) / tz, rz2 = rz * rz, rz3 = rz2 * rz;
         REAL J00 = fx * rz, J02 = (-(fx * txc)) * rz2, J11 = fy * rz, J12 = (-(fy * tyc)) * rz2;
         REAL Tm[6] = {J00 * V[0] + J02 * V[8], J00 * V[1] + J02 * V[9], J00 * V[2] + J02 * V[10],
@@ -438,7 +447,11 @@ void NAME(project_bwd)(int N, const REAL *means, const REAL *scales, REAL glob_s
                             ((R_(-2.0f) * z) * (G[0] + G[4]) + w * (G[3] - G[1])));
         /* through q/|q| */
         REAL dotp = ((qn[0] * vq[0] + qn[1] * vq[1]) + qn[2] * vq[2]) + qn[3] * vq[3];
+#if GG_VJP_GSPLAT_COMPAT
+        for (int k = 0; k < 4; ++k) v_quat[4 * i + k] = vq[k] + R_(0.0f) * dotp * inv_norm;
+#else
         for (int k = 0; k < 4; ++k) v_quat[4 * i + k] = (vq[k] - qn[k] * dotp) * inv_norm;
+#endif
     }
 }
 

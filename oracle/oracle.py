@@ -28,14 +28,25 @@ def build(force: bool = False) -> None:
     subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
 
 
+VARIANT = ""        # "" = the default constants; "compat" = the recalled gsplat-0.1.0 deviations on
+
+
+def use_variant(name: str) -> None:
+    """Select which build of the oracle the functions below call ("" or "compat"; see the Makefile)."""
+    global VARIANT
+    assert name in ("", "compat")
+    VARIANT = name
+
+
 def _lib(dtype):
-    key = "f64" if np.dtype(dtype) == np.float64 else "f32"
+    key = ("compat_" if VARIANT == "compat" else "") + ("f64" if np.dtype(dtype) == np.float64 else "f32")
     if key not in _LIBS:
         path = os.path.join(_HERE, f"libgg_oracle_{key}.so")
         if not os.path.exists(path):
             build()
         _LIBS[key] = C.CDLL(path)
-    return _LIBS[key], ("ggo64_" if key == "f64" else "ggo_"), (C.c_double if key == "f64" else C.c_float)
+    f64 = key.endswith("f64")
+    return _LIBS[key], ("ggo64_" if f64 else "ggo_"), (C.c_double if f64 else C.c_float)
 
 
 def _p(a):

@@ -19,3 +19,31 @@ def oracle():
     from oracle import oracle as O
     O.build()
     return O
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Achieved-error statistics of the toleranced GPU comparisons (tests/test_gpu_parity.py
+    assert_close): printed, and written where a gpurun call brings them back."""
+    mod = sys.modules.get("test_gpu_parity")
+    stats = getattr(mod, "ERROR_STATS", None) if mod else None
+    if not stats:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "grad_errors.json"), "w") as f:
+            json.dump(stats, f, indent=0)
+    except OSError:
+        pass
+    worst = {}
+    for s in stats:
+        key = s["what"].split("[")[0]
+        w = worst.setdefault(key, {"max_abs_over_scale": 0.0, "rel_p999": 0.0, "rel_max": 0.0, "rtol": s["rtol"],
+                                   "atol_frac": s["atol_frac"]})
+        for k in ("max_abs_over_scale", "rel_p999", "rel_max"):
+            w[k] = max(w[k], s[k])
+    print("\nachieved errors of the toleranced comparisons (worst over all cases):")
+    for key, w in sorted(worst.items()):
+        print(f"  {key:40s} max|err|/max|ref| {w['max_abs_over_scale']:.2e}  rel p99.9 {w['rel_p999']:.2e}  "
+              f"rel max {w['rel_max']:.2e}   (allowed rtol {w['rtol']:g} + {w['atol_frac']:g} max|ref|)")

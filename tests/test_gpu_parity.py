@@ -57,12 +57,24 @@ def assert_bitexact(a, b, what):
                              f"{np.nanmax(d):.3e}; first at {bad[0]}: {a[tuple(bad[0])]} vs {b[tuple(bad[0])]}")
 
 
+ERROR_STATS = []     # achieved errors of every assert_close (written to gpurun_out/grad_errors.json)
+
+
 def assert_close(a, b, what, rtol, atol_frac):
-    """|a-b| <= atol_frac*max|b| + rtol*|b|"""
+    """|a-b| <= atol_frac*max|b| + rtol*|b|.  Also records what was ACHIEVED: the largest absolute
+    error as a fraction of max|b|, and the 99.9th percentile / maximum of the relative error over the
+    elements with |b| >= 1 % of max|b| (the tolerances in this file are set from those numbers)."""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     scale = np.abs(b).max() if b.size else 0.0
-    err = np.abs(a - b) - rtol * np.abs(b)
+    diff = np.abs(a - b)
+    err = diff - rtol * np.abs(b)
     worst = err.max() if err.size else 0.0
+    if b.size and scale > 0:
+        big = np.abs(b) >= 1e-2 * scale
+        rel = diff[big] / np.abs(b)[big] if big.any() else np.zeros(1)
+        ERROR_STATS.append({"what": what, "n": int(b.size), "max_abs_over_scale": float(diff.max() / scale),
+                            "rel_p999": float(np.quantile(rel, 0.999)), "rel_max": float(rel.max()),
+                            "rtol": rtol, "atol_frac": atol_frac})
     assert worst <= atol_frac * scale + 1e-30, \
         f"{what}: max excess err {worst:.3e} vs allowed {atol_frac * scale:.3e} (scale {scale:.3e})"
 

@@ -126,6 +126,7 @@ extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *i
                             int flags, gg_stream_t stream) {
     const bool ws_from_forward = (flags & GG_BWD_WS_FROM_FORWARD) != 0;
     const bool acc_colors = (flags & GG_BWD_ACCUMULATE_COLORS) != 0;
+    const bool acc_geom = (flags & GG_BWD_ACCUMULATE_GEOM) != 0;
     GG_REQUIRE(C >= 1, "channels < 1");
     GG_REQUIRE(N >= 0, "num_points < 0");
     GG_REQUIRE(img_h > 0 && img_w > 0, "empty image");
@@ -153,7 +154,17 @@ extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *i
                "GG_BWD_ACCUMULATE_COLORS needs v_colors outside the interleaved geometry record");
     bool fail;
     const size_t n = (size_t)N;
-    if (geom_stride > 0) {
+    if (acc_geom) {
+        // a later segment of a multi-segment call: the geometry gradients (and colours that live in
+        // the same record) keep what the earlier segments added; separate colour arrays are cleared
+        GG_REQUIRE(geom_stride == 0 || (v_conic == v_xy + 2 && v_opacity == v_xy + 5),
+                   "interleaved geometry gradients: v_conic = v_xy + 2 and v_opacity = v_xy + 5 expected");
+        fail = false;
+        const bool in_record = geom_stride > 0 && color_stride == geom_stride && v_colors == v_xy + 6;
+        if (!in_record && !acc_colors)
+            fail = hipMemsetAsync(v_colors, 0, sizeof(float) * (color_stride ? color_stride : C) * n, s) !=
+                   hipSuccess;
+    } else if (geom_stride > 0) {
         // interleaved records {xy, conic, opacity[, colours]} of geom_stride floats per Gaussian
         GG_REQUIRE(v_conic == v_xy + 2 && v_opacity == v_xy + 5, "interleaved geometry gradients: "
                    "v_conic = v_xy + 2 and v_opacity = v_xy + 5 expected");

@@ -525,6 +525,136 @@ class NDRasterizeGaussians(Function):
 
 
 # ------------------------------------------------------------------------------------------------
+# several colour arrays from one binning (what the plugin's fused model calls)
+# ------------------------------------------------------------------------------------------------
+class RasterizeSegments(Function):
+    """apply(xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width,
+             colors_0, background_0, colors_1, background_1, ...) -> (image_0, image_1, ...)
+
+    The blend of K colour arrays (N, C_k) over the SAME Gaussians in one operator: one binning, one
+    record packing, one `final_T / final_idx`, ONE set of geometry gradients (v_xy, v_conic, v_opacity
+    accumulated by every segment's backward kernel into one record, GG_BWD_ACCUMULATE_GEOM) — what the
+    reference's four rasterize calls (:735-784) compute, without their redundancy and without
+    concatenating the colours: each array keeps its own storage (a 32-channel feature array keeps its
+    128-byte aligned rows and, as a leaf, its gradient sink), each image is its own tensor.
+    Images are bit-identical to NDRasterizeGaussians on each array."""
+
+    @staticmethod
+    def forward(ctx, xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, *segs):
+        if len(segs) < 2 or len(segs) % 2:
+            raise ValueError("expected colors_0, background_0[, colors_1, background_1, ...]")
+        if xys.ndimension() != 2 or xys.size(1) != 2:
+            raise ValueError("xys must have dimensions (N, 2)")
+        if opacity.ndimension() != 2 or opacity.size(1) != 1:
+            raise ValueError("opacity must have dimensions (N, 1)")
+        cols, bgs = list(segs[0::2]), list(segs[1::2])
+        dev = _require_hip(xys, depths, radii, conics, num_tiles_hit, opacity, *cols, *bgs)
+        n = xys.size(0)
+        img_height, img_width = int(img_height), int(img_width)
+        for c, b in zip(cols, bgs):
+            if c.ndimension() != 2 or c.size(0) != n:
+                raise ValueError("colors must have dimensions (N, D)")
+            assert b.shape[0] == c.shape[1], f"incorrect shape of background color tensor, expected shape {c.shape[1]}"
+        xys_c, conics_c, opacity_c = _f32(xys), _f32(conics), _f32(opacity)
+        cols_c, bgs_c = [_f32(c) for c in cols], [_f32(b) for b in bgs]
+        ctx.sinks = [(_sink_for(c) if (c.shape[1] > 8 and c.dtype == torch.float32 and c.is_contiguous()) else None)
+                     for c in cols]
+        bins = bin_and_sort_gaussians(xys, depths, radii, num_tiles_hit, img_height, img_width, speculative=True)
+        lib = _lib.load()
+        ws = _workspace(lib.gg_blend_workspace(n), dev)
+        final_Ts = torch.empty(img_height, img_width, dtype=torch.float32, device=dev)
+        final_idx = torch.empty(img_height, img_width, dtype=torch.int32, device=dev)
+        outs = [torch.empty(img_height, img_width, c.shape[1], dtype=torch.float32, device=dev) for c in cols_c]
+        for attempt in range(2):
+            if bins.num_intersects is not None and bins.num_intersects < 1:
+                break
+            for c, b, o in zip(cols_c, bgs_c, outs):
+                _lib.check(lib.gg_blend_fwd(c.shape[1], n, img_height, img_width, _ptr(bins.gaussian_ids_sorted),
+                                            _ptr(bins.tile_bins), _ptr(xys_c), _ptr(conics_c), _ptr(c),
+                                            _ptr(opacity_c), _ptr(b), _ptr(o), _ptr(final_Ts), _ptr(final_idx),
+                                            _ptr(ws), ws.numel(), _stream(dev)), "gg_blend_fwd")
+            if not bins.resolve():
+                break
+        ctx.num_intersects = bins.num_intersects
+        ctx.img = (img_height, img_width)
+        ctx.opacity_shape = tuple(opacity.shape)
+        ctx.nseg = len(cols_c)
+        if bins.num_intersects < 1:
+            outs = [torch.ones(img_height, img_width, c.shape[1], device=dev) * b for c, b in zip(cols_c, bgs_c)]
+            ctx.save_for_backward(xys_c, conics_c, opacity_c, *cols_c)
+            return tuple(outs)
+        ctx.save_for_backward(xys_c, conics_c, opacity_c, bins.gaussian_ids_sorted, bins.tile_bins, final_Ts,
+                              final_idx, ws, *cols_c, *bgs_c)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *v_outs):
+        k = ctx.nseg
+        img_height, img_width = ctx.img
+        if ctx.num_intersects < 1:
+            xys, conics, opacity = ctx.saved_tensors[:3]
+            cols = ctx.saved_tensors[3:]
+            grads = []
+            for c in cols:
+                grads += [torch.zeros_like(c), None]
+            return (torch.zeros_like(xys), None, None, torch.zeros_like(conics), None,
+                    torch.zeros_like(opacity).reshape(ctx.opacity_shape), None, None, *grads)
+        xys, conics, opacity, ids_sorted, tile_bins, final_Ts, final_idx, ws = ctx.saved_tensors[:8]
+        cols, bgs = ctx.saved_tensors[8:8 + k], ctx.saved_tensors[8 + k:8 + 2 * k]
+        dev, n = xys.device, xys.shape[0]
+        lib = _lib.load()
+        # one record per Gaussian for the geometry gradients of ALL segments; the colours of the
+        # narrowest small segment (<= 8 channels) ride in the same record (one cache line per Gaussian)
+        small = [i for i in range(k) if cols[i].shape[1] <= 8]
+        rider = min(small, key=lambda i: cols[i].shape[1]) if small else None
+        gstride = 6 + (cols[rider].shape[1] if rider is not None else 0)
+        rec_g = torch.empty(n, gstride, dtype=torch.float32, device=dev)
+        v_xy, v_conic, v_opacity = rec_g[:, 0:2], rec_g[:, 2:5], rec_g[:, 5:6]
+        order = ([rider] if rider is not None else []) + [i for i in range(k) if i != rider]
+        grads = [None] * k
+        first = True
+        for i in order:
+            ch = cols[i].shape[1]
+            v_out = v_outs[i]
+            if v_out is None:
+                v_out = torch.zeros(img_height, img_width, ch, dtype=torch.float32, device=dev)
+            v_out = _f32(v_out)
+            flags = 1 | (0 if first else 4)
+            sink = ctx.sinks[i]
+            if i == rider:
+                v_colors, cstride = rec_g[:, 6:], gstride
+            elif sink is not None:
+                v_colors, cstride = sink[1], 0
+                flags |= 2
+            else:
+                v_colors, cstride = torch.empty(n, ch, dtype=torch.float32, device=dev), 0
+            _lib.check(lib.gg_blend_bwd(ch, n, img_height, img_width, _ptr(ids_sorted), _ptr(tile_bins), _ptr(xys),
+                                        _ptr(conics), _ptr(cols[i]), _ptr(opacity), _ptr(bgs[i]), _ptr(final_Ts),
+                                        _ptr(final_idx), _ptr(v_out), _ptr(v_xy), _ptr(v_conic), _ptr(v_colors),
+                                        _ptr(v_opacity), gstride, cstride, _ptr(ws), ws.numel(), flags,
+                                        _stream(dev)), "gg_blend_bwd")
+            first = False
+            if flags & 2:
+                if sink[2] is not None:
+                    sink[2](sink[0])
+            else:
+                grads[i] = v_colors
+        seg_grads = []
+        for g in grads:
+            seg_grads += [g, None]
+        return (v_xy, None, None, v_conic, None, v_opacity.reshape(ctx.opacity_shape), None, None, *seg_grads)
+
+
+def rasterize_segments(xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, segments):
+    """segments: sequence of (colors (N, C_k), background (C_k,)) -> list of images (H, W, C_k)."""
+    flat = []
+    for c, b in segments:
+        flat += [c, b]
+    return list(RasterizeSegments.apply(xys, depths, radii, conics, num_tiles_hit, opacity, img_height,
+                                        img_width, *flat))
+
+
+# ------------------------------------------------------------------------------------------------
 # quat_to_rotmat (gsplat._torch_impl; reference gaussian_splatting.py:516,614, scripts/update.py:204,229)
 # ------------------------------------------------------------------------------------------------
 class _QuatToRotmat(Function):

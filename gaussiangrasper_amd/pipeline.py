@@ -75,6 +75,31 @@ def rasterize_activated(act: Dict, view: ViewParams, ops, sh_degree_to_use: int 
     return out
 
 
+def fused_images(ops, xys, depths, radii, conics, num_tiles_hit, opac, h, w, feature, rgbs, normals):
+    """feature (D) | rgb (3) | depth (1, background 10) | normal (3) images from one binning.
+    With `ops.rasterize_segments` (the product) the feature array and the 7-channel rgb|depth|normal array
+    are two segments of ONE operator: no (N, D+7) concatenation, aligned feature rows, one set of
+    geometry gradients.  Otherwise (the oracle-backed test operators) one NDRasterize call on the
+    concatenation.  Same images bit for bit either way."""
+    dev = xys.device
+    d = feature.shape[1]
+    if hasattr(ops, "rasterize_segments"):
+        tail = torch.cat([rgbs, depths[:, None], normals], dim=1)
+        bg_tail = torch.zeros(7, device=dev)
+        bg_tail[3] = 10.0
+        feat_im, tail_im = ops.rasterize_segments(xys, depths, radii, conics, num_tiles_hit, opac, h, w,
+                                                  [(feature, torch.zeros(d, device=dev)), (tail, bg_tail)])
+        rgb, depth, normal = torch.split(tail_im, [3, 1, 3], dim=-1)
+        return feat_im, rgb, depth, normal
+    colors = torch.cat([feature, rgbs, depths[:, None], normals], dim=1)
+    background = torch.zeros(d + 7, device=dev)
+    background[d + 3] = 10.0
+    img = ops.NDRasterizeGaussians.apply(xys, depths, radii, conics, num_tiles_hit, colors, opac, h, w,
+                                         background)
+    # one split (its backward is a single cat of the four cotangents, not four zero-padded adds)
+    return torch.split(img, [d, 3, 1, 3], dim=-1)
+
+
 def rasterize_activated_fused(act: Dict, view: ViewParams, ops, sh_degree_to_use: int = 4
                               ) -> Dict[str, torch.Tensor]:
     """the four outputs from ONE rasterize call — feature(D) | rgb(3) | depth(1) |
@@ -93,13 +118,8 @@ def rasterize_activated_fused(act: Dict, view: ViewParams, ops, sh_degree_to_use
     rgbs = ops.SphericalHarmonics.apply(sh_degree_to_use, act["viewdirs"], act["sh"])
     rgbs = torch.clamp(rgbs + 0.5, 0.0, 1.0)
     d = act["feature"].shape[1]
-    colors = torch.cat([act["feature"], rgbs, depths[:, None], act["normals"]], dim=1)
-    background = torch.zeros(d + 7, device=dev)
-    background[d + 3] = 10.0
-    img = ops.NDRasterizeGaussians.apply(xys, depths, radii, conics, num_tiles_hit, colors, opac, h, w,
-                                         background)
-    # one split (its backward is a single cat of the four cotangents, not four zero-padded adds)
-    feature, rgb, depth, normal = torch.split(img, [d, 3, 1, 3], dim=-1)
+    feature, rgb, depth, normal = fused_images(ops, xys, depths, radii, conics, num_tiles_hit, opac, h, w,
+                                               act["feature"], rgbs, act["normals"])
     return {"xys": xys, "radii": radii, "depths": depths, "conics": conics,
             "num_tiles_hit": num_tiles_hit, "feature": feature, "rgb": rgb, "depth": depth,
             "normal": normal}

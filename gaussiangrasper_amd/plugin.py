@@ -30,6 +30,7 @@ import torch
 from . import ops as _ops
 from .camera import projection_matrix
 from .constants import BLOCK
+from .pipeline import fused_images
 
 DESCRIPTION = ("GaussianGrasper feature-field splatting on the MI355X-native fused rasterizer "
                "(gaussiangrasper_amd): one rasterize call per view for rgb + feature + depth + normal")
@@ -40,7 +41,6 @@ def fused_view(model, means, log_scales, quats, opacities, colors_all, feature, 
                ) -> Optional[Dict[str, torch.Tensor]]:
     """Operator part of `get_outputs` (reference :699-784) with the four rasterize calls fused.
     Sets model.xys / model.radii / model.normals as the reference does.  None if nothing is visible."""
-    dev = means.device
     model.xys, depths, model.radii, conics, num_tiles_hit, _cov3d = ops.ProjectGaussians.apply(
         means, torch.exp(log_scales), 1, quats / quats.norm(dim=-1, keepdim=True), viewmat[:3, :],
         projmat @ viewmat, fx, fy, cx, cy, H, W, tile_bounds)
@@ -59,13 +59,9 @@ def fused_view(model, means, log_scales, quats, opacities, colors_all, feature, 
     rot = ops.quat_to_rotmat(quats)
     idx = log_scales.exp().min(dim=-1)[1][..., None, None].expand(-1, 3, -1)
     model.normals = rot.gather(2, idx).squeeze(dim=2)
-    d = feature.shape[1]
-    colors = torch.cat([feature, rgbs, depths[:, None], model.normals], dim=1)
-    background = torch.zeros(d + 7, device=dev)
-    background[d + 3] = 10.0                                       # the depth call's background (:769)
-    img = ops.NDRasterizeGaussians.apply(model.xys, depths, model.radii, conics, num_tiles_hit, colors,
-                                         torch.sigmoid(opacities), H, W, background)
-    feat_im, rgb, depth_im, normal_im = torch.split(img, [d, 3, 1, 3], dim=-1)
+    # feature | rgb | depth (background 10, :769) | normal from one binning (pipeline.fused_images)
+    feat_im, rgb, depth_im, normal_im = fused_images(ops, model.xys, depths, model.radii, conics, num_tiles_hit,
+                                                     torch.sigmoid(opacities), H, W, feature, rgbs, model.normals)
     return {"rgb": rgb, "feature": feat_im, "depth": depth_im, "normal": normal_im}
 
 

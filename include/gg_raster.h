@@ -156,6 +156,7 @@ int gg_blend_bwd(int channels, int num_points, int img_height, int img_width,
                  int flags, gg_stream_t stream);
 #define GG_BWD_WS_FROM_FORWARD 1
 #define GG_BWD_ACCUMULATE_COLORS 2
+#define GG_BWD_ACCUMULATE_GEOM 4
 
 /* ---- feature up-projection MLP ------------------------------------------------
  * Replaces the forward of the reference's `MLP(32, 512, hidden_list=[128])` module

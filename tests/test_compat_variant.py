@@ -127,9 +127,10 @@ def test_gpu_compat_library_matches_the_compat_oracle(compat_oracle):
     vm, pm = t(v.viewmat[:3].numpy()), t(v.projmat.numpy())
     outs = [torch.empty(n, k, device=DEV) for k in (3, 3, 4)]
     stream = P._stream(m.device)
+    rad_t, con_t, cot_t = t(fwd[2]), t(fwd[3]), [t(c) for c in cot]     # (kept alive across the launches)
     st = lib.gg_project_bwd(n, ptr(m), ptr(s), 1.0, ptr(q), ptr(vm), ptr(pm), v.fx, v.fy, v.cx, v.cy, v.height,
-                            v.width, ptr(t(fwd[2])), ptr(t(fwd[3])), ptr(t(cot[0])), ptr(t(cot[1])),
-                            ptr(t(cot[2])), ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), stream)
+                            v.width, ptr(rad_t), ptr(con_t), ptr(cot_t[0]), ptr(cot_t[1]),
+                            ptr(cot_t[2]), ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), stream)
     assert st == 0
     for name, got, r in zip(("v_mean3d", "v_scale", "v_quat"), outs, ref):
         assert_close(got.cpu().numpy(), r, f"compat.project_bwd.{name}", rtol=1e-4, atol_frac=1e-5)
@@ -137,7 +138,7 @@ def test_gpu_compat_library_matches_the_compat_oracle(compat_oracle):
     dflt = _lib.load()
     outs_d = [torch.empty(n, k, device=DEV) for k in (3, 3, 4)]
     dflt.gg_project_bwd(n, ptr(m), ptr(s), 1.0, ptr(q), ptr(vm), ptr(pm), v.fx, v.fy, v.cx, v.cy, v.height, v.width,
-                        ptr(t(fwd[2])), ptr(t(fwd[3])), ptr(t(cot[0])), ptr(t(cot[1])), ptr(t(cot[2])),
+                        ptr(rad_t), ptr(con_t), ptr(cot_t[0]), ptr(cot_t[1]), ptr(cot_t[2]),
                         ptr(outs_d[0]), ptr(outs_d[1]), ptr(outs_d[2]), stream)
     assert not torch.allclose(outs[0], outs_d[0], rtol=1e-4, atol=1e-6)
     # ---- blend_bwd at GG_ALPHA_MAX_BWD = 0.99
@@ -154,9 +155,9 @@ def test_gpu_compat_library_matches_the_compat_oracle(compat_oracle):
         vx, vc, vo_ = (torch.empty(n, k, device=DEV) for k in (2, 3, 1))
         vcol = torch.empty(n, ch, device=DEV)
         ws = torch.empty(lib.gg_blend_workspace(n), dtype=torch.uint8, device=DEV)
-        st = lib.gg_blend_bwd(ch, n, h, w, ptr(ids), ptr(bins_t), ptr(t(xys)), ptr(t(conics)), ptr(t(colors)),
-                              ptr(t(opac)), ptr(t(bg)), ptr(t(saved["final_Ts"])),
-                              ptr(t(saved["final_idx"].astype(np.int32))), ptr(t(v_out)), ptr(vx), ptr(vc),
+        keep = [t(a) for a in (xys, conics, colors, opac, bg, saved["final_Ts"],
+                               saved["final_idx"].astype(np.int32), v_out)]
+        st = lib.gg_blend_bwd(ch, n, h, w, ptr(ids), ptr(bins_t), *[ptr(k) for k in keep], ptr(vx), ptr(vc),
                               ptr(vcol), ptr(vo_), 0, 0, ptr(ws), ws.numel(), 0, stream)
         assert st == 0
         for name, g, r in zip(("v_xy", "v_conic", "v_colors", "v_opacity"), (vx, vc, vcol, vo_), ref):

@@ -786,3 +786,40 @@ def test_direct_gradient_accumulation_equals_autograd_accumulation():
         # (not bit-equal even for the SH coefficients: their cotangent comes out of the rgb blend
         # backward, whose float atomics sum in a different order from run to run)
         assert_close(_np(b), _np(a), name, rtol=1e-4, atol_frac=2e-6)
+
+
+def test_rasterize_segments_equals_separate_calls(oracle):
+    """RasterizeSegments (feature 32 | rgb+depth+normal 7 | a 3-channel array): images bit-identical to
+    NDRasterize on each array; geometry gradients = the sum over the separate calls; colour gradients per
+    array — against the oracle with the tolerance of test_blend_bwd"""
+    n, h, w = 20000, 150, 200
+    xys, depths, radii, conics, nth, colors, opac, bg = _blend_inputs(oracle, n, h, w, 42, seed=8)
+    segs = [(colors[:, :32].copy(), bg[:32].copy()), (colors[:, 32:39].copy(), bg[32:39].copy()),
+            (colors[:, 39:42].copy(), bg[39:42].copy())]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    rng = np.random.default_rng(5)
+    ref_imgs, ref_g = [], None
+    v_outs = []
+    for c, b in segs:
+        out, saved = oracle.rasterize_fwd(xys, depths, radii, conics, nth, c, opac, h, w, b)
+        v = rng.standard_normal(out.shape).astype(np.float32)
+        bb = saved["bins"]
+        g = oracle.blend_bwd(bb["gaussian_ids_sorted"], bb["tile_bins"], xys, conics, c, opac, h, w, b,
+                             saved["final_Ts"], saved["final_idx"], v)
+        ref_imgs.append(out)
+        v_outs.append(v)
+        ref_g = [g[0].astype(np.float64), g[1].astype(np.float64), [g[2]], g[3].astype(np.float64)] if ref_g is None \
+            else [ref_g[0] + g[0], ref_g[1] + g[1], ref_g[2] + [g[2]], ref_g[3] + g[3]]
+    xt, ct, ot = t(xys).requires_grad_(True), t(conics).requires_grad_(True), t(opac).requires_grad_(True)
+    cts = [t(c).requires_grad_(True) for c, _ in segs]
+    P.clear_bin_cache()
+    imgs = P.rasterize_segments(xt, t(depths), t(radii), ct, t(nth), ot, h, w,
+                                [(cts[i], t(segs[i][1])) for i in range(3)])
+    for i in range(3):
+        assert_bitexact(_np(imgs[i]), ref_imgs[i], f"segment {i} image")
+    torch.autograd.backward(imgs, [t(v) for v in v_outs])
+    assert_close(_np(xt.grad), ref_g[0], "segments.v_xy", rtol=1e-3, atol_frac=2e-5)
+    assert_close(_np(ct.grad), ref_g[1], "segments.v_conic", rtol=1e-3, atol_frac=2e-5)
+    assert_close(_np(ot.grad), ref_g[3].reshape(_np(ot.grad).shape), "segments.v_opacity", rtol=1e-3, atol_frac=2e-5)
+    for i in range(3):
+        assert_close(_np(cts[i].grad), ref_g[2][i], f"segments.v_colors[{i}]", rtol=1e-3, atol_frac=2e-5)

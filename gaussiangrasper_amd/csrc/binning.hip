@@ -7,7 +7,7 @@
 //
 //   1. stable LSD radix sort of the N Gaussians by their 32 depth bits (4 byte-wide passes over
 //      N items; culled Gaussians get key 0xFFFFFFFF and sink to the end);
-//   2. exclusive scan of num_tiles_hit taken in that depth order;
+//   2. exclusive scan of num_tiles_hit taken in that depth order (one launch, decoupled look-back);
 //   3. every Gaussian, in depth order, emits (tile id, Gaussian id) for the tiles of its bbox;
 //   4. stable LSD radix sort of the I pairs by tile id only (ceil(log2 T)/8 = 2 passes).
 //
@@ -18,7 +18,7 @@
 // Radix pass = 3 launches: per-block digit histogram -> per-digit column scan -> stable scatter.
 // Within the scatter a wave ranks its keys with ballot-based match-any (8 ballots per key), so
 // equal digits keep their input order without any LDS sorting network.
-#include "gg_common.h"
+#include "scan.h"
 
 // Device-side item count: the tile-sort kernels can take the number of intersections from device
 // memory (n_dev != NULL), clamped to the capacity n the launch was sized for — the host then needs no
@@ -253,64 +253,18 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// exclusive scan of num_tiles_hit[order[r]]  (3 launches: block sums, scan of sums, apply)
+// exclusive scan of num_tiles_hit[order[r]]: ONE launch (decoupled look-back across workgroups, scan.h)
 // ---------------------------------------------------------------------------------------------
 #define SC_THREADS 256
 #define SC_ITEMS 8
 #define SC_TILE (SC_THREADS * SC_ITEMS)
 
-__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *wsum, uint32_t &total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        uint32_t t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t wpre = 0, tot = 0;
-    for (int w = 0; w < 4; ++w) {
-        uint32_t s = wsum[w];
-        if (w < wave) wpre += s;
-        tot += s;
-    }
-    total = tot;
-    __syncthreads();
-    return wpre + incl - v;
-}
-
-__global__ __launch_bounds__(SC_THREADS) void scan_blocksum_kernel(
+__global__ __launch_bounds__(SC_THREADS) void scan_offsets_kernel(
     int N, const int32_t *__restrict__ nth, const uint32_t *__restrict__ order,
-    uint32_t *__restrict__ block_sums) {
-    __shared__ uint32_t wsum[4];
-    int base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
-    uint32_t acc = 0;
-#pragma unroll
-    for (int k = 0; k < SC_ITEMS; ++k) {
-        int r = base + k;
-        if (r < N) acc += (uint32_t)nth[order[r]];
-    }
-    uint32_t total;
-    block_excl_scan_256(acc, wsum, total);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
-}
-__global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(int nb, uint32_t *block_sums) {
-    __shared__ uint32_t wsum[4];
-    uint32_t carry = 0;
-    for (int start = 0; start < nb; start += SC_THREADS) {
-        int i = start + threadIdx.x;
-        uint32_t v = (i < nb) ? block_sums[i] : 0u;
-        uint32_t total;
-        uint32_t ex = block_excl_scan_256(v, wsum, total);
-        if (i < nb) block_sums[i] = carry + ex;
-        carry += total;
-    }
-}
-__global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(
-    int N, const int32_t *__restrict__ nth, const uint32_t *__restrict__ order,
-    const uint32_t *__restrict__ block_sums, uint32_t *__restrict__ offsets) {
-    __shared__ uint32_t wsum[4];
-    int base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
+    uint32_t *__restrict__ offsets, ScanState *st, int nblocks) {
+    __shared__ unsigned int s_slot, s_excl, wsum[4];
+    const int bid = scan_ticket(st, &s_slot);
+    const int base = bid * SC_TILE + threadIdx.x * SC_ITEMS;
     uint32_t v[SC_ITEMS];
     uint32_t acc = 0;
 #pragma unroll
@@ -319,8 +273,9 @@ __global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(
         v[k] = (r < N) ? (uint32_t)nth[order[r]] : 0u;
         acc += v[k];
     }
-    uint32_t total;
-    uint32_t ex = block_excl_scan_256(acc, wsum, total) + block_sums[blockIdx.x];
+    unsigned int total;
+    uint32_t ex = scan_block256(acc, wsum, total);
+    ex += scan_lookback(st, bid, nblocks, total, &s_excl);
 #pragma unroll
     for (int k = 0; k < SC_ITEMS; ++k) {
         int r = base + k;
@@ -450,7 +405,7 @@ static BinWs bin_ws_layout(void *ws, int N, int64_t I) {
     w.dvalA = take(4 * n);
     w.dvalB = take(4 * n);
     w.offsets = take(4 * n);
-    w.block_sums = take(4 * ((n + SC_TILE - 1) / SC_TILE + 1));
+    w.block_sums = take(gg_scan_state_bytes((int)((n + SC_TILE - 1) / SC_TILE)));   // look-back state of the offsets scan
     int nb = max(radix_nblocks(N), radix_nblocks(I));
     w.G = take(4 * 256 * (size_t)(nb + 1));
     w.totals = take(4 * 256);
@@ -516,11 +471,12 @@ static int bin_sort_impl(int N, int64_t I, const int64_t *I_dev, const float *xy
     const uint32_t *order = va;
     // 2. offsets in depth order
     int nsb = (N + SC_TILE - 1) / SC_TILE;
-    hipLaunchKernelGGL(scan_blocksum_kernel, dim3(nsb), dim3(SC_THREADS), 0, s, N, num_tiles_hit,
-                       order, w.block_sums);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SC_THREADS), 0, s, nsb, w.block_sums);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(SC_THREADS), 0, s, N, num_tiles_hit,
-                       order, w.block_sums, w.offsets);
+    if (hipMemsetAsync(w.block_sums, 0, gg_scan_state_bytes(nsb), s) != hipSuccess) {
+        gg_set_error("gg_bin_sort: memset failed");
+        return GG_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(scan_offsets_kernel, dim3(nsb), dim3(SC_THREADS), 0, s, N, num_tiles_hit, order,
+                       w.offsets, (ScanState *)w.block_sums, nsb);
     // 3./4. emit + sort by tile id; ping-pong so the last pass lands in gaussian_ids_sorted
     int tile_bits = 1;
     while ((1 << tile_bits) < T) ++tile_bits;

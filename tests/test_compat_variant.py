@@ -133,7 +133,7 @@ def test_gpu_compat_library_matches_the_compat_oracle(compat_oracle):
                             ptr(cot_t[2]), ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), stream)
     assert st == 0
     for name, got, r in zip(("v_mean3d", "v_scale", "v_quat"), outs, ref):
-        assert_close(got.cpu().numpy(), r, f"compat.project_bwd.{name}", rtol=1e-4, atol_frac=1e-5)
+        assert_close(got.cpu().numpy(), r, f"compat.project_bwd.{name}", rtol=1e-6, atol_frac=1e-7)
     # and it is NOT the default library's answer
     dflt = _lib.load()
     outs_d = [torch.empty(n, k, device=DEV) for k in (3, 3, 4)]
@@ -161,5 +161,5 @@ def test_gpu_compat_library_matches_the_compat_oracle(compat_oracle):
                               ptr(vcol), ptr(vo_), 0, 0, ptr(ws), ws.numel(), 0, stream)
         assert st == 0
         for name, g, r in zip(("v_xy", "v_conic", "v_colors", "v_opacity"), (vx, vc, vcol, vo_), ref):
-            assert_close(g.cpu().numpy(), r.reshape(g.shape), f"compat.blend_bwd<{ch}>.{name}", rtol=1e-3,
-                         atol_frac=2e-5)
+            assert_close(g.cpu().numpy(), r.reshape(g.shape), f"compat.blend_bwd<{ch}>.{name}", rtol=5e-5,
+                         atol_frac=1e-6)

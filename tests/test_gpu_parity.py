@@ -224,8 +224,10 @@ def test_blend_fwd_bitexact(oracle, n, h, w, ch):
                                       (3000, 64, 80, 2), (3000, 64, 80, 8), (3000, 64, 80, 12),
                                       (3000, 64, 80, 17), (3000, 64, 80, 35)])
 def test_blend_bwd(oracle, n, h, w, ch):
-    """tolerance: |gpu-oracle| <= 2e-5*max|grad| + 1e-3*|grad| (fp32 atomics vs fp64-summed oracle;
-    the kernel uses the algebraically-equal scalar-W form of v_alpha, see blend.hip header)"""
+    """tolerance: |gpu-oracle| <= 1e-6*max|grad| + 5e-5*|grad| (fp32 atomics vs fp64-summed oracle; the
+    kernel uses the algebraically-equal scalar-W form of v_alpha, see blend.hip header).  Set from the
+    ACHIEVED errors (conftest prints them; round 2, all cases of this file): max|err| <= 4.2e-7*max|grad|,
+    relative error of the entries >= 1 % of max|grad|: 99.9th percentile 8.4e-6, maximum 1.4e-5."""
     xys, depths, radii, conics, nth, colors, opac, bg = _blend_inputs(oracle, n, h, w, ch, seed=3)
     ref_out, saved = oracle.rasterize_fwd(xys, depths, radii, conics, nth, colors, opac, h, w, bg)
     v_out = np.random.default_rng(11).standard_normal(ref_out.shape).astype(np.float32)
@@ -243,12 +245,13 @@ def test_blend_bwd(oracle, n, h, w, ch):
     out.backward(t(v_out))
     for name, g, r in zip(("v_xy", "v_conic", "v_colors", "v_opacity"),
                           (xt.grad, ct.grad, colt.grad, ot.grad), ref):
-        assert_close(_np(g), r, f"blend_bwd.{name}", rtol=1e-3, atol_frac=2e-5)
+        assert_close(_np(g), r, f"blend_bwd.{name}", rtol=5e-5, atol_frac=1e-6)
 
 
 @pytest.mark.parametrize("n,h,w", [(7, 45, 70), (1000, 48, 64), (50000, 300, 400)])
 def test_project_bwd(oracle, n, h, w):
-    """tolerance: 1e-5*max|grad| + 1e-4*|grad| (same formulas, fp32, per-Gaussian, no reduction)"""
+    """tolerance: 1e-7*max|grad| + 1e-6*|grad| — achieved: bit-identical to the oracle (same formulas in
+    fp32, one Gaussian per lane, no reduction); the margin only covers a compiler re-association"""
     sc, v = _scene_view(n, h, w)
     ref_fwd = _project_oracle(oracle, sc, v)
     rng = np.random.default_rng(2)
@@ -266,7 +269,7 @@ def test_project_bwd(oracle, n, h, w):
     t = lambda a: torch.from_numpy(a).to(DEV)
     torch.autograd.backward([outs[0], outs[1], outs[3]], [t(v_xy), t(v_depth), t(v_conic)])
     for name, got, r in zip(("v_mean3d", "v_scale", "v_quat"), (m.grad, s.grad, q.grad), ref):
-        assert_close(_np(got), r, f"project_bwd.{name}", rtol=1e-4, atol_frac=1e-5)
+        assert_close(_np(got), r, f"project_bwd.{name}", rtol=1e-6, atol_frac=1e-7)
 
 
 def _activated_leaves(act, dev):
@@ -299,9 +302,9 @@ def test_operator_sequence_bitexact_vs_oracle(oracle, n, h, w, d):
         assert_bitexact(_np(out_g[k]), _np(out_c[k]), f"image.{k}")
     assert_bitexact(_np(out_g["radii"]), _np(out_c["radii"]), "radii")
     assert out_g["xys"].grad is not None and out_g["xys"].grad.abs().sum() > 0
-    assert_close(_np(out_g["xys"].grad), _np(out_c["xys"].grad), "xys.grad", rtol=2e-3, atol_frac=3e-5)
+    assert_close(_np(out_g["xys"].grad), _np(out_c["xys"].grad), "xys.grad", rtol=3e-4, atol_frac=1e-5)
     for name in ("means", "scales", "quats", "opac", "sh", "feature", "normals"):
-        assert_close(_np(a_g[name].grad), _np(a_c[name].grad), f"grad.{name}", rtol=2e-3, atol_frac=3e-5)
+        assert_close(_np(a_g[name].grad), _np(a_c[name].grad), f"grad.{name}", rtol=3e-4, atol_frac=1e-5)
     assert P.bin_cache_stats["hits"] - hits0 == 3  # one sort shared by the four rasterize calls
 
 
@@ -436,7 +439,7 @@ def test_golden_fixtures_on_gpu():
         out.backward(t(z["v_out"]))
         for name, g in zip(("v_xy", "v_conic", "v_colors", "v_opacity"),
                            (xy.grad, con.grad, col.grad, opa.grad)):
-            assert_close(_np(g), z[name], f"{os.path.basename(f)}:{name}", rtol=1e-3, atol_frac=2e-5)
+            assert_close(_np(g), z[name], f"{os.path.basename(f)}:{name}", rtol=5e-5, atol_frac=1e-6)
 
 
 def test_full_size_properties():
@@ -562,7 +565,7 @@ def test_full_size_vs_oracle(oracle, n, cfg, min_visible):
     for k in ("rgb", "feature", "depth", "normal"):
         assert_bitexact(_np(out_g[k]), _np(out_c[k]), f"image.{k}")
     for name in ("means", "scales", "quats", "opac", "sh", "feature", "normals"):
-        assert_close(_np(a_g[name].grad), _np(a_c[name].grad), f"grad.{name}", rtol=2e-3, atol_frac=3e-5)
+        assert_close(_np(a_g[name].grad), _np(a_c[name].grad), f"grad.{name}", rtol=3e-4, atol_frac=1e-5)
 
 
 def test_quat_to_rotmat_hip_vs_oracle_and_torch(oracle):
@@ -706,7 +709,7 @@ def test_blend_bwd_c_abi_gradient_layouts(oracle, ch):
 
     for layout in ("dense", "geom") + (("full",) if ch <= 3 else ()):
         for name, g, r in zip(("v_xy", "v_conic", "v_colors", "v_opacity"), run(layout), ref):
-            assert_close(_np(g), r.reshape(_np(g).shape), f"{layout}.{name}", rtol=1e-3, atol_frac=2e-5)
+            assert_close(_np(g), r.reshape(_np(g).shape), f"{layout}.{name}", rtol=5e-5, atol_frac=1e-6)
     # a bad combination is refused
     rec = torch.zeros(n, 6, device=DEV)
     st = lib.gg_blend_bwd(ch, n, h, w, ptr(ids), ptr(bins_t), ptr(xt), ptr(ct), ptr(colt), ptr(ot), ptr(bgt),
@@ -818,8 +821,8 @@ def test_rasterize_segments_equals_separate_calls(oracle):
     for i in range(3):
         assert_bitexact(_np(imgs[i]), ref_imgs[i], f"segment {i} image")
     torch.autograd.backward(imgs, [t(v) for v in v_outs])
-    assert_close(_np(xt.grad), ref_g[0], "segments.v_xy", rtol=1e-3, atol_frac=2e-5)
-    assert_close(_np(ct.grad), ref_g[1], "segments.v_conic", rtol=1e-3, atol_frac=2e-5)
-    assert_close(_np(ot.grad), ref_g[3].reshape(_np(ot.grad).shape), "segments.v_opacity", rtol=1e-3, atol_frac=2e-5)
+    assert_close(_np(xt.grad), ref_g[0], "segments.v_xy", rtol=5e-5, atol_frac=1e-6)
+    assert_close(_np(ct.grad), ref_g[1], "segments.v_conic", rtol=5e-5, atol_frac=1e-6)
+    assert_close(_np(ot.grad), ref_g[3].reshape(_np(ot.grad).shape), "segments.v_opacity", rtol=5e-5, atol_frac=1e-6)
     for i in range(3):
-        assert_close(_np(cts[i].grad), ref_g[2][i], f"segments.v_colors[{i}]", rtol=1e-3, atol_frac=2e-5)
+        assert_close(_np(cts[i].grad), ref_g[2][i], f"segments.v_colors[{i}]", rtol=5e-5, atol_frac=1e-6)

@@ -79,7 +79,11 @@ def parse(argv=None):
     ap.add_argument("--views-per-step", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the profiled step (no per-kernel times)")
-    ap.add_argument("--no-fused", action="store_true", help="skip the secondary fused-path measurement")
+    ap.add_argument("--route", default="plugin", choices=("plugin", "shim"),
+                    help="headline route: the nerfstudio plugin's fused operator (default) or the shim's "
+                         "four separate rasterize calls; the other one is measured as well")
+    ap.add_argument("--no-secondary", "--no-fused", dest="no_secondary", action="store_true",
+                    help="skip the measurement of the other route")
     ap.add_argument("--no-overlap", action="store_true", help="one all-reduce after the last view")
     ap.add_argument("--no-direct", action="store_true",
                     help="autograd accumulates every parameter gradient (no in-kernel accumulation "
@@ -306,9 +310,11 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
     if hasattr(ops, "clear_bin_cache"):
         ops.clear_bin_cache()
 
-    def render_and_backward(v):
-        out = render_view(scene, views[v], ops)
-        backward_view(out, cot)
+    def make_step(fused: bool):
+        def render_and_backward(v):
+            out = render_view(scene, views[v], ops, fused=fused)
+            backward_view(out, cot)
+        return render_and_backward
 
     overlap = not args.no_overlap
 
@@ -320,36 +326,40 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
         barrier()
         return max_over_ranks(time.perf_counter() - t0)
 
-    for _ in range(args.warmup):
-        train_step(render_and_backward, bucket, my_views, overlap=overlap)
-    elapsed = timed(render_and_backward, args.steps)          # kernel timers off
-
-    if args.dump_grads and rank == 0:
-        torch.save(bucket.gathered().detach().cpu().clone(), args.dump_grads)
-
-    kernels = {}
-    if lib is not None and not args.no_prof:                   # one profiled step, all ranks
-        lib.gg_prof_reset()
-        lib.gg_prof_enable(1)
-        t_prof = timed(render_and_backward, 1)
-        lib.gg_prof_enable(0)
-        kernels = read_kernel_times(lib)
-
-    # secondary measurement (not `value`): same views through the fused single-call path (§8f-1)
-    fused_vps, fused_kernels = None, {}
-    if not args.no_fused and not selftest:
-        def render_and_backward_fused(v):
-            out = render_view(scene, views[v], ops, fused=True)
-            backward_view(out, cot)
-        train_step(render_and_backward_fused, bucket, my_views, overlap=overlap)   # warm-up
-        tf = timed(render_and_backward_fused, args.steps)
-        fused_vps = total_views * args.steps / tf
-        if lib is not None and not args.no_prof:
+    def measure(fused: bool, warmup: int):
+        """warm-up, the timed steps with the kernel timers OFF, then one profiled step"""
+        fn = make_step(fused)
+        for _ in range(warmup):
+            train_step(fn, bucket, my_views, overlap=overlap)
+        t = timed(fn, args.steps)
+        grads = bucket.gathered().detach().cpu().clone() if (args.dump_grads and rank == 0) else None
+        kern, t_prof = {}, None
+        if lib is not None and not args.no_prof:               # all ranks take part (collectives)
             lib.gg_prof_reset()
             lib.gg_prof_enable(1)
-            timed(render_and_backward_fused, 1)
+            t_prof = timed(fn, 1)
             lib.gg_prof_enable(0)
-            fused_kernels = read_kernel_times(lib)
+            kern = read_kernel_times(lib)
+        return t, kern, t_prof, grads
+
+    # Two registration routes, both leave train.sh / render.sh untouched (INTEGRATION.md):
+    #   plugin  NERFSTUDIO_METHOD_CONFIGS="gaussian-splatting=gaussiangrasper_amd.plugin:gaussian_splatting":
+    #           the model subclass renders the four images of a view from ONE operator
+    #           (ops.RasterizeSegments: one binning, one forward and one backward walk per colour array,
+    #           one set of geometry gradients) — the headline;
+    #   shim    PYTHONPATH=<repo>/shim only: the reference's model file with its four separate rasterize
+    #           calls per view (they share the binning) — reported next to it.
+    plugin_first = args.route == "plugin"
+    elapsed, kernels, t_prof, grads = measure(fused=plugin_first, warmup=args.warmup)
+    if grads is not None:
+        torch.save(grads, args.dump_grads)
+    other = None
+    if not args.no_secondary and not selftest:
+        o_t, o_k, _, _ = measure(fused=not plugin_first, warmup=1)
+        other = {"route": "shim (four rasterize calls per view)" if plugin_first else "plugin (one fused operator per view)",
+                 "value": total_views * args.steps / o_t, "unit": "views/s",
+                 "kernels": {k: round(v["avg_ms"], 4) for k, v in sorted(o_k.items())},
+                 "kernel_ms_per_view": sum(v["total_ms"] for v in o_k.values()) / args.views_per_step if o_k else None}
 
     views_done = total_views * args.steps
     ms_per_view_rank = 1e3 * elapsed / (args.steps * args.views_per_step)
@@ -360,10 +370,13 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
         "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic" if not selftest else f"selftest (non-product ops module {args.ops})",
         "config": {"workload": "BASELINE config 4 per-GPU share: %d Gaussians, %dx%d, SH deg 4 rgb + "
-                               "%d-ch feature + depth + normal via the reference's 4 rasterize calls, "
+                               "%d-ch feature + depth + normal images per view (%s), "
                                "fwd+bwd, %d views/step/GPU, gradient all-reduce each step"
                                % (args.points, args.width, args.height, args.feature_dim,
+                                  "nerfstudio plugin route: one fused rasterize operator per view"
+                                  if plugin_first else "shim route: the reference's 4 rasterize calls per view",
                                   args.views_per_step),
+                   "route": args.route,
                    "num_gaussians": args.points, "image": [args.height, args.width],
                    "feature_dim": args.feature_dim, "views_per_step_per_gpu": args.views_per_step,
                    "n_visible": n_vis, "num_intersects": n_isect,
@@ -384,14 +397,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
             tot = sum(v["total_ms"] for v in kernels.values())
             result["kernel_time_fraction_of_wall"] = tot / (1e3 * t_prof)
             result["kernel_ms_per_view"] = tot / args.views_per_step
-        result["fused_single_call_path"] = None if fused_vps is None else {
-            "value": fused_vps, "unit": "views/s",
-            "kernels": {k: round(v["avg_ms"], 4) for k, v in sorted(fused_kernels.items())},
-            "kernel_ms_per_view": sum(v["total_ms"] for v in fused_kernels.values()) / args.views_per_step
-            if fused_kernels else None,
-            "note": "same views and gradients through ONE NDRasterize call on feature|rgb|depth|normal "
-                    "(SURVEY 8f-1; what gaussiangrasper_amd.plugin registers as a nerfstudio method); "
-                    "NOT the headline: the headline is the reference's unchanged 4-call sequence"}
+        result["other_route"] = other
         result["cpu_baseline"] = None
         if world == 1 and not args.no_cpu_baseline and not selftest:
             try:

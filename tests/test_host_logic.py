@@ -180,7 +180,7 @@ def _run_bench(extra, tmp_path, gpus, env_extra=None, timeout=600):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--backend", "gloo",
            "--device", "cpu", "--ops", "oracle_ops", "--points", "300", "--height", "32", "--width", "48",
            "--feature-dim", "4", "--views-per-step", "2", "--steps", "1", "--warmup", "1",
-           "--no-cpu-baseline", "--no-fused"] + extra
+           "--no-cpu-baseline", "--no-secondary"] + extra
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
 
 

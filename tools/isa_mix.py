@@ -46,8 +46,10 @@ COST = {"plain": 1.0, "dpp": 2.5, "permlane": 5.5, "trans": 4.0, "pk": 2.0}
 def main():
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "blend2.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off",
-                               "-std=c++17", "-S", "--cuda-device-only", "-o", asm, SRC],
+        sys.path.insert(0, ROOT)
+        from gaussiangrasper_amd.build import FLAGS     # the product's flags (minus the link step)
+        flags = [f for f in FLAGS if f not in ("-shared", "-fPIC")]
+        subprocess.check_call(["/opt/rocm/bin/hipcc", *flags, "-S", "--cuda-device-only", "-o", asm, SRC],
                               stderr=subprocess.DEVNULL)
         text = open(asm).read().splitlines()
     out = {}

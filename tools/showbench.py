@@ -8,5 +8,5 @@ print(" ".join(f"{k}={v}" for k, v in d["kernels"].items()))
 r = d.get("roofline")
 if r:
     print("dominant", r["kernel"], "frac %.4f" % r["frac"], "valu", r.get("valu"), "whole_view frac %.4f" % r["whole_view"]["frac"])
-f = d.get("fused_single_call_path") or {}
-print("fused", f.get("value"), f.get("kernel_ms_per_view"), f.get("kernels"), "cpu", (d.get("cpu_baseline") or {}).get("value"))
+f = d.get("other_route") or d.get("fused_single_call_path") or {}
+print("other route:", f.get("route"), f.get("value"), f.get("kernel_ms_per_view"), f.get("kernels"), "cpu", (d.get("cpu_baseline") or {}).get("value"))

@@ -55,6 +55,7 @@ SIGNATURES = {
     "gg_bin_sort_dev": (_I, [_I, _I64, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
     "gg_blend_workspace": (_SZ, [_I]),
     "gg_blend_fwd": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "gg_blend_fwd_pair": (_I, [_I, _I, _I, _I, _I] + [_P] * 14 + [_SZ, _P]),
     "gg_blend_bwd": (_I, [_I, _I, _I, _I] + [_P] * 14 + [_I, _I, _P, _SZ, _I, _P]),
     "gg_expf_array": (_I, [_I, _P, _P, _P]),
     "gg_rows_workspace": (_SZ, [_I]),

@@ -58,6 +58,11 @@ void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, 
                                  float *v_conic, float *v_colors, float *v_opacity, int gstride, int cstride, hipStream_t s);
 #endif
 
+void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int ntiles, const int32_t *ids,
+                               const int2 *bins, const GRec *rec, const float *colors, const float *background,
+                               float *out_img, float *final_Ts, int32_t *final_idx, const float *colors2, int C2,
+                               const float *background2, float *out_img2, hipStream_t s);
+
 // Channel chunking: calls with <= 3 channels (rgb / depth / normal) use the narrow kernels with
 // the colours inside the LDS record; anything wider is processed in chunks of 32 channels on the
 // MFMA kernels (a final partial chunk is zero-padded), each chunk re-walking the tile lists.
@@ -110,6 +115,50 @@ extern "C" int gg_blend_fwd(int C, int N, int img_h, int img_w, const int32_t *i
         gg_prof_begin(GG_K_BLEND_FWD + gg_width_index(w), s);
         gg_launch_blend2_fwd(w, C, off, n, img_h, img_w, tiles_x, ntiles, ids, (const int2 *)tile_bins,
                              rec, colors, background, out_img, final_Ts, final_idx, off == 0, s);
+        gg_prof_end(GG_K_BLEND_FWD + gg_width_index(w), s);
+        off += n;
+    }
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+extern "C" int gg_blend_fwd_pair(int C, int C2, int N, int img_h, int img_w, const int32_t *ids,
+                                 const int32_t *tile_bins, const float *xys, const float *conics,
+                                 const float *colors, const float *colors2, const float *opacity,
+                                 const float *background, const float *background2, float *out_img,
+                                 float *out_img2, float *final_Ts, int32_t *final_idx, void *ws,
+                                 size_t ws_bytes, gg_stream_t stream) {
+    GG_REQUIRE(C >= 32, "the first colour array needs >= 32 channels (its first chunk carries the second array)");
+    GG_REQUIRE(C2 >= 1 && C2 <= 8, "the second colour array has 1..8 channels");
+    GG_REQUIRE(N >= 0, "num_points < 0");
+    GG_REQUIRE(img_h > 0 && img_w > 0, "empty image");
+    GG_REQUIRE(tile_bins && background && background2 && out_img && out_img2 && final_Ts && final_idx,
+               "null pointer");
+    GG_REQUIRE(N == 0 || (ids && xys && conics && colors && colors2 && opacity), "null pointer");
+    if (ws == nullptr || ws_bytes < gg_blend_workspace(N)) {
+        gg_set_error("gg_blend_fwd_pair: workspace too small");
+        return GG_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    GRec *rec = (GRec *)ws;
+    if (N > 0) {
+        gg_prof_begin(GG_K_BLEND_PREP, s);
+        hipLaunchKernelGGL(blend_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, xys, conics,
+                           opacity, rec);
+        gg_prof_end(GG_K_BLEND_PREP, s);
+    }
+    const int tiles_x = (img_w + GG_BLOCK - 1) / GG_BLOCK, tiles_y = (img_h + GG_BLOCK - 1) / GG_BLOCK;
+    const int ntiles = tiles_x * tiles_y;
+    gg_prof_begin(GG_K_BLEND_FWD_PAIR, s);
+    gg_launch_blend2_fwd_pair(C, img_h, img_w, tiles_x, ntiles, ids, (const int2 *)tile_bins, rec, colors,
+                              background, out_img, final_Ts, final_idx, colors2, C2, background2, out_img2, s);
+    gg_prof_end(GG_K_BLEND_FWD_PAIR, s);
+    for (int off = 32; off < C;) {
+        const int w = chunk_width(C - off);
+        const int n = min(w, C - off);
+        gg_prof_begin(GG_K_BLEND_FWD + gg_width_index(w), s);
+        gg_launch_blend2_fwd(w, C, off, n, img_h, img_w, tiles_x, ntiles, ids, (const int2 *)tile_bins,
+                             rec, colors, background, out_img, final_Ts, final_idx, 0, s);
         gg_prof_end(GG_K_BLEND_FWD + gg_width_index(w), s);
         off += n;
     }

@@ -55,7 +55,16 @@ struct WaveListT {
     float4 a[LIST_CAP];  // x, y, opacity, (cut-off; NC == 2: list position)
     float4 b[LIST_CAP];  // conic a, b, c, Gaussian id (int bits)
     float4 c[LIST_CAP];  // narrow: colours 0..2(3) ; wide: .x = Gaussian id (int bits). NC == 1: .w = list position
-    float4 d[NC == 2 ? LIST_CAP : 1];
+    float4 d[NC >= 2 ? LIST_CAP : 1];
+    float4 e[NC >= 3 ? LIST_CAP : 1];   // NC == 3: wide forward with a second, <= 8-channel colour array (d, e)
+};
+
+// second colour array blended in the same walk as a 32-channel chunk (gg_blend_fwd_pair)
+struct Seg2 {
+    const float *colors;      // (N, C2)
+    const float *background;  // (C2,)
+    float *out_img;           // (H, W, C2)
+    int C2, nch2;             // row stride and channels used (<= 8)
 };
 typedef WaveListT<1> WaveList;
 
@@ -70,7 +79,8 @@ __device__ __forceinline__ int stage_chunk(LIST &L, int lane, int e, bool valid,
                                            const int32_t *__restrict__ ids,
                                            const GRec *__restrict__ rec,
                                            const float *__restrict__ colors, int C, int ch_off, int nch,
-                                           float xlo, float xhi, float ylo, float yhi) {
+                                           float xlo, float xhi, float ylo, float yhi,
+                                           const Seg2 *seg2 = nullptr) {
     const int g = valid ? ids[e] : 0;
     const float4 ra = reinterpret_cast<const float4 *>(rec + g)[0];
     const float4 rb = reinterpret_cast<const float4 *>(rec + g)[1];
@@ -85,6 +95,13 @@ __device__ __forceinline__ int stage_chunk(LIST &L, int lane, int e, bool valid,
         float4 ra2 = ra;
         if (WIDE) {
             cc.x = __builtin_bit_cast(float, g);
+            if (seg2) {   // the second array's colours ride in the record (d, e)
+                const float *c2 = seg2->colors + (size_t)g * seg2->C2;
+                const int n2 = seg2->nch2;
+                L.d[pos] = make_float4(c2[0], n2 > 1 ? c2[1] : 0.f, n2 > 2 ? c2[2] : 0.f, n2 > 3 ? c2[3] : 0.f);
+                L.e[pos] = make_float4(n2 > 4 ? c2[4] : 0.f, n2 > 5 ? c2[5] : 0.f, n2 > 6 ? c2[6] : 0.f,
+                                       n2 > 7 ? c2[7] : 0.f);
+            }
         } else {
             const float *col = colors + (size_t)g * C + ch_off;
             cc.x = col[0];
@@ -111,6 +128,10 @@ __device__ __forceinline__ int stage_chunk(LIST &L, int lane, int e, bool valid,
         L.b[q] = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, -1));
         L.c[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (CH > 3 && !WIDE) L.d[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (WIDE && seg2) {
+            L.d[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            L.e[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     __builtin_amdgcn_wave_barrier();
     return cnt;
@@ -119,15 +140,18 @@ __device__ __forceinline__ int stage_chunk(LIST &L, int lane, int e, bool valid,
 // =============================================================================================
 // forward
 // =============================================================================================
-template <int CH, bool WIDE, bool FULL>
+// EX: a second colour array of <= 8 channels (Seg2) is blended in the same walk as this 32-channel chunk
+// (gg_blend_fwd_pair: the plugin's feature | rgb+depth+normal forward in one walk instead of two)
+template <int CH, bool WIDE, bool FULL, bool EX = false>
 __global__ __launch_bounds__(256) void blend2_fwd_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
     const float *__restrict__ colors, const float *__restrict__ background,
     float *__restrict__ out_img, float *__restrict__ final_T, int32_t *__restrict__ final_idx,
-    int write_final) {
+    int write_final, Seg2 seg2 = Seg2()) {
     constexpr bool N8 = !WIDE && CH > 3;          // 8-channel narrow record layout
-    typedef WaveListT<N8 ? 2 : 1> LIST;
+    static_assert(!EX || WIDE, "the second array rides on the wide kernel");
+    typedef WaveListT<EX ? 3 : (N8 ? 2 : 1)> LIST;
     __shared__ LIST lists[4];
     const int tile = xcd_tile(blockIdx.x, ntiles);
     if (tile < 0) return;
@@ -146,6 +170,9 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
     int last = range.x;
     bool done = !inside;
     float acc[WIDE ? 1 : CH];
+    float acc2[EX ? 8 : 1];
+#pragma unroll
+    for (int c = 0; c < (EX ? 8 : 1); ++c) acc2[c] = 0.0f;
     f32x16 acc0, acc1;  // WIDE: pixels 0-31 / 32-63 of the quadrant x 32 channels
 #pragma unroll
     for (int c = 0; c < (WIDE ? 1 : CH); ++c) acc[c] = 0.0f;
@@ -158,7 +185,7 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
         if (__ballot(!done) == 0ull) break;
         const int e = base + lane;
         const int cnt = stage_chunk<CH, WIDE, false, LIST>(L, lane, e, e < range.y, ids, rec, colors, C,
-                                                           ch_off, nch, xlo, xhi, ylo, yhi);
+                                                           ch_off, nch, xlo, xhi, ylo, yhi, EX ? &seg2 : nullptr);
         WALK_STAT(0, min(64, range.y - base));
         for (int k = 0; k < cnt; k += GRP) {
             if (k > 0 && __ballot(!done) == 0ull) break;
@@ -210,6 +237,17 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
                 T = blend ? next_T : T;
                 last = blend ? __builtin_bit_cast(int, N8 ? A[q].w : Cc[q].w) : last;
                 done = done || stop;
+                if (EX) {   // the second array's colours: read from the record right where they are used
+                    const float4 xd = L.d[GRP + k + q], xe = L.e[GRP + k + q];
+                    acc2[0] = __builtin_fmaf(xd.x, vis[q], acc2[0]);
+                    acc2[EX ? 1 : 0] = __builtin_fmaf(xd.y, vis[q], acc2[EX ? 1 : 0]);
+                    acc2[EX ? 2 : 0] = __builtin_fmaf(xd.z, vis[q], acc2[EX ? 2 : 0]);
+                    acc2[EX ? 3 : 0] = __builtin_fmaf(xd.w, vis[q], acc2[EX ? 3 : 0]);
+                    acc2[EX ? 4 : 0] = __builtin_fmaf(xe.x, vis[q], acc2[EX ? 4 : 0]);
+                    acc2[EX ? 5 : 0] = __builtin_fmaf(xe.y, vis[q], acc2[EX ? 5 : 0]);
+                    acc2[EX ? 6 : 0] = __builtin_fmaf(xe.z, vis[q], acc2[EX ? 6 : 0]);
+                    acc2[EX ? 7 : 0] = __builtin_fmaf(xe.w, vis[q], acc2[EX ? 7 : 0]);
+                }
                 if (!WIDE) {
                     acc[0] = __builtin_fmaf(Cc[q].x, vis[q], acc[0]);
                     if (CH > 1) acc[CH > 1 ? 1 : 0] = __builtin_fmaf(Cc[q].y, vis[q], acc[CH > 1 ? 1 : 0]);
@@ -243,6 +281,12 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
         const size_t p = (size_t)i * img_w + j;
         final_T[p] = T;
         final_idx[p] = last;
+    }
+    if (EX && inside) {
+        float *o2 = seg2.out_img + ((size_t)i * img_w + j) * seg2.C2;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < seg2.nch2) o2[c] = __builtin_fmaf(T, seg2.background[c], acc2[EX ? c : 0]);
     }
     if (!WIDE) {
         if (inside) {
@@ -655,6 +699,21 @@ void gg_launch_blend2_fwd(int width, int C, int off, int n, int img_h, int img_w
         hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true>), grid, block, 0, s, B2_FWD_ARGS);
     else
         hipLaunchKernelGGL((blend2_fwd_kernel<32, true, false>), grid, block, 0, s, B2_FWD_ARGS);
+}
+
+void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int ntiles, const int32_t *ids,
+                               const int2 *bins, const GRec *rec, const float *colors, const float *background,
+                               float *out_img, float *final_Ts, int32_t *final_idx, const float *colors2, int C2,
+                               const float *background2, float *out_img2, hipStream_t s) {
+    dim3 grid(gg_tile_grid(ntiles)), block(256);
+    Seg2 seg2;
+    seg2.colors = colors2;
+    seg2.background = background2;
+    seg2.out_img = out_img2;
+    seg2.C2 = C2;
+    seg2.nch2 = C2;
+    hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, true>), grid, block, 0, s, C, 0, 32, img_h, img_w,
+                       tiles_x, ntiles, ids, bins, rec, colors, background, out_img, final_Ts, final_idx, 1, seg2);
 }
 
 #define B2_BWDN_ARGS C, off, n, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, \

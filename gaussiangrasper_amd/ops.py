@@ -568,7 +568,19 @@ class RasterizeSegments(Function):
         for attempt in range(2):
             if bins.num_intersects is not None and bins.num_intersects < 1:
                 break
-            for c, b, o in zip(cols_c, bgs_c, outs):
+            # a >= 32-channel array carries a <= 8-channel one through its first forward walk
+            wide = next((i for i, c in enumerate(cols_c) if c.shape[1] >= 32), None)
+            small = next((i for i, c in enumerate(cols_c) if c.shape[1] <= 8), None) if wide is not None else None
+            if small is not None:
+                _lib.check(lib.gg_blend_fwd_pair(
+                    cols_c[wide].shape[1], cols_c[small].shape[1], n, img_height, img_width,
+                    _ptr(bins.gaussian_ids_sorted), _ptr(bins.tile_bins), _ptr(xys_c), _ptr(conics_c),
+                    _ptr(cols_c[wide]), _ptr(cols_c[small]), _ptr(opacity_c), _ptr(bgs_c[wide]), _ptr(bgs_c[small]),
+                    _ptr(outs[wide]), _ptr(outs[small]), _ptr(final_Ts), _ptr(final_idx), _ptr(ws), ws.numel(),
+                    _stream(dev)), "gg_blend_fwd_pair")
+            for i, (c, b, o) in enumerate(zip(cols_c, bgs_c, outs)):
+                if small is not None and i in (wide, small):
+                    continue
                 _lib.check(lib.gg_blend_fwd(c.shape[1], n, img_height, img_width, _ptr(bins.gaussian_ids_sorted),
                                             _ptr(bins.tile_bins), _ptr(xys_c), _ptr(conics_c), _ptr(c),
                                             _ptr(opacity_c), _ptr(b), _ptr(o), _ptr(final_Ts), _ptr(final_idx),

@@ -136,6 +136,19 @@ int gg_blend_fwd(int channels, int num_points, int img_height, int img_width,
                  const float *background, float *out_img, float *final_Ts, int32_t *final_idx,
                  void *ws, size_t ws_bytes, gg_stream_t stream);
 
+/* gg_blend_fwd_pair: gg_blend_fwd of TWO colour arrays over the same Gaussians — colors (N, channels >= 32)
+ * into out_img and colors2 (N, channels2 <= 8) into out_img2 — where the second array is blended in the
+ * same walk as the first 32-channel chunk of the first (its colours ride in the LDS record, 8 more fma
+ * per Gaussian on the VALU while the matrix pipe does the 32 channels).  What `ops.RasterizeSegments`
+ * uses for feature | rgb+depth+normal: one forward walk per view instead of two.  Images are bit-identical
+ * to two gg_blend_fwd calls. */
+int gg_blend_fwd_pair(int channels, int channels2, int num_points, int img_height, int img_width,
+                      const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+                      const float *conics, const float *colors, const float *colors2,
+                      const float *opacity, const float *background, const float *background2,
+                      float *out_img, float *out_img2, float *final_Ts, int32_t *final_idx, void *ws,
+                      size_t ws_bytes, gg_stream_t stream);
+
 /* gg_blend_bwd replaces gsplat `_C.rasterize_backward` / `_C.nd_rasterize_backward`.
  * v_xy (N,2), v_conic (N,3), v_colors (N,C), v_opacity (N,) are fully written.
  * ws_from_forward != 0: `ws` is the very workspace the matching gg_blend_fwd call (same xys, conics,
@@ -278,6 +291,7 @@ int gg_adam_step(int num_groups, const gg_adam_group_t *groups, int zero_grad, g
 #define GG_K_MLP_BWD 9
 #define GG_K_BLEND_FWD 10 /* + width index: template widths {1,3,4,8,16,32} -> 0..5 */
 #define GG_K_BLEND_BWD 20 /* + width index */
+#define GG_K_BLEND_FWD_PAIR 16 /* 32 channels + a second array of <= 8 in one walk */
 #define GG_K_COMPACT 26
 #define GG_K_DENSIFY 27
 #define GG_K_ADAM 28

@@ -44,6 +44,8 @@ SIGNATURES = {
     "gg_sh_bwd_accumulate": (_I, [_I, _I, _I, _P, _P, _P, _P]),
     "gg_quat_to_rotmat_fwd": (_I, [_I, _P, _P, _P]),
     "gg_quat_to_rotmat_bwd": (_I, [_I, _P, _P, _P, _P]),
+    "gg_activate_fwd": (_I, [_I] + [_P] * 12),
+    "gg_activate_bwd": (_I, [_I] + [_P] * 12),
     "gg_mlp_fwd": (_I, [_I64, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "gg_mlp_bwd": (_I, [_I64, _I, _I, _I] + [_P] * 11),
     "gg_cosine_loss_fwd": (_I, [_I64, _I, _P, _P, _P, _P, _P, _P, _P]),
@@ -56,6 +58,7 @@ SIGNATURES = {
     "gg_blend_workspace": (_SZ, [_I]),
     "gg_blend_fwd": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gg_blend_fwd_pair": (_I, [_I, _I, _I, _I, _I] + [_P] * 14 + [_SZ, _P]),
+    "gg_blend_bwd_pair": (_I, [_I, _I, _I, _I, _I] + [_P] * 18 + [_I, _I, _P, _SZ, _I, _P]),
     "gg_blend_bwd": (_I, [_I, _I, _I, _I] + [_P] * 14 + [_I, _I, _P, _SZ, _I, _P]),
     "gg_expf_array": (_I, [_I, _P, _P, _P]),
     "gg_rows_workspace": (_SZ, [_I]),

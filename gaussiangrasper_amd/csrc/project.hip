@@ -615,6 +615,136 @@ extern "C" int gg_quat_to_rotmat_bwd(int N, const float *quats, const float *v_r
     return GG_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Caller-side activations of one view in one kernel each way: what the reference's
+// `get_outputs` does with ~12 torch launches forward and ~25 backward per view —
+//   torch.exp(scales) :701, quats / quats.norm(dim=-1, keepdim=True) :703, torch.sigmoid(opacities) :742,
+//   viewdirs = normalize(means.detach() - camera position) :727-728, and get_normals() :605-619 =
+//   the column of quat_to_rotmat(quats) at argmin(exp(scales)).
+// Used by the plugin's fused model (pipeline.activate_fused); the shim route keeps the caller's torch ops.
+// One lane per Gaussian; O(N), ~70 B read and ~70 B written per Gaussian.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void activate_fwd_kernel(
+    int N, const float *__restrict__ means, const float *__restrict__ log_scales,
+    const float4 *__restrict__ quats, const float *__restrict__ opacities, const float *__restrict__ cam_pos,
+    float *__restrict__ scales, float4 *__restrict__ quats_n, float *__restrict__ opac,
+    float *__restrict__ viewdirs, float *__restrict__ normals, int32_t *__restrict__ axis) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float e[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        e[k] = expf(log_scales[3 * (size_t)i + k]);
+        scales[3 * (size_t)i + k] = e[k];
+    }
+    int ax = 0;                                   // first minimum, as torch.min(dim) reports it
+    if (e[1] < e[ax]) ax = 1;
+    if (e[2] < e[ax]) ax = 2;
+    axis[i] = ax;
+    const float4 q = quats[i];
+    const float n = sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
+    quats_n[i] = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);           // :703 (no eps, as the reference)
+    float w, x, y, z;
+    quat_normalise(q, w, x, y, z);                                            // F.normalize inside quat_to_rotmat
+    float col[3];
+    if (ax == 0) { col[0] = 1.0f - 2.0f * (y * y + z * z); col[1] = 2.0f * (x * y + w * z); col[2] = 2.0f * (x * z - w * y); }
+    else if (ax == 1) { col[0] = 2.0f * (x * y - w * z); col[1] = 1.0f - 2.0f * (x * x + z * z); col[2] = 2.0f * (y * z + w * x); }
+    else { col[0] = 2.0f * (x * z + w * y); col[1] = 2.0f * (y * z - w * x); col[2] = 1.0f - 2.0f * (x * x + y * y); }
+    opac[i] = 1.0f / (1.0f + expf(-opacities[i]));
+    float d[3], dn = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        d[k] = means[3 * (size_t)i + k] - cam_pos[k];
+        dn += d[k] * d[k];
+    }
+    dn = sqrtf(dn);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        viewdirs[3 * (size_t)i + k] = d[k] / dn;
+        normals[3 * (size_t)i + k] = col[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void activate_bwd_kernel(
+    int N, const float4 *__restrict__ quats, const float *__restrict__ scales, const float *__restrict__ opac,
+    const int32_t *__restrict__ axis, const float *__restrict__ v_scales, const float4 *__restrict__ v_quats_n,
+    const float *__restrict__ v_opac, const float *__restrict__ v_normals, float *__restrict__ v_log_scales,
+    float4 *__restrict__ v_quats, float *__restrict__ v_opacities) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        v_log_scales[3 * (size_t)i + k] = v_scales[3 * (size_t)i + k] * scales[3 * (size_t)i + k];
+    const float s = opac[i];
+    v_opacities[i] = v_opac[i] * (s * (1.0f - s));
+    // q / |q|
+    const float4 q = quats[i];
+    const float n = sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
+    const float4 qh = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
+    const float4 g = v_quats_n[i];
+    const float dot = ((qh.x * g.x + qh.y * g.y) + qh.z * g.z) + qh.w * g.w;
+    float4 out = make_float4((g.x - qh.x * dot) / n, (g.y - qh.y * dot) / n, (g.z - qh.z * dot) / n,
+                             (g.w - qh.w * dot) / n);
+    // the normal: one column of R(q / max(|q|, eps))
+    float w, x, y, z;
+    const float d = quat_normalise(q, w, x, y, z);
+    const int ax = axis[i];
+    const float n0 = v_normals[3 * (size_t)i], n1 = v_normals[3 * (size_t)i + 1], n2 = v_normals[3 * (size_t)i + 2];
+    float G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // v_R: only column `ax`
+    G[ax] = n0;
+    G[3 + ax] = n1;
+    G[6 + ax] = n2;
+    float vw = 2.0f * (x * (G[7] - G[5]) + y * (G[2] - G[6]) + z * (G[3] - G[1]));
+    float vx = 2.0f * (y * (G[1] + G[3]) + z * (G[2] + G[6]) + w * (G[7] - G[5]) - 2.0f * x * (G[4] + G[8]));
+    float vy = 2.0f * (x * (G[1] + G[3]) + z * (G[5] + G[7]) + w * (G[2] - G[6]) - 2.0f * y * (G[0] + G[8]));
+    float vz = 2.0f * (x * (G[2] + G[6]) + y * (G[5] + G[7]) + w * (G[3] - G[1]) - 2.0f * z * (G[0] + G[4]));
+    if (d > GG_QUAT_NORM_EPS) {
+        const float dt = ((w * vw + x * vx) + y * vy) + z * vz;
+        out.x += (vw - w * dt) / d;
+        out.y += (vx - x * dt) / d;
+        out.z += (vy - y * dt) / d;
+        out.w += (vz - z * dt) / d;
+    } else {
+        out.x += vw / d;
+        out.y += vx / d;
+        out.z += vy / d;
+        out.w += vz / d;
+    }
+    v_quats[i] = out;
+}
+
+extern "C" int gg_activate_fwd(int N, const float *means, const float *log_scales, const float *quats,
+                               const float *opacities, const float *cam_pos, float *scales, float *quats_n,
+                               float *opac, float *viewdirs, float *normals, int32_t *axis,
+                               gg_stream_t stream) {
+    GG_REQUIRE(N >= 0, "num_points < 0");
+    if (N == 0) return GG_OK;
+    GG_REQUIRE(means && log_scales && quats && opacities && cam_pos && scales && quats_n && opac && viewdirs &&
+                   normals && axis, "null pointer");
+    GG_REQUIRE((((uintptr_t)quats | (uintptr_t)quats_n) & 15) == 0, "quats / quats_n must be 16-byte aligned");
+    hipLaunchKernelGGL(activate_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, means,
+                       log_scales, (const float4 *)quats, opacities, cam_pos, scales, (float4 *)quats_n, opac,
+                       viewdirs, normals, axis);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+extern "C" int gg_activate_bwd(int N, const float *quats, const float *scales, const float *opac,
+                               const int32_t *axis, const float *v_scales, const float *v_quats_n,
+                               const float *v_opac, const float *v_normals, float *v_log_scales,
+                               float *v_quats, float *v_opacities, gg_stream_t stream) {
+    GG_REQUIRE(N >= 0, "num_points < 0");
+    if (N == 0) return GG_OK;
+    GG_REQUIRE(quats && scales && opac && axis && v_scales && v_quats_n && v_opac && v_normals && v_log_scales &&
+                   v_quats && v_opacities, "null pointer");
+    GG_REQUIRE((((uintptr_t)quats | (uintptr_t)v_quats_n | (uintptr_t)v_quats) & 15) == 0,
+               "quaternion arrays must be 16-byte aligned");
+    hipLaunchKernelGGL(activate_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N,
+                       (const float4 *)quats, scales, opac, axis, v_scales, (const float4 *)v_quats_n, v_opac,
+                       v_normals, v_log_scales, (float4 *)v_quats, v_opacities);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
 __global__ void expf_kernel(int n, const float *x, float *y) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = gg_expf(x[i]);

@@ -525,6 +525,51 @@ class NDRasterizeGaussians(Function):
 
 
 # ------------------------------------------------------------------------------------------------
+# caller-side activations of a view in one kernel each way
+# ------------------------------------------------------------------------------------------------
+class ActivateGaussians(Function):
+    """apply(means, log_scales, quats, opacities (N,1) logits, cam_pos (3,)) ->
+    (scales (N,3), quats_n (N,4), opac (N,1), viewdirs (N,3), normals (N,3)): the reference's
+    `torch.exp(scales)` (:701), `quats / quats.norm(dim=-1, keepdim=True)` (:703),
+    `torch.sigmoid(opacities)` (:742), view directions (:727-728, no gradient) and `get_normals()`
+    (:605-619) — ~12 torch launches forward and ~25 backward per view in the reference, one launch each
+    way here.  Used by the plugin's fused model; the shim route leaves the caller's torch ops alone."""
+
+    @staticmethod
+    def forward(ctx, means, log_scales, quats, opacities, cam_pos):
+        dev = _require_hip(means, log_scales, quats, opacities, cam_pos)
+        n = means.shape[0]
+        if tuple(log_scales.shape) != (n, 3) or tuple(quats.shape) != (n, 4) or opacities.numel() != n:
+            raise ValueError("expected means (N,3), scales (N,3), quats (N,4), opacities (N,1)")
+        m, s, q, o, c = _f32(means), _f32(log_scales), _f32(quats), _f32(opacities), _f32(cam_pos).reshape(-1)
+        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        scales, quats_n, opac, viewdirs, normals = f(n, 3), f(n, 4), f(n, 1), f(n, 3), f(n, 3)
+        axis = torch.empty(n, dtype=torch.int32, device=dev)
+        _lib.check(_lib.load().gg_activate_fwd(n, _ptr(m), _ptr(s), _ptr(q), _ptr(o), _ptr(c), _ptr(scales),
+                                               _ptr(quats_n), _ptr(opac), _ptr(viewdirs), _ptr(normals), _ptr(axis),
+                                               _stream(dev)), "gg_activate_fwd")
+        ctx.save_for_backward(q, scales, opac, axis)
+        ctx.opacity_shape = tuple(opacities.shape)
+        ctx.mark_non_differentiable(viewdirs)
+        return scales, quats_n, opac.reshape(ctx.opacity_shape), viewdirs, normals
+
+    @staticmethod
+    def backward(ctx, v_scales, v_quats_n, v_opac, v_viewdirs, v_normals):
+        q, scales, opac, axis = ctx.saved_tensors
+        dev, n = q.device, q.shape[0]
+        z = lambda t, *shape: torch.zeros(*shape, dtype=torch.float32, device=dev) if t is None else _f32(t)
+        v_scales, v_quats_n = z(v_scales, n, 3), z(v_quats_n, n, 4)
+        v_opac, v_normals = z(v_opac, n, 1), z(v_normals, n, 3)
+        v_ls = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        v_q = torch.empty(n, 4, dtype=torch.float32, device=dev)
+        v_o = torch.empty(n, 1, dtype=torch.float32, device=dev)
+        _lib.check(_lib.load().gg_activate_bwd(n, _ptr(q), _ptr(scales), _ptr(opac), _ptr(axis), _ptr(v_scales),
+                                               _ptr(v_quats_n), _ptr(v_opac), _ptr(v_normals), _ptr(v_ls), _ptr(v_q),
+                                               _ptr(v_o), _stream(dev)), "gg_activate_bwd")
+        return None, v_ls, v_q, v_o.reshape(ctx.opacity_shape), None
+
+
+# ------------------------------------------------------------------------------------------------
 # several colour arrays from one binning (SURVEY 8f-1: what the plugin's fused model calls)
 # ------------------------------------------------------------------------------------------------
 class RasterizeSegments(Function):
@@ -625,6 +670,33 @@ class RasterizeSegments(Function):
         order = ([rider] if rider is not None else []) + [i for i in range(k) if i != rider]
         grads = [None] * k
         first = True
+        zeros = lambda ch: torch.zeros(img_height, img_width, ch, dtype=torch.float32, device=dev)
+        # a >= 32-channel array and the small rider: ONE geometry-gradient computation for both (the wide
+        # walk carries the rider's channels in D and W; the rider's walk reduces colour gradients only)
+        wide = next((i for i in range(k) if cols[i].shape[1] >= 32), None) if rider is not None else None
+        if wide is not None:
+            vo_w = _f32(v_outs[wide]) if v_outs[wide] is not None else zeros(cols[wide].shape[1])
+            vo_r = _f32(v_outs[rider]) if v_outs[rider] is not None else zeros(cols[rider].shape[1])
+            sink = ctx.sinks[wide]
+            flags = 1
+            if sink is not None:
+                v_colors, flags = sink[1], flags | 2
+            else:
+                v_colors = torch.empty(n, cols[wide].shape[1], dtype=torch.float32, device=dev)
+            _lib.check(lib.gg_blend_bwd_pair(
+                cols[wide].shape[1], cols[rider].shape[1], n, img_height, img_width, _ptr(ids_sorted),
+                _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(cols[wide]), _ptr(cols[rider]), _ptr(opacity),
+                _ptr(bgs[wide]), _ptr(bgs[rider]), _ptr(final_Ts), _ptr(final_idx), _ptr(vo_w), _ptr(vo_r),
+                _ptr(v_xy), _ptr(v_conic), _ptr(v_colors), _ptr(rec_g[:, 6:]), _ptr(v_opacity), gstride, gstride,
+                _ptr(ws), ws.numel(), flags, _stream(dev)), "gg_blend_bwd_pair")
+            if flags & 2:
+                if sink[2] is not None:
+                    sink[2](sink[0])
+            else:
+                grads[wide] = v_colors
+            grads[rider] = rec_g[:, 6:]
+            first = False
+            order = [i for i in order if i not in (wide, rider)]
         for i in order:
             ch = cols[i].shape[1]
             v_out = v_outs[i]

@@ -43,6 +43,17 @@ def activate(scene: Scene, view: ViewParams, quat_to_rotmat) -> Dict[str, Union[
     }
 
 
+def activate_fused(scene: Scene, view: ViewParams, ops) -> Dict[str, Union[torch.Tensor, Callable]]:
+    """`activate` through ONE operator (ops.ActivateGaussians: one kernel forward, one backward) where the
+    operator namespace has it; same dictionary, opacity activated once."""
+    if not hasattr(ops, "ActivateGaussians"):
+        return activate(scene, view, ops.quat_to_rotmat)
+    scales, quats_n, opac, viewdirs, normals = ops.ActivateGaussians.apply(
+        scene.means, scene.scales, scene.quats, scene.opacities, view.cam_pos.to(scene.means.device))
+    return {"means": scene.means, "scales": scales, "quats": quats_n, "opac": opac, "viewdirs": viewdirs,
+            "sh": scene.colors_all, "feature": scene.feature, "normals": normals}
+
+
 def rasterize_activated(act: Dict, view: ViewParams, ops, sh_degree_to_use: int = 4,
                         channels=CHANNELS) -> Dict[str, torch.Tensor]:
     dev = act["means"].device
@@ -127,9 +138,9 @@ def rasterize_activated_fused(act: Dict, view: ViewParams, ops, sh_degree_to_use
 
 def render_view(scene: Scene, view: ViewParams, ops, sh_degree_to_use: int = 4,
                 channels=CHANNELS, fused: bool = False) -> Dict[str, torch.Tensor]:
+    if fused:      # the plugin route: fused activations, one rasterize operator
+        return rasterize_activated_fused(activate_fused(scene, view, ops), view, ops, sh_degree_to_use)
     act = activate(scene, view, ops.quat_to_rotmat)
-    if fused:
-        return rasterize_activated_fused(act, view, ops, sh_degree_to_use)
     return rasterize_activated(act, view, ops, sh_degree_to_use, channels)
 
 

@@ -41,27 +41,34 @@ def fused_view(model, means, log_scales, quats, opacities, colors_all, feature, 
                ) -> Optional[Dict[str, torch.Tensor]]:
     """Operator part of `get_outputs` (reference :699-784) with the four rasterize calls fused.
     Sets model.xys / model.radii / model.normals as the reference does.  None if nothing is visible."""
+    fused_act = hasattr(ops, "ActivateGaussians")
+    if fused_act:      # exp / normalise / sigmoid / view directions / normals: one kernel each way
+        scales_e, quats_n, opac, viewdirs, model.normals = ops.ActivateGaussians.apply(
+            means, log_scales, quats, opacities, cam_pos.reshape(-1)[:3])
+    else:
+        scales_e, quats_n = torch.exp(log_scales), quats / quats.norm(dim=-1, keepdim=True)
+        opac = torch.sigmoid(opacities)
     model.xys, depths, model.radii, conics, num_tiles_hit, _cov3d = ops.ProjectGaussians.apply(
-        means, torch.exp(log_scales), 1, quats / quats.norm(dim=-1, keepdim=True), viewmat[:3, :],
-        projmat @ viewmat, fx, fy, cx, cy, H, W, tile_bounds)
+        means, scales_e, 1, quats_n, viewmat[:3, :], projmat @ viewmat, fx, fy, cx, cy, H, W, tile_bounds)
     if (model.radii).sum() == 0:                                   # :714
         return None
     if model.training:
         model.xys.retain_grad()                                    # :724-725
     if model.config.sh_degree > 0:
-        viewdirs = means.detach() - cam_pos                        # :727-728
-        viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
+        if not fused_act:
+            viewdirs = means.detach() - cam_pos                    # :727-728
+            viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
         rgbs = ops.SphericalHarmonics.apply(sh_degree_to_use, viewdirs, colors_all)
         rgbs = torch.clamp(rgbs + 0.5, 0.0, 1.0)                   # :731
     else:
         rgbs = torch.sigmoid(colors_all[:, 0, :])
-    # smallest-axis normals (:605-619) of the rendered subset
-    rot = ops.quat_to_rotmat(quats)
-    idx = log_scales.exp().min(dim=-1)[1][..., None, None].expand(-1, 3, -1)
-    model.normals = rot.gather(2, idx).squeeze(dim=2)
+    if not fused_act:  # smallest-axis normals (:605-619) of the rendered subset
+        rot = ops.quat_to_rotmat(quats)
+        idx = log_scales.exp().min(dim=-1)[1][..., None, None].expand(-1, 3, -1)
+        model.normals = rot.gather(2, idx).squeeze(dim=2)
     # feature | rgb | depth (background 10, :769) | normal from one binning (pipeline.fused_images)
     feat_im, rgb, depth_im, normal_im = fused_images(ops, model.xys, depths, model.radii, conics, num_tiles_hit,
-                                                     torch.sigmoid(opacities), H, W, feature, rgbs, model.normals)
+                                                     opac, H, W, feature, rgbs, model.normals)
     return {"rgb": rgb, "feature": feat_im, "depth": depth_im, "normal": normal_im}
 
 

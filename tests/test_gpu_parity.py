@@ -826,3 +826,34 @@ def test_rasterize_segments_equals_separate_calls(oracle):
     assert_close(_np(ot.grad), ref_g[3].reshape(_np(ot.grad).shape), "segments.v_opacity", rtol=5e-5, atol_frac=1e-6)
     for i in range(3):
         assert_close(_np(cts[i].grad), ref_g[2][i], f"segments.v_colors[{i}]", rtol=5e-5, atol_frac=1e-6)
+
+
+def test_fused_activations_match_the_callers_torch_ops():
+    """ops.ActivateGaussians (one kernel each way) against the torch ops the reference's get_outputs runs
+    (:701,:703,:742,:727-728,:605-619) on the same device: values to 1e-6 (expf of ocml vs torch's), argmin
+    axis identical, gradients of a random cotangent to 1e-5"""
+    n = 50_000
+    sc = make_scene(n, config_index=11).to(DEV)
+    cam = torch.tensor([0.3, -2.0, 1.1], device=DEV)
+    cot = [torch.randn(n, k, device=DEV) for k in (3, 4, 1, 3)]
+
+    def ref(means, scales, quats, opacities):
+        rot = P.quat_to_rotmat(quats)
+        idx = scales.exp().min(dim=-1)[1][..., None, None].expand(-1, 3, -1)
+        vd = means.detach() - cam
+        return (torch.exp(scales), quats / quats.norm(dim=-1, keepdim=True), torch.sigmoid(opacities),
+                vd / vd.norm(dim=-1, keepdim=True), rot.gather(2, idx).squeeze(dim=2))
+
+    outs, grads = [], []
+    for fn in (ref, lambda m, s, q, o: P.ActivateGaussians.apply(m, s, q, o, cam)):
+        leaves = [t.detach().clone().requires_grad_(True) for t in (sc.means, sc.scales, sc.quats, sc.opacities)]
+        o = fn(*leaves)
+        torch.autograd.backward([o[0], o[1], o[2], o[4]], cot)
+        outs.append([t.detach() for t in o])
+        grads.append([t.grad for t in leaves])
+    for name, a, b in zip(("scales", "quats_n", "opac", "viewdirs", "normals"), outs[1], outs[0]):
+        assert a.shape == b.shape, name
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), name
+    assert grads[1][0] is None or not grads[1][0].any()          # means: no gradient (viewdirs detached)
+    for name, a, b in zip(("scales", "quats", "opacities"), grads[1][1:], grads[0][1:]):
+        assert torch.allclose(a, b, rtol=2e-5, atol=1e-6 * float(b.abs().max())), name

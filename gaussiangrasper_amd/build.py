@@ -23,10 +23,11 @@ FLAGS = ["-O3", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off"
          "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
-def _stale() -> bool:
-    if not os.path.exists(OUT):
+def _stale(out: str = None) -> bool:
+    out = out or OUT
+    if not os.path.exists(out):
         return True
-    t = os.path.getmtime(OUT)
+    t = os.path.getmtime(out)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     deps += [os.path.join(HERE, "..", "include", f) for f in ("gg_raster.h", "gg_constants.h")]
     return any(os.path.getmtime(d) > t for d in deps)
@@ -56,9 +57,12 @@ COMPAT_OUT = os.path.join(HERE, "libgg_raster_compat.so")
 COMPAT_FLAGS = ("-DGG_VJP_GSPLAT_COMPAT=1", "-DGG_ALPHA_MAX_BWD=0.99f")
 
 
-def build_compat(verbose: bool = False) -> str:
+def build_compat(verbose: bool = False, force: bool = True) -> str:
     """Variant with the recalled gsplat-0.1.0 deviations switched on (include/gg_constants.h, PARITY.md):
-    tests/test_compat_variant.py holds it to the oracle built with the same switches.  Not the product."""
+    tests/test_compat_variant.py holds it to the oracle built with the same switches.  Not the product.
+    force=False rebuilds only when a source is newer than the library."""
+    if not force and not _stale(COMPAT_OUT):
+        return COMPAT_OUT
     return build(force=True, verbose=verbose, extra_flags=COMPAT_FLAGS, out=COMPAT_OUT)
 
 
@@ -70,3 +74,5 @@ if __name__ == "__main__":
     else:
         build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or True)
         print(OUT)
+        if "--all" in sys.argv:
+            print(build_compat(verbose=True))

@@ -63,13 +63,6 @@ void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
                                float *out_img, float *final_Ts, int32_t *final_idx, const float *colors2, int C2,
                                const float *background2, float *out_img2, hipStream_t s);
 
-void gg_launch_blend2_bwd_pair(int C, int img_h, int img_w, int tiles_x, int ntiles, const int32_t *ids,
-                               const int2 *bins, const GRec *rec, const float *colors, const float *background,
-                               const float *final_Ts, const int32_t *final_idx, const float *v_out, float *v_xy,
-                               float *v_conic, float *v_colors, float *v_opacity, int gstride, int cstride,
-                               const float *colors2, int C2, const float *background2, const float *v_out2,
-                               float *v_colors2, int cstride2, hipStream_t s);
-
 // Channel chunking: calls with <= 3 channels (rgb / depth / normal) use the narrow kernels with
 // the colours inside the LDS record; anything wider is processed in chunks of 32 channels on the
 // MFMA kernels (a final partial chunk is zero-padded), each chunk re-walking the tile lists.
@@ -263,72 +256,6 @@ extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *i
                                  color_stride, s);
         gg_prof_end(GG_K_BLEND_BWD + gg_width_index(w), s);
         off += n;
-    }
-    GG_CHECK_LAUNCH();
-    return GG_OK;
-}
-
-// Backward of gg_blend_fwd_pair.  The wide kernel of the first 32-channel chunk carries the second array's
-// channels in D and W, so it produces the geometry gradients of BOTH arrays; the second array's own kernel
-// only reduces its colour gradients (no D, W, v_alpha, geometry partials: a 32-value butterfly per group
-// instead of 56).  Geometry gradients: ONE interleaved record of geom_stride >= 6 floats per Gaussian
-// (v_conic = v_xy + 2, v_opacity = v_xy + 5), cleared here; v_colors (N, C) dense (cleared here unless
-// GG_BWD_ACCUMULATE_COLORS); v_colors2 with color2_stride floats between Gaussians (inside the record when
-// v_colors2 = v_xy + 6 and color2_stride = geom_stride, else cleared here).
-extern "C" int gg_blend_bwd_pair(int C, int C2, int N, int img_h, int img_w, const int32_t *ids,
-                                 const int32_t *tile_bins, const float *xys, const float *conics,
-                                 const float *colors, const float *colors2, const float *opacity,
-                                 const float *background, const float *background2, const float *final_Ts,
-                                 const int32_t *final_idx, const float *v_out, const float *v_out2,
-                                 float *v_xy, float *v_conic, float *v_colors, float *v_colors2,
-                                 float *v_opacity, int geom_stride, int color2_stride, void *ws,
-                                 size_t ws_bytes, int flags, gg_stream_t stream) {
-    GG_REQUIRE(C >= 32, "the first colour array needs >= 32 channels");
-    GG_REQUIRE(C2 >= 1 && C2 <= 8, "the second colour array has 1..8 channels");
-    GG_REQUIRE(N >= 0, "num_points < 0");
-    GG_REQUIRE(img_h > 0 && img_w > 0, "empty image");
-    if (N == 0) return GG_OK;
-    GG_REQUIRE(ids && tile_bins && xys && conics && colors && colors2 && opacity && background && background2 &&
-                   final_Ts && final_idx && v_out && v_out2 && v_xy && v_conic && v_colors && v_colors2 && v_opacity,
-               "null pointer");
-    GG_REQUIRE(geom_stride >= 6 && v_conic == v_xy + 2 && v_opacity == v_xy + 5,
-               "geometry gradients must be one interleaved record (geom_stride >= 6)");
-    GG_REQUIRE(color2_stride >= C2, "color2_stride must be >= channels2");
-    if (ws == nullptr || ws_bytes < gg_blend_workspace(N)) {
-        gg_set_error("gg_blend_bwd_pair: workspace too small");
-        return GG_ERR_WORKSPACE;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    GRec *rec = (GRec *)ws;
-    if (!(flags & GG_BWD_WS_FROM_FORWARD)) {
-        gg_prof_begin(GG_K_BLEND_PREP, s);
-        hipLaunchKernelGGL(blend_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, xys, conics, opacity, rec);
-        gg_prof_end(GG_K_BLEND_PREP, s);
-    }
-    const size_t n = (size_t)N;
-    bool fail = hipMemsetAsync(v_xy, 0, sizeof(float) * geom_stride * n, s) != hipSuccess;
-    if (!(flags & GG_BWD_ACCUMULATE_COLORS))
-        fail |= hipMemsetAsync(v_colors, 0, sizeof(float) * (size_t)C * n, s) != hipSuccess;
-    const bool in_record = (v_colors2 == v_xy + 6) && color2_stride == geom_stride;
-    if (!in_record) fail |= hipMemsetAsync(v_colors2, 0, sizeof(float) * (size_t)color2_stride * n, s) != hipSuccess;
-    if (fail) {
-        gg_set_error("gg_blend_bwd_pair: memset failed");
-        return GG_ERR_LAUNCH;
-    }
-    const int tiles_x = (img_w + GG_BLOCK - 1) / GG_BLOCK, tiles_y = (img_h + GG_BLOCK - 1) / GG_BLOCK;
-    const int ntiles = tiles_x * tiles_y;
-    gg_launch_blend2_bwd_pair(C, img_h, img_w, tiles_x, ntiles, ids, (const int2 *)tile_bins, rec, colors,
-                              background, final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity,
-                              geom_stride, 0, colors2, C2, background2, v_out2, v_colors2, color2_stride, s);
-    for (int off = 32; off < C;) {     // further chunks of the first array: full kernels, adding their geometry
-        const int w = chunk_width(C - off);
-        const int nn = min(w, C - off);
-        gg_prof_begin(GG_K_BLEND_BWD + gg_width_index(w), s);
-        gg_launch_blend2_bwd(w, C, off, nn, img_h, img_w, tiles_x, ntiles, ids, (const int2 *)tile_bins, rec,
-                             colors, background, final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity,
-                             geom_stride, 0, s);
-        gg_prof_end(GG_K_BLEND_BWD + gg_width_index(w), s);
-        off += nn;
     }
     GG_CHECK_LAUNCH();
     return GG_OK;

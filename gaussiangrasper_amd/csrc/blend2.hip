@@ -327,9 +327,7 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
 //   1 = no global atomics, 2 = also no butterfly, 3 = also no recurrence/partials (geometry only),
 //   4 = staging + cull only (no group loop)
 #define KEEP(x) asm volatile("" ::"v"(x))
-// CONLY: only the colour gradients (fac = alpha * T needs no D, W or v_alpha): the geometry gradients of
-// this array are produced by the wide kernel of the pair (EX2), which carries its channels in D and W.
-template <int CH, int ABL = 0, bool CONLY = false>
+template <int CH, int ABL = 0>
 __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
@@ -337,8 +335,8 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
     const float *__restrict__ final_T, const int32_t *__restrict__ final_idx,
     const float *__restrict__ v_out, float *__restrict__ v_xy, float *__restrict__ v_conic,
     float *__restrict__ v_colors, float *__restrict__ v_opacity, int gstride, int cstride) {
-    constexpr int K = CONLY ? CH : CH + 6;   // per-Gaussian values: CH colours[, xy(2), conic(3), opacity(1)]
-    constexpr int KB = GRP * K;              // butterfly width
+    constexpr int K = CH + 6;       // per-Gaussian values: CH colours, xy(2), conic(3), opacity(1)
+    constexpr int KB = GRP * K;     // butterfly width
     using R = Red6<KB>;
     constexpr bool N8 = CH > 3;
     typedef WaveListT<N8 ? 2 : 1> LIST;
@@ -390,7 +388,6 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
         my_stride = cstride ? cstride : C;
         owner = owner && (!N8 || my_k < nch);      // channels past nch belong to the next row
     }
-    else if (CONLY) { my_base = v_colors; my_stride = 0; owner = false; }
     else if (my_k < CH + 2) { my_base = v_xy + (my_k - CH); my_stride = gstride ? gstride : 2; }
     else if (my_k < CH + 5) { my_base = v_conic + (my_k - CH - 2); my_stride = gstride ? gstride : 3; }
     else { my_base = v_opacity; my_stride = gstride ? gstride : 1; }
@@ -439,12 +436,6 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
                 const float ra_ = __builtin_amdgcn_rcpf(1.0f - alpha[q]);
                 const float Tn = T * ra_;
                 const float fac = pass[q] ? alpha[q] * Tn : 0.0f;
-                if (CONLY) {
-#pragma unroll
-                    for (int c = 0; c < CH; ++c) part[q * K + c] = fac * vo[c];
-                    T = pass[q] ? Tn : T;
-                    continue;
-                }
                 float D = Cc[q].x * vo[0];
                 if (CH > 1) D = __builtin_fmaf(Cc[q].y, vo[CH > 1 ? 1 : 0], D);
                 if (CH > 2) D = __builtin_fmaf(Cc[q].z, vo[CH > 2 ? 2 : 0], D);
@@ -504,25 +495,14 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
 // 3 also no butterfly / geometry atomics, 4 also no D (colour loads + 32 fma), 5 geometry only
 // CHD: channels of this chunk rounded up to 8, 16 or 32 — registers for v_out and the length of the
 // D loop (a 7-channel tail chunk, e.g. rgb+depth+normal of the fused call, does not pay for 32).
-// Second colour array of a pair (gg_blend_bwd_pair): its <= 8 channels enter D = <colour, v_out> and W of
-// THIS walk, so that this kernel produces the geometry gradients of both arrays and the second array's own
-// backward only has to reduce its colour gradients (blend2_bwd_narrow_kernel<8, 0, true>).
-struct Seg2B {
-    const float *colors;      // (N, C2)
-    const float *background;  // (C2,)
-    const float *v_out;       // (H, W, C2)
-    int C2, nch2;
-};
-
-template <bool FULL, int ABL = 0, int CHD = 32, bool EX2 = false>
+template <bool FULL, int ABL = 0, int CHD = 32>
 __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
     const float *__restrict__ colors, const float *__restrict__ background,
     const float *__restrict__ final_T, const int32_t *__restrict__ final_idx,
     const float *__restrict__ v_out, float *__restrict__ v_xy, float *__restrict__ v_conic,
-    float *__restrict__ v_colors, float *__restrict__ v_opacity, int gstride, int cstride,
-    Seg2B seg2 = Seg2B()) {
+    float *__restrict__ v_colors, float *__restrict__ v_opacity, int gstride, int cstride) {
     constexpr int CH = CHD;
     constexpr int KG = 6;
     constexpr int KB = GRP * KG;
@@ -560,16 +540,6 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
             if (FULL || c < nch) Bsum = __builtin_fmaf(background[ch_off + c], vo[c], Bsum);
         }
         W = T_final * Bsum;
-    }
-    float vo2[EX2 ? 8 : 1];
-    if (EX2) {
-        float B2 = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            vo2[EX2 ? c : 0] = (inside && c < seg2.nch2) ? seg2.v_out[p * seg2.C2 + c] : 0.0f;
-            if (c < seg2.nch2) B2 = __builtin_fmaf(seg2.background[c], vo2[EX2 ? c : 0], B2);
-        }
-        W = __builtin_fmaf(T_final, B2, W);
     }
     const int wch = lane & 31, half = lane >> 5;
     const bool wch_ok = FULL || wch < nch;
@@ -671,16 +641,6 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
                     d3 = __builtin_fmaf((FULL || c + 3 < nch) ? col[c + 3] : 0.f, vo[c + 3], d3);
                 }
                 float D = (d0 + d1) + (d2 + d3);
-                if (EX2) {   // the second array's colours: wave-uniform scalar loads like the row above
-                    const float *c2 = seg2.colors + (size_t)gid * seg2.C2;
-                    float e0 = 0.f, e1 = 0.f;
-#pragma unroll
-                    for (int c = 0; c < 8; c += 2) {
-                        e0 = __builtin_fmaf(c < seg2.nch2 ? c2[c] : 0.f, vo2[EX2 ? c : 0], e0);
-                        e1 = __builtin_fmaf(c + 1 < seg2.nch2 ? c2[c + 1] : 0.f, vo2[EX2 ? c + 1 : 0], e1);
-                    }
-                    D += e0 + e1;
-                }
                 if (ABL >= 4) D = vo[0] * (float)gid;
                 const float ra_ = __builtin_amdgcn_rcpf(1.0f - alpha[q]);
                 const float Tn = T * ra_;
@@ -754,33 +714,6 @@ void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
     seg2.nch2 = C2;
     hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, true>), grid, block, 0, s, C, 0, 32, img_h, img_w,
                        tiles_x, ntiles, ids, bins, rec, colors, background, out_img, final_Ts, final_idx, 1, seg2);
-}
-
-void gg_launch_blend2_bwd_pair(int C, int img_h, int img_w, int tiles_x, int ntiles, const int32_t *ids,
-                               const int2 *bins, const GRec *rec, const float *colors, const float *background,
-                               const float *final_Ts, const int32_t *final_idx, const float *v_out, float *v_xy,
-                               float *v_conic, float *v_colors, float *v_opacity, int gstride, int cstride,
-                               const float *colors2, int C2, const float *background2, const float *v_out2,
-                               float *v_colors2, int cstride2, hipStream_t s) {
-    dim3 grid(gg_tile_grid(ntiles)), block(256);
-    Seg2B seg2;
-    seg2.colors = colors2;
-    seg2.background = background2;
-    seg2.v_out = v_out2;
-    seg2.C2 = C2;
-    seg2.nch2 = C2;
-    // geometry gradients of both arrays + colour gradients of the first 32 channels
-    gg_prof_begin(GG_K_BLEND_BWD_PAIR, s);
-    hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, 0, 32, true>), grid, block, 0, s, C, 0, 32, img_h, img_w,
-                       tiles_x, ntiles, ids, bins, rec, colors, background, final_Ts, final_idx, v_out, v_xy,
-                       v_conic, v_colors, v_opacity, gstride, cstride, seg2);
-    gg_prof_end(GG_K_BLEND_BWD_PAIR, s);
-    // colour gradients of the second array
-    gg_prof_begin(GG_K_BLEND_BWD_CONLY, s);
-    hipLaunchKernelGGL((blend2_bwd_narrow_kernel<8, 0, true>), grid, block, 0, s, C2, 0, C2, img_h, img_w, tiles_x,
-                       ntiles, ids, bins, rec, colors2, background2, final_Ts, final_idx, v_out2, v_xy, v_conic,
-                       v_colors2, v_opacity, gstride, cstride2);
-    gg_prof_end(GG_K_BLEND_BWD_CONLY, s);
 }
 
 #define B2_BWDN_ARGS C, off, n, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, \

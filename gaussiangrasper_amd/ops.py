@@ -670,33 +670,6 @@ class RasterizeSegments(Function):
         order = ([rider] if rider is not None else []) + [i for i in range(k) if i != rider]
         grads = [None] * k
         first = True
-        zeros = lambda ch: torch.zeros(img_height, img_width, ch, dtype=torch.float32, device=dev)
-        # a >= 32-channel array and the small rider: ONE geometry-gradient computation for both (the wide
-        # walk carries the rider's channels in D and W; the rider's walk reduces colour gradients only)
-        wide = next((i for i in range(k) if cols[i].shape[1] >= 32), None) if rider is not None else None
-        if wide is not None:
-            vo_w = _f32(v_outs[wide]) if v_outs[wide] is not None else zeros(cols[wide].shape[1])
-            vo_r = _f32(v_outs[rider]) if v_outs[rider] is not None else zeros(cols[rider].shape[1])
-            sink = ctx.sinks[wide]
-            flags = 1
-            if sink is not None:
-                v_colors, flags = sink[1], flags | 2
-            else:
-                v_colors = torch.empty(n, cols[wide].shape[1], dtype=torch.float32, device=dev)
-            _lib.check(lib.gg_blend_bwd_pair(
-                cols[wide].shape[1], cols[rider].shape[1], n, img_height, img_width, _ptr(ids_sorted),
-                _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(cols[wide]), _ptr(cols[rider]), _ptr(opacity),
-                _ptr(bgs[wide]), _ptr(bgs[rider]), _ptr(final_Ts), _ptr(final_idx), _ptr(vo_w), _ptr(vo_r),
-                _ptr(v_xy), _ptr(v_conic), _ptr(v_colors), _ptr(rec_g[:, 6:]), _ptr(v_opacity), gstride, gstride,
-                _ptr(ws), ws.numel(), flags, _stream(dev)), "gg_blend_bwd_pair")
-            if flags & 2:
-                if sink[2] is not None:
-                    sink[2](sink[0])
-            else:
-                grads[wide] = v_colors
-            grads[rider] = rec_g[:, 6:]
-            first = False
-            order = [i for i in order if i not in (wide, rider)]
         for i in order:
             ch = cols[i].shape[1]
             v_out = v_outs[i]

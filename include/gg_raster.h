@@ -186,22 +186,6 @@ int gg_blend_bwd(int channels, int num_points, int img_height, int img_width,
 #define GG_BWD_ACCUMULATE_COLORS 2
 #define GG_BWD_ACCUMULATE_GEOM 4
 
-/* gg_blend_bwd_pair: backward of gg_blend_fwd_pair.  The 32-channel walk carries the second array's
- * channels in D = <colour, v_out> and in W, so it yields the geometry gradients of BOTH arrays; the second
- * array's walk only reduces its colour gradients.  v_xy / v_conic / v_opacity: one interleaved record of
- * geom_stride >= 6 floats per Gaussian (v_conic = v_xy + 2, v_opacity = v_xy + 5), cleared by the call;
- * v_colors (N, channels) dense; v_colors2 with color2_stride floats per Gaussian (may live in the record:
- * v_colors2 = v_xy + 6, color2_stride = geom_stride).  flags: GG_BWD_WS_FROM_FORWARD,
- * GG_BWD_ACCUMULATE_COLORS (for v_colors). */
-int gg_blend_bwd_pair(int channels, int channels2, int num_points, int img_height, int img_width,
-                      const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
-                      const float *conics, const float *colors, const float *colors2,
-                      const float *opacity, const float *background, const float *background2,
-                      const float *final_Ts, const int32_t *final_idx, const float *v_out_img,
-                      const float *v_out_img2, float *v_xy, float *v_conic, float *v_colors,
-                      float *v_colors2, float *v_opacity, int geom_stride, int color2_stride, void *ws,
-                      size_t ws_bytes, int flags, gg_stream_t stream);
-
 /* ---- feature up-projection MLP ------------------------------------------------
  * Replaces the forward of the reference's `MLP(32, 512, hidden_list=[128])` module
  * (nerfstudio/models/gaussian_splatting.py:198-213; `self.fea_up`, called on every pixel of the
@@ -323,8 +307,6 @@ int gg_adam_step(int num_groups, const gg_adam_group_t *groups, int zero_grad, g
 #define GG_K_BLEND_FWD 10 /* + width index: template widths {1,3,4,8,16,32} -> 0..5 */
 #define GG_K_BLEND_BWD 20 /* + width index */
 #define GG_K_BLEND_FWD_PAIR 16 /* 32 channels + a second array of <= 8 in one walk */
-#define GG_K_BLEND_BWD_PAIR 17  /* backward, wide walk with both arrays in D and W (all geometry gradients) */
-#define GG_K_BLEND_BWD_CONLY 18 /* backward, second array: colour gradients only */
 #define GG_K_COMPACT 26
 #define GG_K_DENSIFY 27
 #define GG_K_ADAM 28

@@ -92,6 +92,8 @@ def parse(argv=None):
     ap.add_argument("--device", default="cuda", choices=("cuda", "cpu"))
     ap.add_argument("--ops", default=PRODUCT_OPS, help="operator module (tests only)")
     ap.add_argument("--dump-grads", default=None)
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="test hook: every rank uses cuda:0 (a one-GPU box rehearsing N ranks; gloo backend)")
     a = ap.parse_args(argv)
     d4 = dict(points=1_000_000, height=1200, width=1600, feature_dim=32)
     d5 = dict(points=5_000_000, height=1080, width=1920, feature_dim=128)
@@ -244,6 +246,10 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
     if args.device == "cuda":
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+        if args.share_gpu:
+            if args.backend != "gloo":
+                raise SystemExit("--share-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     else:
@@ -253,7 +259,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
         dev = torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        kw = {"device_id": dev} if args.device == "cuda" else {}
+        kw = {"device_id": dev} if (args.device == "cuda" and args.backend == "nccl") else {}
         dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
 
     if selftest:
@@ -508,7 +514,7 @@ def main(argv=None) -> int:
     # the GPU (importing torch and counting devices do not initialise HIP), and the children are
     # fresh interpreters — no process that has initialised HIP is ever re-exec'd.
     from gaussiangrasper_amd.dist import spawn_ranks
-    if args.device == "cuda":
+    if args.device == "cuda" and not args.share_gpu:
         import torch
         n_dev = torch.cuda.device_count()               # does not initialise HIP on this image
         if n_dev < args.gpus:

@@ -857,3 +857,62 @@ def test_fused_activations_match_the_callers_torch_ops():
     assert grads[1][0] is None or not grads[1][0].any()          # means: no gradient (viewdirs detached)
     for name, a, b in zip(("scales", "quats", "opacities"), grads[1][1:], grads[0][1:]):
         assert torch.allclose(a, b, rtol=2e-5, atol=1e-6 * float(b.abs().max())), name
+
+
+def test_two_ranks_of_the_hip_path_reduce_to_the_single_process_gradient(tmp_path):
+    """bench.py --gpus 2 with the PRODUCT operators: two processes (both on this box's one GPU, gloo as the
+    collective backend since RCCL refuses two ranks on one device), views sharded, SH / feature gradients
+    added into the bucket by the kernels, per-parameter overlapped reduction — the reduced gradient equals
+    the single-process sum over the same views up to the order of the float atomics."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+
+    def run(gpus, vps, out, extra=()):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--backend", "gloo", "--share-gpu",
+               "--points", "30000", "--height", "200", "--width", "304", "--views-per-step", str(vps), "--steps", "1",
+               "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--no-prof", "--dump-grads", str(out), *extra]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1 and lines[0]["n_gpus"] == gpus and lines[0]["data"] == "synthetic"
+        return lines[0]
+
+    g2, g1, g2s = tmp_path / "g2.pt", tmp_path / "g1.pt", tmp_path / "g2s.pt"
+    l2 = run(2, 2, g2)
+    l1 = run(1, 4, g1)
+    run(2, 2, g2s, ("--route", "shim", "--no-overlap", "--no-direct"))
+    assert l2["config"]["grad_allreduce_bytes"] == l1["config"]["grad_allreduce_bytes"] == 30000 * 472
+    a, b, c = (torch.load(f, weights_only=True) for f in (g2, g1, g2s))
+    assert float(b.abs().sum()) > 0
+    assert_close(a.numpy(), b.numpy(), "two ranks (plugin route, overlapped, direct) vs one", rtol=1e-4, atol_frac=2e-6)
+    assert_close(c.numpy(), b.numpy(), "two ranks (shim route, one collective, autograd adds) vs one", rtol=1e-4,
+                 atol_frac=2e-6)
+
+
+def test_segments_and_activations_edge_cases():
+    """nothing visible (every Gaussian behind the camera): background images and zero gradients; and an
+    empty scene through the fused activation operator"""
+    n, h, w = 64, 32, 48
+    sc = make_scene(n, feature_dim=32, config_index=13).to(DEV)
+    v = ring_cameras(2, h, w, device=DEV)[0]
+    means = (sc.means - 100.0 * (v.viewmat[2, :3])).requires_grad_(True)       # far behind the camera
+    xys, depths, radii, conics, nth, _ = P.ProjectGaussians.apply(
+        means, sc.scales.exp(), 1, sc.quats, v.viewmat[:3], v.projmat, v.fx, v.fy, v.cx, v.cy, h, w, v.tile_bounds)
+    assert int(nth.sum()) == 0
+    feat = sc.feature.clone().requires_grad_(True)
+    tail = torch.rand(n, 7, device=DEV, requires_grad=True)
+    bg = torch.arange(7, device=DEV, dtype=torch.float32)
+    P.clear_bin_cache()
+    f_im, t_im = P.rasterize_segments(xys, depths, radii, conics, nth, torch.sigmoid(sc.opacities), h, w,
+                                      [(feat, torch.zeros(32, device=DEV)), (tail, bg)])
+    assert f_im.shape == (h, w, 32) and not f_im.any()
+    assert torch.equal(t_im, bg.expand(h, w, 7))
+    (f_im.sum() + t_im.sum()).backward()
+    assert not feat.grad.any() and not tail.grad.any() and not means.grad.any()
+    empty = [torch.zeros(0, k, device=DEV) for k in (3, 3, 4, 1)]
+    outs = P.ActivateGaussians.apply(*empty, torch.zeros(3, device=DEV))
+    assert [tuple(o.shape) for o in outs] == [(0, 3), (0, 4), (0, 1), (0, 3), (0, 3)]

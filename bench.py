@@ -88,6 +88,9 @@ def parse(argv=None):
     ap.add_argument("--no-direct", action="store_true",
                     help="autograd accumulates every parameter gradient (no in-kernel accumulation "
                          "into the gradient bucket for the SH and feature parameters)")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="bit-reproducible blend gradients (ops.set_deterministic_backward): a measurement of "
+                         "that mode's cost, never the headline")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
     ap.add_argument("--device", default="cuda", choices=("cuda", "cpu"))
     ap.add_argument("--ops", default=PRODUCT_OPS, help="operator module (tests only)")
@@ -304,6 +307,8 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
     views = ring_cameras(total_views, args.height, args.width, device=dev)
     my_views = shard_views(total_views, rank, world)
     bucket = GradBucket(scene.params())
+    if args.deterministic:
+        ops.set_deterministic_backward(True)
     direct = not args.no_direct and hasattr(ops, "register_grad_sink")
     if direct:
         bucket.enable_direct(ops, [scene.colors_all, scene.feature])
@@ -382,7 +387,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
                                   "nerfstudio plugin route: one fused rasterize operator per view"
                                   if plugin_first else "shim route: the reference's 4 rasterize calls per view",
                                   args.views_per_step),
-                   "route": args.route,
+                   "route": args.route, "deterministic_backward": bool(args.deterministic),
                    "num_gaussians": args.points, "image": [args.height, args.width],
                    "feature_dim": args.feature_dim, "views_per_step_per_gpu": args.views_per_step,
                    "n_visible": n_vis, "num_intersects": n_isect,

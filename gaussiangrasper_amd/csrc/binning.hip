@@ -528,3 +528,41 @@ extern "C" int gg_bin_sort_dev(int N, int64_t capacity, const int64_t *num_inter
     return bin_sort_impl(N, capacity, num_intersects_dev, xys, depths, radii, num_tiles_hit, tiles_x,
                          tiles_y, gaussian_ids_sorted, tile_bins, isect_tile_sorted, ws, ws_bytes, stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// stable sort of (key, value) u32 pairs by the low `bits` bits of the key — the radix passes above,
+// exported for the deterministic backward (blend.hip: list entries grouped by Gaussian id, in list order)
+// ---------------------------------------------------------------------------------------------
+size_t gg_sort_pairs_workspace(int64_t n) {
+    const size_t i = (size_t)(n > 0 ? n : 1);
+    return gg_align_up(4 * i, 256) * 2 + gg_align_up(4 * 256 * (size_t)(radix_nblocks(n) + 1), 256) +
+           gg_align_up(4 * 256, 256);
+}
+// keys / vals are sorted in place (ping-pong through the workspace); returns 0 on success
+int gg_sort_pairs(int64_t n, uint32_t *keys, uint32_t *vals, int bits, void *ws, size_t ws_bytes, hipStream_t s) {
+    if (n <= 0) return GG_OK;
+    if (ws == nullptr || ws_bytes < gg_sort_pairs_workspace(n)) return GG_ERR_WORKSPACE;
+    char *p = (char *)ws;
+    const size_t i = (size_t)n;
+    uint32_t *kalt = (uint32_t *)p;
+    p += gg_align_up(4 * i, 256);
+    uint32_t *valt = (uint32_t *)p;
+    p += gg_align_up(4 * i, 256);
+    BinWs w;
+    w.G = (uint32_t *)p;
+    p += gg_align_up(4 * 256 * (size_t)(radix_nblocks(n) + 1), 256);
+    w.totals = (uint32_t *)p;
+    uint32_t *kc = keys, *vc = vals, *ka = kalt, *va = valt;
+    const int passes = (bits + 7) / 8;
+    for (int pass = 0; pass < passes; ++pass) {
+        const int b = min(8, bits - 8 * pass);
+        radix_pass(n, nullptr, kc, vc, ka, va, 8 * pass, (1u << b) - 1u, w, s);
+        uint32_t *t = kc; kc = ka; ka = t;
+        t = vc; vc = va; va = t;
+    }
+    if (kc != keys) {   // odd number of passes: bring the result home
+        if (hipMemcpyAsync(keys, kc, 4 * i, hipMemcpyDeviceToDevice, s) != hipSuccess) return GG_ERR_LAUNCH;
+        if (hipMemcpyAsync(vals, vc, 4 * i, hipMemcpyDeviceToDevice, s) != hipSuccess) return GG_ERR_LAUNCH;
+    }
+    return GG_OK;
+}

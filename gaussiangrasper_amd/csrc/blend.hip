@@ -49,7 +49,10 @@ void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w
                           int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
                           const float *colors, const float *background, const float *final_Ts,
                           const int32_t *final_idx, const float *v_out, float *v_xy, float *v_conic,
-                          float *v_colors, float *v_opacity, int gstride, int cstride, hipStream_t s);
+                          float *v_colors, float *v_opacity, int gstride, int cstride, hipStream_t s,
+                          DetSlab det);
+size_t gg_sort_pairs_workspace(int64_t n);   // binning.hip: stable LSD radix sort of (key, value) pairs
+int gg_sort_pairs(int64_t n, uint32_t *keys, uint32_t *vals, int bits, void *ws, size_t ws_bytes, hipStream_t s);
 #ifdef GG_ABLATION
 void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, int tiles_x,
                                  int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
@@ -166,13 +169,106 @@ extern "C" int gg_blend_fwd_pair(int C, int C2, int N, int img_h, int img_w, con
     return GG_OK;
 }
 
-extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *ids,
-                            const int32_t *tile_bins, const float *xys, const float *conics,
-                            const float *colors, const float *opacity, const float *background,
-                            const float *final_Ts, const int32_t *final_idx, const float *v_out,
-                            float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
-                            int geom_stride, int color_stride, void *ws, size_t ws_bytes,
-                            int flags, gg_stream_t stream) {
+// ---------------------------------------------------------------------------------------------
+// deterministic backward: slab of per-(list entry, quadrant) totals + ordered per-Gaussian sums
+// ---------------------------------------------------------------------------------------------
+struct DetWs {
+    float *slab;              // I * 4 * ks
+    uint32_t *keys, *vals;    // I each: Gaussian id / list entry, sorted by id (stable: entries ascend)
+    int32_t *seg;             // 2 N: [first, last) of each Gaussian's run in keys
+    void *sort_ws;
+    size_t sort_bytes, bytes;
+};
+static int det_chunks(int C) {
+    int nc = 0;
+    for (int off = 0; off < C; ++nc) off += min(chunk_width(C - off), C - off);
+    return nc;
+}
+static DetWs det_ws_layout(void *ws, int N, int C, int64_t I) {
+    DetWs w;
+    size_t off = 0;
+    auto take = [&](size_t nbytes) {
+        char *p = ws ? (char *)ws + off : nullptr;
+        off += gg_align_up(nbytes, 256);
+        return (void *)p;
+    };
+    const size_t i = (size_t)(I > 0 ? I : 1), n = (size_t)(N > 0 ? N : 1);
+    const size_t ks = (size_t)C + 6 * (size_t)det_chunks(C);
+    w.slab = (float *)take(sizeof(float) * 4 * ks * i);
+    w.keys = (uint32_t *)take(4 * i);
+    w.vals = (uint32_t *)take(4 * i);
+    w.seg = (int32_t *)take(8 * n);
+    w.sort_bytes = gg_sort_pairs_workspace((int64_t)i);
+    w.sort_ws = take(w.sort_bytes);
+    w.bytes = off;
+    return w;
+}
+extern "C" size_t gg_blend_bwd_deterministic_workspace(int num_points, int channels, int64_t num_intersects) {
+    if (channels < 1) return 0;
+    return det_ws_layout(nullptr, num_points, channels, num_intersects).bytes;
+}
+
+__global__ void det_pairs_kernel(int64_t I, const int32_t *__restrict__ ids, uint32_t *__restrict__ keys,
+                                 uint32_t *__restrict__ vals) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= I) return;
+    keys[e] = (uint32_t)ids[e];
+    vals[e] = (uint32_t)e;
+}
+__global__ void det_edges_kernel(int64_t I, int N, const uint32_t *__restrict__ keys, int32_t *__restrict__ seg) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= I) return;
+    const uint32_t k = keys[e];
+    if (k >= (uint32_t)N) return;
+    if (e == 0 || keys[e - 1] != k) seg[2 * (size_t)k] = (int32_t)e;
+    if (e == I - 1 || keys[e + 1] != k) seg[2 * (size_t)k + 1] = (int32_t)e + 1;
+}
+// One wave per Gaussian; lane l owns output column l (and l + 64, ...): colour channel c < C or geometry
+// component m = column - C.  Every sum runs over the Gaussian's list entries in ascending order, quadrants
+// 0..3 inside an entry and (geometry) channel chunks inside a quadrant: one fixed order, no atomics.
+__global__ __launch_bounds__(256) void det_reduce_kernel(int N, int C, int nchunks, int ks,
+                                                         const float *__restrict__ slab,
+                                                         const uint32_t *__restrict__ vals,
+                                                         const int32_t *__restrict__ seg, float *v_xy, float *v_conic,
+                                                         float *v_colors, float *v_opacity, int gstride, int cstride) {
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (g >= N) return;
+    const int first = seg[2 * (size_t)g], last = seg[2 * (size_t)g + 1];
+    if (last <= first) return;
+    for (int col = lane; col < C + 6; col += 64) {
+        float sum = 0.0f;
+        const bool geom = col >= C;
+        const int c0 = geom ? C + (col - C) : col;
+        for (int r = first; r < last; ++r) {
+            const float *row = slab + (size_t)vals[r] * 4 * ks;
+            for (int w = 0; w < 4; ++w) {
+                if (geom)
+                    for (int c = 0; c < nchunks; ++c) sum += row[(size_t)w * ks + c0 + 6 * c];
+                else
+                    sum += row[(size_t)w * ks + c0];
+            }
+        }
+        float *dst;
+        if (!geom) dst = v_colors + (size_t)g * (cstride ? cstride : C) + col;
+        else {
+            const int m = col - C;
+            if (m < 2) dst = v_xy + (size_t)g * (gstride ? gstride : 2) + m;
+            else if (m < 5) dst = v_conic + (size_t)g * (gstride ? gstride : 3) + (m - 2);
+            else dst = v_opacity + (size_t)g * (gstride ? gstride : 1);
+        }
+        *dst += sum;   // the arrays start at zero (or hold what earlier calls added: the accumulate flags)
+    }
+}
+
+static int blend_bwd_impl(int C, int N, int img_h, int img_w, const int32_t *ids,
+                          const int32_t *tile_bins, const float *xys, const float *conics,
+                          const float *colors, const float *opacity, const float *background,
+                          const float *final_Ts, const int32_t *final_idx, const float *v_out,
+                          float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
+                          int geom_stride, int color_stride, void *ws, size_t ws_bytes,
+                          int flags, gg_stream_t stream, bool deterministic, int64_t I, void *det_ws,
+                          size_t det_ws_bytes) {
     const bool ws_from_forward = (flags & GG_BWD_WS_FROM_FORWARD) != 0;
     const bool acc_colors = (flags & GG_BWD_ACCUMULATE_COLORS) != 0;
     const bool acc_geom = (flags & GG_BWD_ACCUMULATE_GEOM) != 0;
@@ -238,9 +334,26 @@ extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *i
     }
     const int tiles_x = (img_w + GG_BLOCK - 1) / GG_BLOCK, tiles_y = (img_h + GG_BLOCK - 1) / GG_BLOCK;
     const int ntiles = tiles_x * tiles_y;
-    for (int off = 0; off < C;) {
+    DetSlab det = DetSlab();
+    DetWs dw;
+    const int nchunks = det_chunks(C);
+    if (deterministic) {
+        if (I == 0) return GG_OK;   // empty lists: the zeroed (or untouched) arrays are the answer
+        dw = det_ws_layout(det_ws, N, C, I);
+        det.p = dw.slab;
+        det.ks = C + 6 * nchunks;
+        if (hipMemsetAsync(dw.slab, 0, sizeof(float) * 4 * (size_t)det.ks * (size_t)I, s) != hipSuccess ||
+            hipMemsetAsync(dw.seg, 0, 8 * (size_t)N, s) != hipSuccess) {
+            gg_set_error("gg_blend_bwd_deterministic: memset failed");
+            return GG_ERR_LAUNCH;
+        }
+    }
+    int chunk = 0;
+    for (int off = 0; off < C; ++chunk) {
         const int w = chunk_width(C - off);
         const int n = min(w, C - off);
+        det.coff = off;
+        det.goff = C + 6 * chunk;
         gg_prof_begin(GG_K_BLEND_BWD + gg_width_index(w), s);
 #ifdef GG_ABLATION
         if ((w == 3 && g_ablate > 0 && g_ablate < 10) || (w == 32 && n == 32 && g_ablate > 10))
@@ -253,10 +366,56 @@ extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *i
             gg_launch_blend2_bwd(w, C, off, n, img_h, img_w, tiles_x, ntiles, ids,
                                  (const int2 *)tile_bins, rec, colors, background, final_Ts,
                                  final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, geom_stride,
-                                 color_stride, s);
+                                 color_stride, s, det);
         gg_prof_end(GG_K_BLEND_BWD + gg_width_index(w), s);
         off += n;
     }
+    if (deterministic) {
+        const unsigned nb = (unsigned)((I + 255) / 256);
+        hipLaunchKernelGGL(det_pairs_kernel, dim3(nb), dim3(256), 0, s, I, ids, dw.keys, dw.vals);
+        int bits = 1;
+        while (((int64_t)1 << bits) < (int64_t)N) ++bits;
+        const int rc = gg_sort_pairs(I, dw.keys, dw.vals, bits, dw.sort_ws, dw.sort_bytes, s);
+        if (rc != GG_OK) {
+            gg_set_error("gg_blend_bwd_deterministic: sort failed");
+            return rc;
+        }
+        hipLaunchKernelGGL(det_edges_kernel, dim3(nb), dim3(256), 0, s, I, N, dw.keys, dw.seg);
+        hipLaunchKernelGGL(det_reduce_kernel, dim3((N + 3) / 4), dim3(256), 0, s, N, C, nchunks, det.ks, dw.slab,
+                           dw.vals, dw.seg, v_xy, v_conic, v_colors, v_opacity, geom_stride, color_stride);
+    }
     GG_CHECK_LAUNCH();
     return GG_OK;
+}
+
+extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *ids,
+                            const int32_t *tile_bins, const float *xys, const float *conics,
+                            const float *colors, const float *opacity, const float *background,
+                            const float *final_Ts, const int32_t *final_idx, const float *v_out,
+                            float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
+                            int geom_stride, int color_stride, void *ws, size_t ws_bytes,
+                            int flags, gg_stream_t stream) {
+    return blend_bwd_impl(C, N, img_h, img_w, ids, tile_bins, xys, conics, colors, opacity, background, final_Ts,
+                          final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, geom_stride, color_stride, ws,
+                          ws_bytes, flags, stream, false, 0, nullptr, 0);
+}
+
+extern "C" int gg_blend_bwd_deterministic(int C, int N, int img_h, int img_w, const int32_t *ids,
+                                          const int32_t *tile_bins, const float *xys, const float *conics,
+                                          const float *colors, const float *opacity, const float *background,
+                                          const float *final_Ts, const int32_t *final_idx, const float *v_out,
+                                          float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
+                                          int geom_stride, int color_stride, void *ws, size_t ws_bytes,
+                                          int flags, int64_t num_intersects, void *det_ws, size_t det_ws_bytes,
+                                          gg_stream_t stream) {
+    GG_REQUIRE(C >= 1, "channels < 1");
+    GG_REQUIRE(num_intersects >= 0 && num_intersects < ((int64_t)1 << 31), "num_intersects out of range");
+    if (num_intersects > 0 &&
+        (det_ws == nullptr || det_ws_bytes < gg_blend_bwd_deterministic_workspace(N, C, num_intersects))) {
+        gg_set_error("gg_blend_bwd_deterministic: deterministic workspace too small");
+        return GG_ERR_WORKSPACE;
+    }
+    return blend_bwd_impl(C, N, img_h, img_w, ids, tile_bins, xys, conics, colors, opacity, background, final_Ts,
+                          final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, geom_stride, color_stride, ws,
+                          ws_bytes, flags, stream, true, num_intersects, det_ws, det_ws_bytes);
 }

@@ -327,14 +327,15 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
 //   1 = no global atomics, 2 = also no butterfly, 3 = also no recurrence/partials (geometry only),
 //   4 = staging + cull only (no group loop)
 #define KEEP(x) asm volatile("" ::"v"(x))
-template <int CH, int ABL = 0>
+template <int CH, int ABL = 0, bool DET = false>
 __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
     const float *__restrict__ colors, const float *__restrict__ background,
     const float *__restrict__ final_T, const int32_t *__restrict__ final_idx,
     const float *__restrict__ v_out, float *__restrict__ v_xy, float *__restrict__ v_conic,
-    float *__restrict__ v_colors, float *__restrict__ v_opacity, int gstride, int cstride) {
+    float *__restrict__ v_colors, float *__restrict__ v_opacity, int gstride, int cstride,
+    DetSlab det = DetSlab()) {
     constexpr int K = CH + 6;       // per-Gaussian values: CH colours, xy(2), conic(3), opacity(1)
     constexpr int KB = GRP * K;     // butterfly width
     using R = Red6<KB>;
@@ -472,6 +473,13 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
             // id bits live in b.w of the record
             const int my_gid = __builtin_bit_cast(int, L.b[kk - my_q].w);
             if (ABL >= 1) { KEEP(mine); KEEP(my_gid); continue; }
+            if (DET) {   // deterministic mode: the total of (list entry, quadrant) goes to the slab
+                const int pos = __builtin_bit_cast(int, N8 ? L.a[kk - my_q].w : L.c[kk - my_q].w);
+                const size_t e = (size_t)(top - 64 + pos);
+                if (owner && my_gid >= 0)
+                    det.p[(e * 4 + wave) * det.ks + (my_k < CH ? det.coff + my_k : det.goff + (my_k - CH))] = mine;
+                continue;
+            }
             if (owner && my_gid >= 0 && mine != 0.0f) atomicAdd(my_base + (size_t)my_gid * my_stride, mine);
         }
         __builtin_amdgcn_wave_barrier();  // the list is rewritten by the next chunk
@@ -495,14 +503,15 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
 // 3 also no butterfly / geometry atomics, 4 also no D (colour loads + 32 fma), 5 geometry only
 // CHD: channels of this chunk rounded up to 8, 16 or 32 — registers for v_out and the length of the
 // D loop (a 7-channel tail chunk, e.g. rgb+depth+normal of the fused call, does not pay for 32).
-template <bool FULL, int ABL = 0, int CHD = 32>
+template <bool FULL, int ABL = 0, int CHD = 32, bool DET = false>
 __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
     const float *__restrict__ colors, const float *__restrict__ background,
     const float *__restrict__ final_T, const int32_t *__restrict__ final_idx,
     const float *__restrict__ v_out, float *__restrict__ v_xy, float *__restrict__ v_conic,
-    float *__restrict__ v_colors, float *__restrict__ v_opacity, int gstride, int cstride) {
+    float *__restrict__ v_colors, float *__restrict__ v_opacity, int gstride, int cstride,
+    DetSlab det = DetSlab()) {
     constexpr int CH = CHD;
     constexpr int KG = 6;
     constexpr int KB = GRP * KG;
@@ -510,6 +519,7 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
     __shared__ WaveList lists[4];
     __shared__ float s_fac[4][B2_SLOTS * B2_FSTRIDE];
     __shared__ int s_slotgid[4][B2_SLOTS];
+    __shared__ int s_slote[4][DET ? B2_SLOTS : 1];     // list entry of each slot (deterministic mode)
 
     const int tile = xcd_tile(blockIdx.x, ntiles);
     if (tile < 0) return;
@@ -518,6 +528,7 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
     WaveList &L = lists[wave];
     float *fac_w = s_fac[wave];
     int *slotgid = s_slotgid[wave];
+    int *slote = s_slote[wave];
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int qx0 = tx * GG_BLOCK + (wave & 1) * 8, qy0 = ty * GG_BLOCK + (wave >> 1) * 8;
     const int j = qx0 + (lane & 7), i = qy0 + (lane >> 3);
@@ -581,6 +592,11 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
         for (int r = 0; r < 16; ++r) {
             const int slot = (r & 3) + 8 * (r >> 2) + 4 * half;
             if (ABL >= 1) { KEEP(acc[r]); continue; }
+            if (DET) {
+                if (slot < nslots && wch_ok)
+                    det.p[((size_t)slote[slot] * 4 + wave) * det.ks + det.coff + wch] = acc[r];
+                continue;
+            }
             if (slot < nslots && wch_ok && acc[r] != 0.0f)
                 atomicAdd(v_colors + (size_t)slotgid[slot] * cs + ch_off + wch, acc[r]);
         }
@@ -659,7 +675,11 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
                 pg[5] = pass[q] ? vis[q] * v_alpha : 0.0f;
                 // park fac for the matrix pipe
                 fac_w[nslots * B2_FSTRIDE + lane] = fac;
-                if (lane == 0) slotgid[nslots] = gid;
+                if (lane == 0) {
+                    slotgid[nslots] = gid;
+                    if (DET)
+                        slote[nslots] = top - 64 + __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, L.c[kk - q].w));
+                }
                 ++nslots;
                 if (nslots == B2_SLOTS) flush_slots();
             }
@@ -670,6 +690,11 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
             }
             const float mine = R::run(part, lane);
             const int my_gid = __builtin_bit_cast(int, L.b[kk - my_q].w);
+            if (DET) {
+                const size_t e = (size_t)(top - 64 + __builtin_bit_cast(int, L.c[kk - my_q].w));
+                if (owner && my_gid >= 0) det.p[(e * 4 + wave) * det.ks + det.goff + my_k] = mine;
+                continue;
+            }
             if (owner && my_gid >= 0 && mine != 0.0f) atomicAdd(my_base + (size_t)my_gid * my_stride, mine);
         }
         __builtin_amdgcn_wave_barrier();
@@ -716,14 +741,32 @@ void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
                        tiles_x, ntiles, ids, bins, rec, colors, background, out_img, final_Ts, final_idx, 1, seg2);
 }
 
+#define B2_BWDW_ARGS C, off, n, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, \
+                     final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, gstride, cstride, det
 #define B2_BWDN_ARGS C, off, n, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, \
-                     final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, gstride, cstride
+                     final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, gstride, cstride, det
 void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w, int tiles_x,
                           int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
                           const float *colors, const float *background, const float *final_Ts,
                           const int32_t *final_idx, const float *v_out, float *v_xy, float *v_conic,
-                          float *v_colors, float *v_opacity, int gstride, int cstride, hipStream_t s) {
+                          float *v_colors, float *v_opacity, int gstride, int cstride, hipStream_t s,
+                          DetSlab det) {
     dim3 grid(gg_tile_grid(ntiles)), block(256);
+    if (det.p) {   // deterministic mode: same kernels with the atomics replaced by slab stores
+        if (width == 1)
+            hipLaunchKernelGGL((blend2_bwd_narrow_kernel<1, 0, true>), grid, block, 0, s, B2_BWDN_ARGS);
+        else if (width == 2)
+            hipLaunchKernelGGL((blend2_bwd_narrow_kernel<2, 0, true>), grid, block, 0, s, B2_BWDN_ARGS);
+        else if (width == 3)
+            hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3, 0, true>), grid, block, 0, s, B2_BWDN_ARGS);
+        else if (width == 8)
+            hipLaunchKernelGGL((blend2_bwd_narrow_kernel<8, 0, true>), grid, block, 0, s, B2_BWDN_ARGS);
+        else if (n == 32)
+            hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, 0, 32, true>), grid, block, 0, s, B2_BWDW_ARGS);
+        else   // partial 32-channel chunk: one masked variant is enough for this mode
+            hipLaunchKernelGGL((blend2_bwd_wide_kernel<false, 0, 32, true>), grid, block, 0, s, B2_BWDW_ARGS);
+        return;
+    }
     if (width == 1)
         hipLaunchKernelGGL((blend2_bwd_narrow_kernel<1>), grid, block, 0, s, B2_BWDN_ARGS);
     else if (width == 2)
@@ -732,8 +775,6 @@ void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w
         hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3>), grid, block, 0, s, B2_BWDN_ARGS);
     else if (width == 8)
         hipLaunchKernelGGL((blend2_bwd_narrow_kernel<8>), grid, block, 0, s, B2_BWDN_ARGS);
-#define B2_BWDW_ARGS C, off, n, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, \
-                     final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, gstride, cstride
     else if (n == 32)
         hipLaunchKernelGGL((blend2_bwd_wide_kernel<true>), grid, block, 0, s, B2_BWDW_ARGS);
     else if (n <= 8)
@@ -753,10 +794,11 @@ void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, 
                                  float *v_conic, float *v_colors, float *v_opacity, int gstride, int cstride, hipStream_t s) {
     dim3 grid(gg_tile_grid(ntiles)), block(256);
     const int n = 3;   // B2_BWDN_ARGS: the ablated narrow builds are the 3-channel ones
+    const DetSlab det = DetSlab();
     switch (abl) {
 #define B2_WABL(L) hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, L>), grid, block, 0, s, C, off, 32, \
         img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, final_Ts, final_idx, v_out, \
-        v_xy, v_conic, v_colors, v_opacity, gstride, cstride)
+        v_xy, v_conic, v_colors, v_opacity, gstride, cstride, det)
         case 11: B2_WABL(1); break;
         case 12: B2_WABL(2); break;
         case 13: B2_WABL(3); break;

@@ -6,6 +6,15 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define BW_BATCH 64
 
+// Deterministic backward (gg_blend_bwd_deterministic): instead of float atomics the kernels store the total
+// of every (list entry, quadrant) into a slab, slab[(entry * 4 + quadrant) * ks + column]; a second pass
+// sums each Gaussian's entries in list order.  Columns: [0, C) colours, [C + 6 c, C + 6 c + 6) the geometry
+// partials of channel chunk c.  p == nullptr: atomics.
+struct DetSlab {
+    float *p;
+    int ks, goff, coff;
+};
+
 struct __attribute__((aligned(16))) GRec {
     float x, y, opac, thr;  // thr: sigma above which alpha < 1/255 for certain (conservative)
     float ca, cb, cc, pad;

@@ -447,6 +447,41 @@ def _rasterize_forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, o
     return out_img
 
 
+_DETERMINISTIC = False
+
+
+def set_deterministic_backward(on: bool = True) -> bool:
+    """Bit-reproducible blend gradients.  The default backward adds pixel contributions with float atomics,
+    whose order changes from run to run (as in gsplat 0.1.0: csrc/backward.cu atomicAdd).  With this switch the
+    kernels store the total of every (tile-list entry, quadrant) instead and a second pass sums each
+    Gaussian's entries in list order (`gg_blend_bwd_deterministic`): same values to ~1 ulp of the largest term,
+    identical bits on every run, at the price of 16 (C + 6) bytes of scratch per list entry and roughly twice
+    the time.  Returns the previous setting."""
+    global _DETERMINISTIC
+    prev, _DETERMINISTIC = _DETERMINISTIC, bool(on)
+    return prev
+
+
+def _blend_bwd(lib, ch, n, img_height, img_width, ids_sorted, tile_bins, xys, conics, colors, opacity, background,
+               final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, gstride, cstride, ws, flags,
+               num_intersects):
+    dev = xys.device
+    if not _DETERMINISTIC:
+        _lib.check(lib.gg_blend_bwd(ch, n, img_height, img_width, _ptr(ids_sorted), _ptr(tile_bins), _ptr(xys),
+                                    _ptr(conics), _ptr(colors), _ptr(opacity), _ptr(background), _ptr(final_Ts),
+                                    _ptr(final_idx), _ptr(v_out), _ptr(v_xy), _ptr(v_conic), _ptr(v_colors),
+                                    _ptr(v_opacity), gstride, cstride, _ptr(ws), ws.numel(), flags,
+                                    _stream(dev)), "gg_blend_bwd")
+        return
+    det_ws = _workspace(lib.gg_blend_bwd_deterministic_workspace(n, ch, num_intersects), dev)
+    _lib.check(lib.gg_blend_bwd_deterministic(ch, n, img_height, img_width, _ptr(ids_sorted), _ptr(tile_bins),
+                                              _ptr(xys), _ptr(conics), _ptr(colors), _ptr(opacity),
+                                              _ptr(background), _ptr(final_Ts), _ptr(final_idx), _ptr(v_out),
+                                              _ptr(v_xy), _ptr(v_conic), _ptr(v_colors), _ptr(v_opacity), gstride,
+                                              cstride, _ptr(ws), ws.numel(), flags, num_intersects, _ptr(det_ws),
+                                              det_ws.numel(), _stream(dev)), "gg_blend_bwd_deterministic")
+
+
 def _rasterize_backward(ctx, v_out_img):
     img_height, img_width = ctx.img
     if ctx.num_intersects < 1:
@@ -479,12 +514,9 @@ def _rasterize_backward(ctx, v_out_img):
             gstride, cstride = 6, 0
         v_xy, v_conic, v_opacity = rec_g[:, 0:2], rec_g[:, 2:5], rec_g[:, 5:6]
         lib = _lib.load()
-        _lib.check(lib.gg_blend_bwd(ch, n, img_height, img_width, _ptr(ids_sorted),
-                                    _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(colors),
-                                    _ptr(opacity), _ptr(background), _ptr(final_Ts),
-                                    _ptr(final_idx), _ptr(v_out_img), _ptr(v_xy), _ptr(v_conic),
-                                    _ptr(v_colors), _ptr(v_opacity), gstride, cstride, _ptr(ws),
-                                    ws.numel(), flags, _stream(dev)), "gg_blend_bwd")
+        _blend_bwd(lib, ch, n, img_height, img_width, ids_sorted, tile_bins, xys, conics, colors, opacity,
+                   background, final_Ts, final_idx, v_out_img, v_xy, v_conic, v_colors, v_opacity, gstride,
+                   cstride, ws, flags, ctx.num_intersects)
         if flags & 2:
             v_colors = None
             if sink[2] is not None:
@@ -685,11 +717,9 @@ class RasterizeSegments(Function):
                 flags |= 2
             else:
                 v_colors, cstride = torch.empty(n, ch, dtype=torch.float32, device=dev), 0
-            _lib.check(lib.gg_blend_bwd(ch, n, img_height, img_width, _ptr(ids_sorted), _ptr(tile_bins), _ptr(xys),
-                                        _ptr(conics), _ptr(cols[i]), _ptr(opacity), _ptr(bgs[i]), _ptr(final_Ts),
-                                        _ptr(final_idx), _ptr(v_out), _ptr(v_xy), _ptr(v_conic), _ptr(v_colors),
-                                        _ptr(v_opacity), gstride, cstride, _ptr(ws), ws.numel(), flags,
-                                        _stream(dev)), "gg_blend_bwd")
+            _blend_bwd(lib, ch, n, img_height, img_width, ids_sorted, tile_bins, xys, conics, cols[i], opacity,
+                       bgs[i], final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, gstride, cstride,
+                       ws, flags, ctx.num_intersects)
             first = False
             if flags & 2:
                 if sink[2] is not None:

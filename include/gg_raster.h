@@ -186,6 +186,24 @@ int gg_blend_bwd(int channels, int num_points, int img_height, int img_width,
 #define GG_BWD_ACCUMULATE_COLORS 2
 #define GG_BWD_ACCUMULATE_GEOM 4
 
+/* gg_blend_bwd_deterministic: gg_blend_bwd with bit-reproducible results.  gsplat's backward
+ * (csrc/backward.cu: one atomicAdd per warp per Gaussian) and gg_blend_bwd add in whatever order the
+ * hardware schedules; here the kernels store the total of every (tile-list entry, 8x8 quadrant) into a slab
+ * and a second pass (stable sort of the list by Gaussian id, one wave per Gaussian) sums each Gaussian's
+ * entries in list order, quadrants 0..3 inside an entry.  Same arguments and flags as gg_blend_bwd plus
+ * num_intersects (length of gaussian_ids_sorted) and a second workspace of
+ * gg_blend_bwd_deterministic_workspace(num_points, channels, num_intersects) bytes
+ * (16 (channels + 6 ceil(channels / 32)) bytes per list entry dominate). */
+size_t gg_blend_bwd_deterministic_workspace(int num_points, int channels, int64_t num_intersects);
+int gg_blend_bwd_deterministic(int channels, int num_points, int img_height, int img_width,
+                               const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+                               const float *conics, const float *colors, const float *opacity,
+                               const float *background, const float *final_Ts, const int32_t *final_idx,
+                               const float *v_out_img, float *v_xy, float *v_conic, float *v_colors,
+                               float *v_opacity, int geom_stride, int color_stride, void *ws, size_t ws_bytes,
+                               int flags, int64_t num_intersects, void *det_ws, size_t det_ws_bytes,
+                               gg_stream_t stream);
+
 /* ---- feature up-projection MLP ------------------------------------------------
  * Replaces the forward of the reference's `MLP(32, 512, hidden_list=[128])` module
  * (nerfstudio/models/gaussian_splatting.py:198-213; `self.fea_up`, called on every pixel of the

@@ -916,3 +916,82 @@ def test_segments_and_activations_edge_cases():
     empty = [torch.zeros(0, k, device=DEV) for k in (3, 3, 4, 1)]
     outs = P.ActivateGaussians.apply(*empty, torch.zeros(3, device=DEV))
     assert [tuple(o.shape) for o in outs] == [(0, 3), (0, 4), (0, 1), (0, 3), (0, 3)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,h,w,ch", [(7, 45, 70, 3), (2000, 48, 64, 1), (2000, 48, 64, 5), (50000, 300, 400, 3),
+                                      (50000, 300, 400, 32), (20000, 150, 200, 39), (3000, 64, 80, 70),
+                                      (3000, 64, 80, 17)])
+def test_deterministic_backward_is_bit_reproducible_and_matches_the_oracle(oracle, n, h, w, ch):
+    """ops.set_deterministic_backward: gg_blend_bwd_deterministic (slab of per-(entry, quadrant) totals + ordered
+    per-Gaussian sums) gives the same bits on every run and the oracle's gradients within test_blend_bwd's
+    tolerance; the default atomic path agrees with it to the same tolerance."""
+    xys, depths, radii, conics, nth, colors, opac, bg = _blend_inputs(oracle, n, h, w, ch, seed=3)
+    ref_out, saved = oracle.rasterize_fwd(xys, depths, radii, conics, nth, colors, opac, h, w, bg)
+    v_out = np.random.default_rng(11).standard_normal(ref_out.shape).astype(np.float32)
+    b = saved["bins"]
+    assert b["num_intersects"] > 0
+    ref = oracle.blend_bwd(b["gaussian_ids_sorted"], b["tile_bins"], xys, conics, colors, opac, h, w,
+                           bg, saved["final_Ts"], saved["final_idx"], v_out)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    op = P.RasterizeGaussians if ch == 3 else P.NDRasterizeGaussians
+
+    def run():
+        xt, ct, colt, ot = (t(xys).requires_grad_(True), t(conics).requires_grad_(True),
+                            t(colors).requires_grad_(True), t(opac).requires_grad_(True))
+        P.clear_bin_cache()
+        out = op.apply(xt, t(depths), t(radii), ct, t(nth), colt, ot, h, w, t(bg))
+        out.backward(t(v_out))
+        return [_np(g) for g in (xt.grad, ct.grad, colt.grad, ot.grad)]
+
+    prev = P.set_deterministic_backward(True)
+    try:
+        first, second = run(), run()
+    finally:
+        P.set_deterministic_backward(prev)
+    names = ("v_xy", "v_conic", "v_colors", "v_opacity")
+    for name, a, c, r in zip(names, first, second, ref):
+        assert_bitexact(a, c, f"deterministic {name}: run 1 vs run 2")
+        assert_close(a, r.reshape(a.shape), f"deterministic.{name}", rtol=5e-5, atol_frac=1e-6)
+    for name, a, c in zip(names, first, run()):
+        assert_close(c, a, f"atomics vs deterministic {name}", rtol=5e-5, atol_frac=1e-6)
+
+
+@pytest.mark.gpu
+def test_deterministic_backward_through_segments_and_gradient_sinks(oracle):
+    """the multi-segment operator (rider record, GG_BWD_ACCUMULATE_GEOM on later segments) and the direct
+    colour-gradient sinks (GG_BWD_ACCUMULATE_COLORS) in deterministic mode: two runs bit-identical, values
+    equal to the atomic path within the blend tolerance"""
+    n, h, w = 20000, 150, 200
+    xys, depths, radii, conics, nth, colors, opac, bg = _blend_inputs(oracle, n, h, w, 42, seed=8)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    cuts = [(0, 32), (32, 39), (39, 42)]
+    v_outs = [t(np.random.default_rng(5 + i).standard_normal((h, w, hi - lo)).astype(np.float32))
+              for i, (lo, hi) in enumerate(cuts)]
+
+    def run(use_sink):
+        xt, ct, ot = t(xys).requires_grad_(True), t(conics).requires_grad_(True), t(opac).requires_grad_(True)
+        cts = [t(colors[:, lo:hi]).requires_grad_(True) for lo, hi in cuts]
+        sink_buf = torch.zeros(n, 32, device=DEV)
+        P.clear_grad_sinks()
+        if use_sink:
+            P.register_grad_sink(cts[0], sink_buf)
+        P.clear_bin_cache()
+        imgs = P.rasterize_segments(xt, t(depths), t(radii), ct, t(nth), ot, h, w,
+                                    [(cts[i], t(bg[lo:hi])) for i, (lo, hi) in enumerate(cuts)])
+        torch.autograd.backward(imgs, v_outs)
+        P.clear_grad_sinks()
+        g0 = sink_buf if use_sink else cts[0].grad
+        return [_np(g) for g in (xt.grad, ct.grad, ot.grad, g0, cts[1].grad, cts[2].grad)]
+
+    names = ("v_xy", "v_conic", "v_opacity", "v_colors[0]", "v_colors[1]", "v_colors[2]")
+    atomic = run(False)
+    prev = P.set_deterministic_backward(True)
+    try:
+        a, b, c = run(False), run(False), run(True)
+    finally:
+        P.set_deterministic_backward(prev)
+    for name, x, y, z, r in zip(names, a, b, c, atomic):
+        assert_bitexact(x, y, f"deterministic segments {name}: run 1 vs run 2")
+        assert_bitexact(x, z, f"deterministic segments {name}: autograd buffer vs gradient sink")
+        assert_close(x, r, f"deterministic segments vs atomics {name}", rtol=5e-5, atol_frac=1e-6)

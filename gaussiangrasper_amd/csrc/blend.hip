@@ -61,6 +61,12 @@ void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, 
                                  float *v_conic, float *v_colors, float *v_opacity, int gstride, int cstride, hipStream_t s);
 #endif
 
+void gg_launch_blend2_bwd_pair(int C, int img_h, int img_w, int tiles_x, int ntiles, const int32_t *ids,
+                               const int2 *bins, const GRec *rec, const float *colors, const float *background,
+                               const float *final_Ts, const int32_t *final_idx, const float *v_out, float *v_xy,
+                               float *v_conic, float *v_colors, float *v_opacity, int gstride, int cstride,
+                               const float *colors2, int C2, const float *background2, const float *v_out2,
+                               float *v_colors2, int cstride2, hipStream_t s);
 void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int ntiles, const int32_t *ids,
                                const int2 *bins, const GRec *rec, const float *colors, const float *background,
                                float *out_img, float *final_Ts, int32_t *final_idx, const float *colors2, int C2,
@@ -398,6 +404,81 @@ extern "C" int gg_blend_bwd(int C, int N, int img_h, int img_w, const int32_t *i
     return blend_bwd_impl(C, N, img_h, img_w, ids, tile_bins, xys, conics, colors, opacity, background, final_Ts,
                           final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, geom_stride, color_stride, ws,
                           ws_bytes, flags, stream, false, 0, nullptr, 0);
+}
+
+extern "C" int gg_blend_bwd_pair(int C, int C2, int N, int img_h, int img_w, const int32_t *ids,
+                                 const int32_t *tile_bins, const float *xys, const float *conics,
+                                 const float *colors, const float *colors2, const float *opacity,
+                                 const float *background, const float *background2, const float *final_Ts,
+                                 const int32_t *final_idx, const float *v_out, const float *v_out2, float *v_xy,
+                                 float *v_conic, float *v_colors, float *v_colors2, float *v_opacity,
+                                 int geom_stride, int color_stride, int color_stride2, void *ws, size_t ws_bytes,
+                                 int flags, gg_stream_t stream) {
+    const bool ws_from_forward = (flags & GG_BWD_WS_FROM_FORWARD) != 0;
+    const bool acc_colors = (flags & GG_BWD_ACCUMULATE_COLORS) != 0;
+    GG_REQUIRE((flags & GG_BWD_ACCUMULATE_GEOM) == 0, "gg_blend_bwd_pair writes the geometry gradients itself");
+    GG_REQUIRE(C >= 32, "the first colour array needs >= 32 channels (its first chunk carries the second array)");
+    GG_REQUIRE(C2 >= 1 && C2 <= 8, "the second colour array has 1..8 channels");
+    GG_REQUIRE(N >= 0, "num_points < 0");
+    GG_REQUIRE(img_h > 0 && img_w > 0, "empty image");
+    if (N == 0) return GG_OK;
+    GG_REQUIRE(ids && tile_bins && xys && conics && colors && colors2 && opacity && background && background2 &&
+                   final_Ts && final_idx && v_out && v_out2 && v_xy && v_conic && v_colors && v_colors2 && v_opacity,
+               "null pointer");
+    GG_REQUIRE(geom_stride == 0 || geom_stride >= 6, "geom_stride must be 0 (dense) or >= 6");
+    GG_REQUIRE(color_stride == 0 || color_stride >= C, "color_stride must be 0 (dense) or >= channels");
+    GG_REQUIRE(color_stride2 == 0 || color_stride2 >= C2, "color_stride2 must be 0 (dense) or >= channels2");
+    GG_REQUIRE(geom_stride == 0 || (v_conic == v_xy + 2 && v_opacity == v_xy + 5),
+               "interleaved geometry gradients: v_conic = v_xy + 2 and v_opacity = v_xy + 5 expected");
+    if (ws == nullptr || ws_bytes < gg_blend_workspace(N)) {
+        gg_set_error("gg_blend_bwd_pair: workspace too small");
+        return GG_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    GRec *rec = (GRec *)ws;
+    if (!ws_from_forward) {
+        gg_prof_begin(GG_K_BLEND_PREP, s);
+        hipLaunchKernelGGL(blend_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, xys, conics, opacity, rec);
+        gg_prof_end(GG_K_BLEND_PREP, s);
+    }
+    const size_t n = (size_t)N;
+    const bool in_record = geom_stride > 0 && color_stride2 == geom_stride && v_colors2 == v_xy + 6;
+    GG_REQUIRE(!in_record || geom_stride >= 6 + C2, "the record is too short for the second array's gradients");
+    bool fail = false;
+    if (geom_stride > 0) {
+        fail |= hipMemsetAsync(v_xy, 0, sizeof(float) * geom_stride * n, s) != hipSuccess;
+    } else {
+        fail |= hipMemsetAsync(v_xy, 0, sizeof(float) * 2 * n, s) != hipSuccess;
+        fail |= hipMemsetAsync(v_conic, 0, sizeof(float) * 3 * n, s) != hipSuccess;
+        fail |= hipMemsetAsync(v_opacity, 0, sizeof(float) * n, s) != hipSuccess;
+    }
+    if (!in_record)
+        fail |= hipMemsetAsync(v_colors2, 0, sizeof(float) * (color_stride2 ? color_stride2 : C2) * n, s) != hipSuccess;
+    if (!acc_colors)
+        fail |= hipMemsetAsync(v_colors, 0, sizeof(float) * (color_stride ? color_stride : C) * n, s) != hipSuccess;
+    if (fail) {
+        gg_set_error("gg_blend_bwd_pair: memset failed");
+        return GG_ERR_LAUNCH;
+    }
+    const int tiles_x = (img_w + GG_BLOCK - 1) / GG_BLOCK, tiles_y = (img_h + GG_BLOCK - 1) / GG_BLOCK;
+    const int ntiles = tiles_x * tiles_y;
+    gg_prof_begin(GG_K_BLEND_BWD_PAIR, s);
+    gg_launch_blend2_bwd_pair(C, img_h, img_w, tiles_x, ntiles, ids, (const int2 *)tile_bins, rec, colors, background,
+                              final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, geom_stride,
+                              color_stride, colors2, C2, background2, v_out2, v_colors2, color_stride2, s);
+    gg_prof_end(GG_K_BLEND_BWD_PAIR, s);
+    for (int off = 32; off < C;) {   // further chunks of the first array: their own walks, adding to the same arrays
+        const int w = chunk_width(C - off);
+        const int nn = min(w, C - off);
+        gg_prof_begin(GG_K_BLEND_BWD + gg_width_index(w), s);
+        gg_launch_blend2_bwd(w, C, off, nn, img_h, img_w, tiles_x, ntiles, ids, (const int2 *)tile_bins, rec, colors,
+                             background, final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, geom_stride,
+                             color_stride, s, DetSlab());
+        gg_prof_end(GG_K_BLEND_BWD + gg_width_index(w), s);
+        off += nn;
+    }
+    GG_CHECK_LAUNCH();
+    return GG_OK;
 }
 
 extern "C" int gg_blend_bwd_deterministic(int C, int N, int img_h, int img_w, const int32_t *ids,

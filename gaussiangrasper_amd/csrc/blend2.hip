@@ -76,12 +76,11 @@ __device__ __forceinline__ int lane_prefix(uint64_t m) {
 // GRP null records (opacity 0 -> never pass) on both sides.
 template <int CH, bool WIDE, bool REL = false, typename LIST = WaveList>
 __device__ __forceinline__ int stage_chunk(LIST &L, int lane, int e, bool valid,
-                                           const int32_t *__restrict__ ids,
+                                           const int g /* ids[e], loaded by the caller one chunk ahead */,
                                            const GRec *__restrict__ rec,
                                            const float *__restrict__ colors, int C, int ch_off, int nch,
                                            float xlo, float xhi, float ylo, float yhi,
                                            const Seg2 *seg2 = nullptr) {
-    const int g = valid ? ids[e] : 0;
     const float4 ra = reinterpret_cast<const float4 *>(rec + g)[0];
     const float4 rb = reinterpret_cast<const float4 *>(rec + g)[1];
     const bool hit = valid && rec_hits_rect(ra, rb, xlo, xhi, ylo, yhi);
@@ -184,7 +183,8 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
     for (int base = range.x; base < range.y; base += 64) {
         if (__ballot(!done) == 0ull) break;
         const int e = base + lane;
-        const int cnt = stage_chunk<CH, WIDE, false, LIST>(L, lane, e, e < range.y, ids, rec, colors, C,
+        const int g_cur = e < range.y ? ids[e] : 0;   // (loading it a chunk ahead measures the same here)
+        const int cnt = stage_chunk<CH, WIDE, false, LIST>(L, lane, e, e < range.y, g_cur, rec, colors, C,
                                                            ch_off, nch, xlo, xhi, ylo, yhi, EX ? &seg2 : nullptr);
         WALK_STAT(0, min(64, range.y - base));
         for (int k = 0; k < cnt; k += GRP) {
@@ -393,10 +393,20 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
     else if (my_k < CH + 5) { my_base = v_conic + (my_k - CH - 2); my_stride = gstride ? gstride : 3; }
     else { my_base = v_opacity; my_stride = gstride ? gstride : 1; }
 
+    // 8-channel build: the first of the two dependent staging loads (id, then record) runs one chunk ahead
+    // (-2.5 %; on the <= 3-channel builds the extra register costs a wave of occupancy and it measures +1 %)
+    int g_nxt = (N8 && hi > range.x && hi - 64 + lane >= range.x) ? ids[hi - 64 + lane] : 0;
     for (int top = hi; top > range.x; top -= 64) {
         const int e = top - 64 + lane;
         const bool valid = e >= range.x;
-        const int cnt = stage_chunk<CH, false, true, LIST>(L, lane, e, valid, ids, rec, colors, C, ch_off,
+        int g_cur;
+        if (N8) {
+            g_cur = g_nxt;
+            g_nxt = (top - 64 > range.x && e - 64 >= range.x) ? ids[e - 64] : 0;
+        } else {
+            g_cur = valid ? ids[e] : 0;
+        }
+        const int cnt = stage_chunk<CH, false, true, LIST>(L, lane, e, valid, g_cur, rec, colors, C, ch_off,
                                                            N8 ? nch : CH, xlo, xhi, ylo, yhi);
         const int fin_rel = fin - (top - 64);  // entries at chunk position >= fin_rel are not mine
         if (ABL >= 4) { KEEP(cnt); continue; }
@@ -486,24 +496,52 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
     }
 }
 
-// =============================================================================================
-// backward, wide (32-channel chunk): wave-autonomous, matrix pipe for the colour gradients
-// =============================================================================================
-// Same walk as the narrow kernel.  Per Gaussian with at least one contributing pixel:
-//   D = <colour, v_out> with the colour row in SGPRs (wave-uniform scalar loads, 4 fma chains);
-//   fac is parked in LDS ([slot][pixel]); after 32 slots FAC[32 x 64] * V_OUT[64 x 32] runs as 32
-//   v_mfma_f32_32x32x2_f32 (exact fp32 fma chains) and the 32x32 result goes to v_colors with 16
-//   global-atomic wave-instructions of two full 128-byte rows each.
-// The 6 geometry partials of the four Gaussians of a group share one butterfly (Red6<24>) and one
-// atomic wave-instruction.  No LDS slab, no workgroup barrier.
 #define B2_SLOTS 32
-#define B2_FSTRIDE 65
+// fac / D slab [slot][pixel]: 65 floats per slot — a column access (32 slots, one pixel: the MFMA operand
+// layouts) and a row access both spread over the banks, and every address stays base + immediate (an XOR
+// swizzle at stride 64 costs one live address register per access: 134 spilled VGPRs)
+#define FIDX(slot, pix) ((slot) * 65 + (pix))
 
-// ABL > 0 (measurement builds only): 1 no colour-gradient atomics, 2 also no MFMA flush,
-// 3 also no butterfly / geometry atomics, 4 also no D (colour loads + 32 fma), 5 geometry only
-// CHD: channels of this chunk rounded up to 8, 16 or 32 — registers for v_out and the length of the
-// D loop (a 7-channel tail chunk, e.g. rgb+depth+normal of the fused call, does not pay for 32).
-template <bool FULL, int ABL = 0, int CHD = 32, bool DET = false>
+// =============================================================================================
+// backward, wide (32-channel chunk): wave-autonomous, matrix pipe for D = <colour, v_out> AND for the colour
+// gradients; survivors queued to full batches of 32
+// =============================================================================================
+// The previous generation (round 1 .. mid round 2: colour row of every Gaussian in SGPRs through scalar loads,
+// 32 fma for D on the VALU, fac parked per contributing Gaussian, one MFMA flush per 32 of them) spent 39 % of
+// its wave-cycles in s_waitcnt — every Gaussian waited for its colour row — and issued 37 % of the VALU peak
+// (profiles/r02_pmc.csv as of commit 22193a5).  Here the survivors of the quadrant cull are QUEUED in LDS (processing order =
+// descending list order) until 32 are there; for a batch
+//     D[64 pixels x 32 Gaussians] = V_OUT[64 x CH] * COLOUR^T[CH x 32]
+// runs as 2 x CH/2 v_mfma_f32_32x32x2_f32 (B operand: every lane loads half a colour row of ITS Gaussian with
+// vector loads, no scalar loads, nothing waited for inside the walk) and lands in the fac slab [slot][pixel];
+// the walk reads D with one ds_read per Gaussian, writes fac over it, and the batch ends with the same
+// FAC * V_OUT flush as before.  Per Gaussian the VALU loses the 32 fma and the colour-row bookkeeping; the
+// matrix pipe (idle otherwise) takes 2 x 64 cycles per Gaussian.
+// 27 left over + 64 staged (last index 90); the null records sit behind <= 27 left over.  Every byte counts:
+// with the second array's v_out tile the workgroup needs 53 248 B of LDS, and three workgroups per CU fit only
+// up to there (the allocation granule; 54 272 B measured 2 per CU, whatever the occupancy API says)
+#define BQ_CAP 92
+
+struct __attribute__((aligned(16))) WaveQueue {
+    float4 a[BQ_CAP];   // x, y, opacity, list position (int bits)
+    float4 b[BQ_CAP];   // conic a, b, c, Gaussian id (int bits; -1 = null record)
+};
+
+// second colour array (<= 8 channels) whose backward rides on the walk of a 32-channel chunk (gg_blend_bwd_pair)
+struct Seg2B {
+    const float *colors;      // (N, C2)
+    const float *background;  // (C2,)
+    const float *v_out;       // (H, W, C2)
+    float *v_colors;          // gradient rows, cs2 floats apart
+    int C2, nch2, cs2;
+};
+
+// EX: the backward of a second colour array of <= 8 channels (Seg2B) in the same walk: alpha, T and the geometry
+// partials are those of ALL channels together (v_alpha is linear in <colour, v_out>), so D gets 4 more k-steps,
+// the second array's v_out tile (64 pixels x 8) sits in LDS, and its colour gradients are a second, small flush
+// (FAC[32 x 64] * V_OUT2[64 x 8] as v_mfma_f32_16x16x4_f32).  What the plugin route's feature | rgb+depth+normal
+// operator uses: one backward walk per view instead of two.
+template <bool FULL, int ABL = 0, int CHD = 32, bool DET = false, bool EX = false>
 __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
@@ -511,23 +549,25 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
     const float *__restrict__ final_T, const int32_t *__restrict__ final_idx,
     const float *__restrict__ v_out, float *__restrict__ v_xy, float *__restrict__ v_conic,
     float *__restrict__ v_colors, float *__restrict__ v_opacity, int gstride, int cstride,
-    DetSlab det = DetSlab()) {
+    DetSlab det = DetSlab(), Seg2B seg2 = Seg2B()) {
+    static_assert(!EX || (FULL && CHD == 32 && !DET), "the second array rides on the full 32-channel build");
     constexpr int CH = CHD;
+    constexpr int KS = CHD / 2;     // k-steps of the D product; lane half h supplies channels [KS h, KS h + KS)
     constexpr int KG = 6;
     constexpr int KB = GRP * KG;
     using R = Red6<KB>;
-    __shared__ WaveList lists[4];
-    __shared__ float s_fac[4][B2_SLOTS * B2_FSTRIDE];
-    __shared__ int s_slotgid[4][B2_SLOTS];
-    __shared__ int s_slote[4][DET ? B2_SLOTS : 1];     // list entry of each slot (deterministic mode)
+    __shared__ WaveQueue queues[4];
+    __shared__ float s_fac[4][B2_SLOTS * 65];
+    __shared__ int s_slote[4][DET ? B2_SLOTS : 1];
+    __shared__ __attribute__((aligned(16))) float s_vt[4][EX ? 64 * 8 : 4];   // EX: V_OUT2[pixel][8]
 
     const int tile = xcd_tile(blockIdx.x, ntiles);
     if (tile < 0) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    WaveList &L = lists[wave];
+    float *vt = s_vt[wave];
+    WaveQueue &Q = queues[wave];
     float *fac_w = s_fac[wave];
-    int *slotgid = s_slotgid[wave];
     int *slote = s_slote[wave];
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int qx0 = tx * GG_BLOCK + (wave & 1) * 8, qy0 = ty * GG_BLOCK + (wave >> 1) * 8;
@@ -541,20 +581,42 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
     const float T_final = inside ? final_T[p] : 1.0f;
     const int fin = inside ? final_idx[p] : range.x;
     float T = T_final;
-    float vo[CH];
     float W;
     {
         float Bsum = 0.0f;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            vo[c] = (inside && (FULL || c < nch)) ? v_out[p * C + ch_off + c] : 0.0f;
-            if (FULL || c < nch) Bsum = __builtin_fmaf(background[ch_off + c], vo[c], Bsum);
+            const float v = (inside && (FULL || c < nch)) ? v_out[p * C + ch_off + c] : 0.0f;
+            if (FULL || c < nch) Bsum = __builtin_fmaf(background[ch_off + c], v, Bsum);
+        }
+        if (EX) {
+            float t8[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                t8[c] = (inside && c < seg2.nch2) ? seg2.v_out[p * seg2.C2 + c] : 0.0f;
+                if (c < seg2.nch2) Bsum = __builtin_fmaf(seg2.background[c], t8[c], Bsum);
+            }
+            reinterpret_cast<float4 *>(vt + lane * 8)[0] = make_float4(t8[0], t8[1], t8[2], t8[3]);
+            reinterpret_cast<float4 *>(vt + lane * 8)[1] = make_float4(t8[4], t8[5], t8[6], t8[7]);
         }
         W = T_final * Bsum;
     }
     const int wch = lane & 31, half = lane >> 5;
     const bool wch_ok = FULL || wch < nch;
-    float vob[32];  // MFMA B operands: V_OUT[pixel 2s + half][channel wch]
+    // D product, A operands: V_OUT[pixel (lane & 31) + 32 c][channel KS half + s]
+    float voa[2][KS];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int pm = (lane & 31) + 32 * c;
+        const int pj = qx0 + (pm & 7), pi = qy0 + (pm >> 3);
+        const bool pin = (pi < img_h) && (pj < img_w);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int ch = KS * half + s;
+            voa[c][s] = (pin && (FULL || ch < nch)) ? v_out[((size_t)pi * img_w + pj) * C + ch_off + ch] : 0.0f;
+        }
+    }
+    float vob[32];  // flush, B operands: V_OUT[pixel 2s + half][channel wch]
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
         const int pq = 2 * s + half;
@@ -575,48 +637,75 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
     else if (my_k < 5) { my_base = v_conic + (my_k - 2); my_stride = gstride ? gstride : 3; }
     else { my_base = v_opacity; my_stride = gstride ? gstride : 1; }
     const int cs = cstride ? cstride : C;
+    // vector loads of the colour half-rows need 16-byte aligned rows
+    const bool vec = FULL && (C % 4 == 0) && (ch_off % 4 == 0) && ((reinterpret_cast<uintptr_t>(colors) & 15) == 0);
 
-    int nslots = 0;  // wave-uniform
-    auto flush_slots = [&]() {
-        if (ABL >= 2) { nslots = 0; return; }
-        f32x16 acc;
+    // one batch: queue entries [base, base + n), n <= 32 (n < 32 only for the last batch of the walk, which
+    // is followed by null records up to a multiple of GRP)
+    auto run_batch = [&](const int base, const int n) {
+        if (ABL >= 6) { KEEP(n); return; }   // staging + queue only
+        const int jl = lane & 31;
+        const int cgid = (jl < n) ? __builtin_bit_cast(int, Q.b[base + jl].w) : -1;
+        f32x16 d0, d1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        const float *arow = fac_w + (lane & 31) * B2_FSTRIDE + half;
+        for (int r = 0; r < 16; ++r) d0[r] = d1[r] = 0.0f;
+        if (ABL < 4) {
+            float colb[KS];
+            const float *row = colors + (size_t)(cgid < 0 ? 0 : cgid) * C + ch_off + KS * half;
+            if (vec) {
 #pragma unroll
-        for (int s = 0; s < 32; ++s)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * s], vob[s], acc, 0, 0, 0);
-        // D: column = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*half (slot): every instruction
-        // below adds two complete 128-byte colour-gradient rows
+                for (int s = 0; s < KS; s += 4) {
+                    const float4 v4 = *reinterpret_cast<const float4 *>(row + s);
+                    colb[s] = v4.x; colb[s + 1] = v4.y; colb[s + 2] = v4.z; colb[s + 3] = v4.w;
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) colb[s] = (FULL || KS * half + s < nch) ? row[s] : 0.0f;
+            }
+            float colb2[4];
+            float4 va0, va1;
+            if (EX) {   // second array: channels 4 half + s of ITS colour row, and of the v_out tile in LDS
+                const float *row2 = seg2.colors + (size_t)(cgid < 0 ? 0 : cgid) * seg2.C2 + 4 * half;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) colb2[s] = (4 * half + s < seg2.nch2) ? row2[s] : 0.0f;
+                va0 = *reinterpret_cast<const float4 *>(vt + (lane & 31) * 8 + 4 * half);
+                va1 = *reinterpret_cast<const float4 *>(vt + ((lane & 31) + 32) * 8 + 4 * half);
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const float bv = cgid < 0 ? 0.0f : colb[s];
+                d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(voa[0][s], bv, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(voa[1][s], bv, d1, 0, 0, 0);
+            }
+            if (EX) {
+                const float a0[4] = {va0.x, va0.y, va0.z, va0.w}, a1[4] = {va1.x, va1.y, va1.z, va1.w};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float bv = cgid < 0 ? 0.0f : colb2[s];
+                    d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], bv, d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], bv, d1, 0, 0, 0);
+                }
+            }
+        }
+        if (DET && lane < 32) slote[jl] = __builtin_bit_cast(int, Q.a[base + min(jl, n - 1)].w);
+        // D[pixel m][slot n]: lane holds n = lane & 31, m = (r & 3) + 8 (r >> 2) + 4 half (+ 32 for d1)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int slot = (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (ABL >= 1) { KEEP(acc[r]); continue; }
-            if (DET) {
-                if (slot < nslots && wch_ok)
-                    det.p[((size_t)slote[slot] * 4 + wave) * det.ks + det.coff + wch] = acc[r];
-                continue;
-            }
-            if (slot < nslots && wch_ok && acc[r] != 0.0f)
-                atomicAdd(v_colors + (size_t)slotgid[slot] * cs + ch_off + wch, acc[r]);
+            const int pix = (r & 3) + 8 * (r >> 2) + 4 * half;
+            fac_w[FIDX(jl, pix)] = d0[r];
+            fac_w[FIDX(jl, 32 + pix)] = d1[r];
         }
-        nslots = 0;
-    };
-
-    for (int top = hi; top > range.x; top -= 64) {
-        const int e = top - 64 + lane;
-        const bool valid = e >= range.x;
-        const int cnt = stage_chunk<CH, true, true>(L, lane, e, valid, ids, rec, colors, C, ch_off,
-                                                    nch, xlo, xhi, ylo, yhi);
-        const int fin_rel = fin - (top - 64);
-        for (int kk = GRP + cnt - 1; kk >= GRP; kk -= GRP) {
-            float vis[GRP], alpha[GRP], dxs[GRP], dys[GRP], opac[GRP];
+        __builtin_amdgcn_wave_barrier();
+        unsigned slotmask = 0u;   // wave-uniform: slots with at least one blending pixel
+        for (int g = 0; g < n; g += GRP) {
+            float vis[GRP], alpha[GRP], dxs[GRP], dys[GRP], opac[GRP], Dv[GRP];
             float ca[GRP], cb[GRP], cc[GRP];
             bool pass[GRP];
 #pragma unroll
             for (int q = 0; q < GRP; ++q) {
-                const float4 A = L.a[kk - q], B = L.b[kk - q];
-                const int pos = __builtin_bit_cast(int, L.c[kk - q].w);
+                const float4 A = Q.a[base + g + q], B = Q.b[base + g + q];
+                Dv[q] = fac_w[FIDX(g + q, lane)];
+                const int pos = __builtin_bit_cast(int, A.w);
                 const float dx = A.x - px, dy = A.y - py;
                 dxs[q] = dx;
                 dys[q] = dy;
@@ -628,7 +717,7 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
                     0.5f, __builtin_fmaf(B.x * dx, dx, (B.z * dy) * dy), (B.y * dx) * dy);
                 vis[q] = gg_expf(-sigma);
                 alpha[q] = fminf(GG_ALPHA_MAX_BWD, A.z * vis[q]);
-                pass[q] = (pos < fin_rel) && sigma >= 0.0f && !(alpha[q] < GG_ALPHA_MIN);
+                pass[q] = (pos < fin) && sigma >= 0.0f && !(alpha[q] < GG_ALPHA_MIN);
             }
             if (__ballot(pass[0] || pass[1] || pass[2] || pass[3]) == 0ull) continue;
             if (ABL >= 5) {
@@ -636,7 +725,6 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
                 for (int q = 0; q < GRP; ++q) { KEEP(vis[q]); KEEP(alpha[q]); KEEP((int)pass[q]); }
                 continue;
             }
-
             float part[KB];
 #pragma unroll
             for (int q = 0; q < GRP; ++q) {
@@ -646,18 +734,7 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
                     for (int v = 0; v < KG; ++v) pg[v] = 0.0f;
                     continue;
                 }
-                const int gid = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, L.b[kk - q].w));
-                const float *col = colors + (size_t)gid * C + ch_off;
-                float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;  // 4 chains: latency, not order
-#pragma unroll
-                for (int c = 0; c < CH; c += 4) {
-                    d0 = __builtin_fmaf((FULL || c + 0 < nch) ? col[c + 0] : 0.f, vo[c + 0], d0);
-                    d1 = __builtin_fmaf((FULL || c + 1 < nch) ? col[c + 1] : 0.f, vo[c + 1], d1);
-                    d2 = __builtin_fmaf((FULL || c + 2 < nch) ? col[c + 2] : 0.f, vo[c + 2], d2);
-                    d3 = __builtin_fmaf((FULL || c + 3 < nch) ? col[c + 3] : 0.f, vo[c + 3], d3);
-                }
-                float D = (d0 + d1) + (d2 + d3);
-                if (ABL >= 4) D = vo[0] * (float)gid;
+                const float D = Dv[q];
                 const float ra_ = __builtin_amdgcn_rcpf(1.0f - alpha[q]);
                 const float Tn = T * ra_;
                 const float fac = pass[q] ? alpha[q] * Tn : 0.0f;
@@ -673,15 +750,8 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
                 pg[3] = (hs * dx) * dy;
                 pg[4] = (hs * dy) * dy;
                 pg[5] = pass[q] ? vis[q] * v_alpha : 0.0f;
-                // park fac for the matrix pipe
-                fac_w[nslots * B2_FSTRIDE + lane] = fac;
-                if (lane == 0) {
-                    slotgid[nslots] = gid;
-                    if (DET)
-                        slote[nslots] = top - 64 + __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, L.c[kk - q].w));
-                }
-                ++nslots;
-                if (nslots == B2_SLOTS) flush_slots();
+                fac_w[FIDX(g + q, lane)] = fac;   // over D: the flush reads fac from here
+                slotmask |= 1u << (g + q);
             }
             if (ABL >= 3) {
 #pragma unroll
@@ -689,17 +759,117 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
                 continue;
             }
             const float mine = R::run(part, lane);
-            const int my_gid = __builtin_bit_cast(int, L.b[kk - my_q].w);
+            const int my_gid = __builtin_bit_cast(int, Q.b[base + g + my_q].w);
             if (DET) {
-                const size_t e = (size_t)(top - 64 + __builtin_bit_cast(int, L.c[kk - my_q].w));
+                const size_t e = (size_t)__builtin_bit_cast(int, Q.a[base + g + my_q].w);
                 if (owner && my_gid >= 0) det.p[(e * 4 + wave) * det.ks + det.goff + my_k] = mine;
                 continue;
             }
             if (owner && my_gid >= 0 && mine != 0.0f) atomicAdd(my_base + (size_t)my_gid * my_stride, mine);
         }
+        // flush: FAC[32 slots x 64 pixels] * V_OUT[64 x 32 channels]; rows outside slotmask still hold D and
+        // are not written
+        slotmask = __builtin_amdgcn_readfirstlane(slotmask);
+        if (ABL >= 2 || slotmask == 0u) return;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fac_w[FIDX(lane & 31, 2 * s + half)], vob[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int slot = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (ABL >= 1) { KEEP(acc[r]); continue; }
+            const bool on = ((slotmask >> slot) & 1u) != 0u && wch_ok;
+            if (DET) {
+                if (on) det.p[((size_t)slote[slot] * 4 + wave) * det.ks + det.coff + wch] = acc[r];
+                continue;
+            }
+            if (on && acc[r] != 0.0f) {
+                const int sg = __builtin_bit_cast(int, Q.b[base + slot].w);   // the slot's Gaussian
+                atomicAdd(v_colors + (size_t)sg * cs + ch_off + wch, acc[r]);
+            }
+        }
+        if (EX) {
+            // second array: FAC[32 slots x 64 pixels] * V_OUT2[64 x 8] as 2 x 16 v_mfma_f32_16x16x4_f32
+            // (A: slot 16 mb + (lane & 15), pixel 4 s + (lane >> 4); B: the same pixel, channel lane & 15;
+            //  D: lane holds channel lane & 15 of slots 16 mb + 4 (lane >> 4) + r)
+            const int n16 = lane & 15, k4 = lane >> 4;
+            const float *vbp = vt + k4 * 8 + (n16 & 7);
+            const float vmask = n16 < 8 ? 1.0f : 0.0f;   // lanes of channels 8..15 supply zeros
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                if (((slotmask >> (16 * mb)) & 0xffffu) == 0u) continue;
+                f32x4 a4 = {0.0f, 0.0f, 0.0f, 0.0f};
+                const int m = 16 * mb + n16;
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fac_w[FIDX(m, 4 * s + k4)], vbp[32 * s] * vmask, a4,
+                                                              0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int slot = 16 * mb + 4 * k4 + r;
+                    if (ABL >= 1) { KEEP(a4[r]); continue; }
+                    const bool on = ((slotmask >> slot) & 1u) != 0u && n16 < seg2.nch2;
+                    if (on && a4[r] != 0.0f) {
+                        const int sg = __builtin_bit_cast(int, Q.b[base + slot].w);
+                        atomicAdd(seg2.v_colors + (size_t)sg * seg2.cs2 + n16, a4[r]);
+                    }
+                }
+            }
+        }
         __builtin_amdgcn_wave_barrier();
+    };
+
+    int qn = 0;   // queued survivors (wave-uniform)
+    // the first of the two dependent loads of the staging (id, then record) runs one chunk ahead of the walk
+    auto load_id = [&](int top_) {
+        const int e_ = top_ - 64 + lane;
+        return (top_ > range.x && e_ >= range.x) ? ids[e_] : 0;
+    };
+    int g_nxt = load_id(hi);
+    for (int top = hi; top > range.x; top -= 64) {
+        const int e = top - 64 + lane;
+        const bool valid = e >= range.x;
+        const int g = g_nxt;
+        const float4 ra = reinterpret_cast<const float4 *>(rec + g)[0];
+        const float4 rb = reinterpret_cast<const float4 *>(rec + g)[1];
+        g_nxt = load_id(top - 64);
+        const bool hit = valid && rec_hits_rect(ra, rb, xlo, xhi, ylo, yhi);
+        const uint64_t m = __ballot(hit);
+        const int cnt = __builtin_popcountll(m);
+        if (hit) {   // processing order: descending list position
+            const int pos = qn + __builtin_popcountll((m >> lane) >> 1);
+            Q.a[pos] = make_float4(ra.x, ra.y, ra.z, __builtin_bit_cast(float, e));
+            Q.b[pos] = make_float4(rb.x, rb.y, rb.z, __builtin_bit_cast(float, g));
+        }
+        qn += cnt;
+        __builtin_amdgcn_wave_barrier();
+        int done = 0;
+        while (qn - done >= 28) {   // 28 or 32 (a multiple of GRP): at most 27 stay behind, BQ_CAP
+            const int nb = min(32, (qn - done) & ~3);
+            run_batch(done, nb);
+            done += nb;
+        }
+        if (done > 0) {   // bring the left-over (< 28) to the front; source and destination do not overlap
+            const int left = qn - done;
+            float4 ta, tb;
+            if (lane < left) { ta = Q.a[done + lane]; tb = Q.b[done + lane]; }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < left) { Q.a[lane] = ta; Q.b[lane] = tb; }
+            qn = left;
+            __builtin_amdgcn_wave_barrier();
+        }
     }
-    if (nslots > 0) flush_slots();
+    if (qn > 0) {
+        if (lane < GRP) {   // null records behind the last survivor: opacity 0 -> alpha 0 -> never pass
+            Q.a[qn + lane] = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, 0x7fffffff));
+            Q.b[qn + lane] = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, -1));
+        }
+        __builtin_amdgcn_wave_barrier();
+        run_batch(0, qn);
+    }
 }
 
 // =============================================================================================
@@ -786,6 +956,47 @@ void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w
 }
 
 #ifdef GG_ABLATION
+static int g_pair_ablate = 0;
+extern "C" int gg_debug_set_pair_ablation(int level) {
+    const int prev = g_pair_ablate;
+    g_pair_ablate = level;
+    return prev;
+}
+#endif
+// first 32 channels of `colors` + a second array of <= 8 channels in one walk (gg_blend_bwd_pair)
+void gg_launch_blend2_bwd_pair(int C, int img_h, int img_w, int tiles_x, int ntiles, const int32_t *ids,
+                               const int2 *bins, const GRec *rec, const float *colors, const float *background,
+                               const float *final_Ts, const int32_t *final_idx, const float *v_out, float *v_xy,
+                               float *v_conic, float *v_colors, float *v_opacity, int gstride, int cstride,
+                               const float *colors2, int C2, const float *background2, const float *v_out2,
+                               float *v_colors2, int cstride2, hipStream_t s) {
+    dim3 grid(gg_tile_grid(ntiles)), block(256);
+    Seg2B seg2;
+    seg2.colors = colors2;
+    seg2.background = background2;
+    seg2.v_out = v_out2;
+    seg2.v_colors = v_colors2;
+    seg2.C2 = C2;
+    seg2.nch2 = C2;
+    seg2.cs2 = cstride2 ? cstride2 : C2;
+#define B2_PAIR(L) hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, L, 32, false, true>), grid, block, 0, s, C, 0, 32, \
+        img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, final_Ts, final_idx, v_out, v_xy, \
+        v_conic, v_colors, v_opacity, gstride, cstride, DetSlab(), seg2)
+#ifdef GG_ABLATION
+    switch (g_pair_ablate) {   // measurement twin (tools/kbench.py): wrong results on purpose
+        case 1: B2_PAIR(1); return;
+        case 2: B2_PAIR(2); return;
+        case 3: B2_PAIR(3); return;
+        case 4: B2_PAIR(4); return;
+        case 5: B2_PAIR(5); return;
+        case 6: B2_PAIR(6); return;
+        default: break;
+    }
+#endif
+    B2_PAIR(0);
+}
+
+#ifdef GG_ABLATION
 // measurement-only entry (tools/kbench.py): ablated builds of the 3-channel backward
 void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, int tiles_x,
                                  int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
@@ -804,11 +1015,27 @@ void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, 
         case 13: B2_WABL(3); break;
         case 14: B2_WABL(4); break;
         case 15: B2_WABL(5); break;
+        case 16: B2_WABL(6); break;
         case 1: hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3, 1>), grid, block, 0, s, B2_BWDN_ARGS); break;
         case 2: hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3, 2>), grid, block, 0, s, B2_BWDN_ARGS); break;
         case 3: hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3, 3>), grid, block, 0, s, B2_BWDN_ARGS); break;
         case 4: hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3, 4>), grid, block, 0, s, B2_BWDN_ARGS); break;
         default: hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3, 0>), grid, block, 0, s, B2_BWDN_ARGS); break;
     }
+}
+// resident workgroups per CU of the backward kernels (tools/kbench.py prints them)
+extern "C" int gg_debug_occupancy(int *out4) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blend2_bwd_wide_kernel<true>, 256, 0) != hipSuccess) return -1;
+    out4[0] = n;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blend2_bwd_wide_kernel<true, 0, 32, false, true>, 256, 0) !=
+        hipSuccess) return -1;
+    out4[1] = n;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blend2_bwd_narrow_kernel<8>, 256, 0) != hipSuccess) return -1;
+    out4[2] = n;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blend2_fwd_kernel<32, true, true, true>, 256, 0) != hipSuccess)
+        return -1;
+    out4[3] = n;
+    return 0;
 }
 #endif  // GG_ABLATION

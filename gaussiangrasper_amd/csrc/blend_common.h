@@ -4,6 +4,7 @@
 #include "gg_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define BW_BATCH 64
 
 // Deterministic backward (gg_blend_bwd_deterministic): instead of float atomics the kernels store the total

@@ -96,6 +96,7 @@ extern "C" const char *gg_prof_name(int id) {
         case GG_K_MLP_FWD: return "mlp_fwd_kernel";
         case GG_K_MLP_BWD: return "mlp_bwd_kernel";
         case GG_K_BLEND_FWD_PAIR: return "blend_fwd_pair_kernel<40>";
+        case GG_K_BLEND_BWD_PAIR: return "blend_bwd_pair_kernel<40>";
         case GG_K_COMPACT: return "compact_rows_kernel";
         case GG_K_DENSIFY: return "densify_rows_kernel";
         case GG_K_ADAM: return "adam_kernel";

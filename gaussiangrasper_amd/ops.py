@@ -702,12 +702,42 @@ class RasterizeSegments(Function):
         order = ([rider] if rider is not None else []) + [i for i in range(k) if i != rider]
         grads = [None] * k
         first = True
+
+        def cotangent(i):
+            v = v_outs[i]
+            if v is None:
+                v = torch.zeros(img_height, img_width, cols[i].shape[1], dtype=torch.float32, device=dev)
+            return _f32(v)
+
+        # a >= 32-channel array carries the rider through its first backward walk (gg_blend_bwd_pair): one
+        # walk computes alpha, T and the geometry gradients of both arrays
+        wide = next((i for i in range(k) if cols[i].shape[1] >= 32), None)
+        if rider is not None and wide is not None and not _DETERMINISTIC:
+            sink = ctx.sinks[wide]
+            flags = 1
+            if sink is not None:
+                v_colors = sink[1]
+                flags |= 2
+            else:
+                v_colors = torch.empty(n, cols[wide].shape[1], dtype=torch.float32, device=dev)
+            vo_w, vo_r = cotangent(wide), cotangent(rider)
+            _lib.check(lib.gg_blend_bwd_pair(
+                cols[wide].shape[1], cols[rider].shape[1], n, img_height, img_width, _ptr(ids_sorted),
+                _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(cols[wide]), _ptr(cols[rider]), _ptr(opacity),
+                _ptr(bgs[wide]), _ptr(bgs[rider]), _ptr(final_Ts), _ptr(final_idx), _ptr(vo_w), _ptr(vo_r),
+                _ptr(v_xy), _ptr(v_conic), _ptr(v_colors), _ptr(rec_g[:, 6:]), _ptr(v_opacity), gstride, 0, gstride,
+                _ptr(ws), ws.numel(), flags, _stream(dev)), "gg_blend_bwd_pair")
+            grads[rider] = rec_g[:, 6:]
+            if flags & 2:
+                if sink[2] is not None:
+                    sink[2](sink[0])
+            else:
+                grads[wide] = v_colors
+            order = [i for i in range(k) if i not in (wide, rider)]
+            first = False
         for i in order:
             ch = cols[i].shape[1]
-            v_out = v_outs[i]
-            if v_out is None:
-                v_out = torch.zeros(img_height, img_width, ch, dtype=torch.float32, device=dev)
-            v_out = _f32(v_out)
+            v_out = cotangent(i)
             flags = 1 | (0 if first else 4)
             sink = ctx.sinks[i]
             if i == rider:

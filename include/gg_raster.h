@@ -186,6 +186,23 @@ int gg_blend_bwd(int channels, int num_points, int img_height, int img_width,
 #define GG_BWD_ACCUMULATE_COLORS 2
 #define GG_BWD_ACCUMULATE_GEOM 4
 
+/* gg_blend_bwd_pair: the backward of gg_blend_fwd_pair — colors (N, channels >= 32) with v_out_img and colors2
+ * (N, channels2 <= 8) with v_out_img2 — in ONE walk of the tile lists for the first 32 channels and the second
+ * array together (alpha, T and the geometry gradients are those of all channels at once; D = <colour, v_out>
+ * over 40 channels and both colour-gradient products run on the matrix pipe).  v_xy, v_conic, v_opacity hold
+ * the geometry gradients of BOTH arrays (what autograd would sum over two gg_blend_bwd calls); v_colors /
+ * v_colors2 the colour gradients, rows color_stride / color_stride2 floats apart (0 = dense).  geom_stride as
+ * in gg_blend_bwd; v_colors2 = v_xy + 6 with color_stride2 = geom_stride puts the second array's gradients
+ * into the interleaved record.  flags: GG_BWD_WS_FROM_FORWARD, GG_BWD_ACCUMULATE_COLORS (for v_colors). */
+int gg_blend_bwd_pair(int channels, int channels2, int num_points, int img_height, int img_width,
+                      const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+                      const float *conics, const float *colors, const float *colors2, const float *opacity,
+                      const float *background, const float *background2, const float *final_Ts,
+                      const int32_t *final_idx, const float *v_out_img, const float *v_out_img2, float *v_xy,
+                      float *v_conic, float *v_colors, float *v_colors2, float *v_opacity, int geom_stride,
+                      int color_stride, int color_stride2, void *ws, size_t ws_bytes, int flags,
+                      gg_stream_t stream);
+
 /* gg_blend_bwd_deterministic: gg_blend_bwd with bit-reproducible results.  gsplat's backward
  * (csrc/backward.cu: one atomicAdd per warp per Gaussian) and gg_blend_bwd add in whatever order the
  * hardware schedules; here the kernels store the total of every (tile-list entry, 8x8 quadrant) into a slab
@@ -325,6 +342,7 @@ int gg_adam_step(int num_groups, const gg_adam_group_t *groups, int zero_grad, g
 #define GG_K_BLEND_FWD 10 /* + width index: template widths {1,3,4,8,16,32} -> 0..5 */
 #define GG_K_BLEND_BWD 20 /* + width index */
 #define GG_K_BLEND_FWD_PAIR 16 /* 32 channels + a second array of <= 8 in one walk */
+#define GG_K_BLEND_BWD_PAIR 17
 #define GG_K_COMPACT 26
 #define GG_K_DENSIFY 27
 #define GG_K_ADAM 28

@@ -21,4 +21,14 @@ for cols, op in ((torch.rand(n, 3, device=dev), ops.RasterizeGaussians), (sc.fea
     for _ in range(2):
         out = op.apply(x, depths, radii, conics.detach(), nth, c, opac.detach(), h, w, torch.zeros(c.shape[1], device=dev))
         out.backward(vo)
+# the plugin route's operator: feature (32) | rgb + depth + normal (7) -> forward pair kernel, 8-channel
+# rider backward, 32-channel backward
+feat = sc.feature.detach().requires_grad_(True)
+tail = torch.rand(n, 7, device=dev).requires_grad_(True)
+x = xys.detach().requires_grad_(True)
+vo = [torch.randn(h, w, 32, device=dev), torch.randn(h, w, 7, device=dev)]
+for _ in range(2):
+    imgs = ops.rasterize_segments(x, depths, radii, conics.detach(), nth, opac.detach(), h, w,
+                                  [(feat, torch.zeros(32, device=dev)), (tail, torch.zeros(7, device=dev))])
+    torch.autograd.backward(imgs, vo)
 torch.cuda.synchronize()

@@ -349,11 +349,18 @@ __host__ __device__ static inline int sh_nbases(int deg) {
 // per-lane walk would touch 64 cache lines per load; instead each wave copies its 64 rows
 // (64*3K contiguous floats) through LDS with fully coalesced dword loads and every lane then
 // reads its own row from LDS (row stride 3K words is odd -> bank-conflict free).
-template <int K>
+// TAIL (gg_shade_tail_fwd): the plugin route's 7-channel array rgb | depth | normal in one pass — colours =
+// clamp(sh + 0.5, 0, 1) (reference gaussian_splatting.py:731) written to columns 0..2 of a (N, 7) row, depth to
+// column 3, the normal to 4..6, and one byte per Gaussian saying which of the three clamps let the gradient
+// through (torch.clamp: min <= x <= max) for the backward.
+template <int K, bool TAIL = false>
 __global__ __launch_bounds__(256) void sh_fwd_kernel(int N, int deg,
                                                      const float *__restrict__ viewdirs,
                                                      const float *__restrict__ coeffs,
-                                                     float *__restrict__ colors) {
+                                                     float *__restrict__ colors,
+                                                     const float *__restrict__ depths = nullptr,
+                                                     const float *__restrict__ normals = nullptr,
+                                                     uint8_t *__restrict__ mask = nullptr) {
     // SH_ROWS Gaussians per wave: 32 halves the LDS per workgroup (38 KB at K = 25), which doubles
     // the resident waves and with them the loads in flight — the kernel only moves bytes
     // (K = 25, N = 1 M: 0.112 -> 0.092 ms = 3.4 TB/s; 16 rows per wave: no further change)
@@ -379,22 +386,42 @@ __global__ __launch_bounds__(256) void sh_fwd_kernel(int N, int deg,
     sh_basis(deg, viewdirs[3 * i], viewdirs[3 * i + 1], viewdirs[3 * i + 2], Y);
     const int nb = min(sh_nbases(deg), K);
     const float *cf = st + lane * ROW;
+    unsigned open_bits = 0u;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float acc = Y[0] * cf[c];
 #pragma unroll
         for (int k = 1; k < K; ++k)
             if (k < nb) acc = __builtin_fmaf(Y[k], cf[3 * k + c], acc);
-        colors[3 * (size_t)i + c] = acc;
+        if (TAIL) {
+            const float x = acc + 0.5f;
+            if (x >= 0.0f && x <= 1.0f) open_bits |= 1u << c;
+            // torch.clamp: NaN stays NaN
+            colors[7 * (size_t)i + c] = (x != x) ? x : fminf(fmaxf(x, 0.0f), 1.0f);
+        } else {
+            colors[3 * (size_t)i + c] = acc;
+        }
+    }
+    if (TAIL) {
+        colors[7 * (size_t)i + 3] = depths[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) colors[7 * (size_t)i + 4 + c] = normals[3 * (size_t)i + c];
+        mask[i] = (uint8_t)open_bits;
     }
 }
 
 // ACC: add to v_coeffs instead of overwriting it (gg_sh_bwd_accumulate: the caller's gradient buffer)
-template <int K, bool ACC = false>
+// TAIL (gg_shade_tail_bwd): v_colors is a (N, >= 7) array with rows vstride floats apart (the interleaved gradient
+// record of the blend backward); the colour cotangent passes the clamp where the forward's mask says so, the depth
+// and normal cotangents are copied out.
+template <int K, bool ACC = false, bool TAIL = false>
 __global__ __launch_bounds__(256) void sh_bwd_kernel(int N, int deg,
                                                      const float *__restrict__ viewdirs,
                                                      const float *__restrict__ v_colors,
-                                                     float *__restrict__ v_coeffs) {
+                                                     float *__restrict__ v_coeffs, int vstride = 3,
+                                                     const uint8_t *__restrict__ mask = nullptr,
+                                                     float *__restrict__ v_depths = nullptr,
+                                                     float *__restrict__ v_normals = nullptr) {
     constexpr int ROW = 3 * K;
     __shared__ float stage[4][64 * ROW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -407,7 +434,18 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(int N, int deg,
         float Y[GG_SH_MAX_BASES];
         sh_basis(deg, viewdirs[3 * i], viewdirs[3 * i + 1], viewdirs[3 * i + 2], Y);
         const int nb = min(sh_nbases(deg), K);
-        float vc[3] = {v_colors[3 * i], v_colors[3 * i + 1], v_colors[3 * i + 2]};
+        float vc[3];
+        if (TAIL) {
+            const float *vt = v_colors + (size_t)i * vstride;
+            const unsigned m = mask[i];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vc[c] = ((m >> c) & 1u) ? vt[c] : 0.0f;
+            v_depths[i] = vt[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v_normals[3 * (size_t)i + c] = vt[4 + c];
+        } else {
+            vc[0] = v_colors[3 * i]; vc[1] = v_colors[3 * i + 1]; vc[2] = v_colors[3 * i + 2];
+        }
         float *row = st + lane * ROW;
 #pragma unroll
         for (int k = 0; k < K; ++k)
@@ -514,6 +552,59 @@ extern "C" int gg_sh_bwd(int N, int K, int deg, const float *viewdirs, const flo
 extern "C" int gg_sh_bwd_accumulate(int N, int K, int deg, const float *viewdirs, const float *v_colors,
                                     float *v_coeffs, gg_stream_t stream) {
     return sh_dispatch(false, true, N, K, deg, viewdirs, v_colors, v_coeffs, stream);
+}
+
+template <int K>
+static void launch_tail(bool fwd, bool acc, int N, int deg, const float *viewdirs, const float *in, float *out,
+                        const float *depths, const float *normals, uint8_t *mask, int vstride, float *v_depths,
+                        float *v_normals, hipStream_t s) {
+    dim3 grid((N + 255) / 256), block(256);
+    const int rows_fwd = 4 * ((K >= 16) ? 32 : 64);
+    if (fwd)
+        hipLaunchKernelGGL((sh_fwd_kernel<K, true>), dim3((N + rows_fwd - 1) / rows_fwd), block, 0, s, N, deg,
+                           viewdirs, in, out, depths, normals, mask);
+    else if (acc)
+        hipLaunchKernelGGL((sh_bwd_kernel<K, true, true>), grid, block, 0, s, N, deg, viewdirs, in, out, vstride,
+                           mask, v_depths, v_normals);
+    else
+        hipLaunchKernelGGL((sh_bwd_kernel<K, false, true>), grid, block, 0, s, N, deg, viewdirs, in, out, vstride,
+                           mask, v_depths, v_normals);
+}
+static int tail_dispatch(bool fwd, bool acc, int N, int K, int deg, const float *viewdirs, const float *in,
+                         float *out, const float *depths, const float *normals, uint8_t *mask, int vstride,
+                         float *v_depths, float *v_normals, gg_stream_t stream) {
+    GG_REQUIRE(N >= 0, "num_points < 0");
+    GG_REQUIRE(K == 1 || K == 4 || K == 9 || K == 16 || K == 25, "num_bases must be 1,4,9,16,25");
+    GG_REQUIRE(deg >= 0 && sh_nbases(deg) <= K, "degrees_to_use exceeds stored bases");
+    if (N == 0) return GG_OK;
+    GG_REQUIRE(viewdirs && in && out && mask, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    gg_prof_begin(fwd ? GG_K_SH_FWD : GG_K_SH_BWD, s);
+    switch (K) {
+        case 1: launch_tail<1>(fwd, acc, N, deg, viewdirs, in, out, depths, normals, mask, vstride, v_depths, v_normals, s); break;
+        case 4: launch_tail<4>(fwd, acc, N, deg, viewdirs, in, out, depths, normals, mask, vstride, v_depths, v_normals, s); break;
+        case 9: launch_tail<9>(fwd, acc, N, deg, viewdirs, in, out, depths, normals, mask, vstride, v_depths, v_normals, s); break;
+        case 16: launch_tail<16>(fwd, acc, N, deg, viewdirs, in, out, depths, normals, mask, vstride, v_depths, v_normals, s); break;
+        default: launch_tail<25>(fwd, acc, N, deg, viewdirs, in, out, depths, normals, mask, vstride, v_depths, v_normals, s); break;
+    }
+    gg_prof_end(fwd ? GG_K_SH_FWD : GG_K_SH_BWD, s);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+extern "C" int gg_shade_tail_fwd(int N, int K, int deg, const float *viewdirs, const float *coeffs,
+                                 const float *depths, const float *normals, float *tail, uint8_t *clamp_mask,
+                                 gg_stream_t stream) {
+    GG_REQUIRE(N == 0 || (depths && normals), "null pointer");
+    return tail_dispatch(true, false, N, K, deg, viewdirs, coeffs, tail, depths, normals, clamp_mask, 7, nullptr,
+                         nullptr, stream);
+}
+extern "C" int gg_shade_tail_bwd(int N, int K, int deg, const float *viewdirs, const float *v_tail,
+                                 int v_tail_stride, const uint8_t *clamp_mask, float *v_coeffs, int accumulate,
+                                 float *v_depths, float *v_normals, gg_stream_t stream) {
+    GG_REQUIRE(v_tail_stride >= 7, "v_tail rows hold 7 values");
+    GG_REQUIRE(N == 0 || (v_depths && v_normals), "null pointer");
+    return tail_dispatch(false, accumulate != 0, N, K, deg, viewdirs, v_tail, v_coeffs, nullptr, nullptr,
+                         const_cast<uint8_t *>(clamp_mask), v_tail_stride, v_depths, v_normals, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -256,6 +256,59 @@ class SphericalHarmonics(Function):
         return None, None, v_coeffs
 
 
+class ShadeTail(Function):
+    """apply(degrees_to_use, viewdirs (N,3), coeffs (N,K,3), depths (N,), normals (N,3)) -> tail (N, 7) =
+    [ clamp(SphericalHarmonics(...) + 0.5, 0, 1) | depth | normal ]: the 7-channel colour array of the plugin
+    route's rasterize operator in one kernel each way (reference :730-731 clamp, :765 depth, :779 normal colours).
+    The backward reads the cotangent rows in place (the blend backward's interleaved gradient record, any row
+    stride) and adds the SH gradient into a registered gradient sink like SphericalHarmonics does."""
+
+    @staticmethod
+    def forward(ctx, degrees_to_use: int, viewdirs: Tensor, coeffs: Tensor, depths: Tensor, normals: Tensor):
+        n, k = coeffs.shape[0], coeffs.shape[-2]
+        assert k >= num_sh_bases(degrees_to_use), "not enough SH bases for degrees_to_use"
+        deg_from_sh(k)
+        if coeffs.shape[-1] != 3 or tuple(viewdirs.shape) != (n, 3):
+            raise ValueError("viewdirs must be (N, 3) and coeffs (N, K, 3)")
+        if tuple(depths.shape) != (n,) or tuple(normals.shape) != (n, 3):
+            raise ValueError("depths must be (N,) and normals (N, 3)")
+        dev = _require_hip(viewdirs, coeffs, depths, normals)
+        viewdirs, coeffs, depths_c, normals_c = _f32(viewdirs), _f32(coeffs), _f32(depths), _f32(normals)
+        tail = torch.empty(n, 7, dtype=torch.float32, device=dev)
+        mask = torch.empty(n, dtype=torch.uint8, device=dev)
+        _lib.check(_lib.load().gg_shade_tail_fwd(n, k, int(degrees_to_use), _ptr(viewdirs), _ptr(coeffs),
+                                                 _ptr(depths_c), _ptr(normals_c), _ptr(tail), _ptr(mask),
+                                                 _stream(dev)), "gg_shade_tail_fwd")
+        ctx.degrees_to_use, ctx.num_bases = int(degrees_to_use), k
+        ctx.save_for_backward(viewdirs, mask)
+        ctx.sink = _sink_for(coeffs) if coeffs.dtype == torch.float32 else None
+        return tail
+
+    @staticmethod
+    def backward(ctx, v_tail: Tensor):
+        viewdirs, mask = ctx.saved_tensors
+        dev, n = viewdirs.device, viewdirs.shape[0]
+        if v_tail.dtype != torch.float32 or v_tail.stride(1) != 1 or v_tail.stride(0) < 7:
+            v_tail = _f32(v_tail)      # rows of a wider record are read in place; anything else is copied
+        stride = v_tail.stride(0)
+        v_depths = torch.empty(n, dtype=torch.float32, device=dev)
+        v_normals = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        if ctx.sink is not None:
+            param, buf, notify = ctx.sink
+            _lib.check(lib.gg_shade_tail_bwd(n, ctx.num_bases, ctx.degrees_to_use, _ptr(viewdirs), _ptr(v_tail),
+                                             stride, _ptr(mask), _ptr(buf), 1, _ptr(v_depths), _ptr(v_normals),
+                                             _stream(dev)), "gg_shade_tail_bwd")
+            if notify is not None:
+                notify(param)
+            return None, None, None, v_depths, v_normals
+        v_coeffs = torch.empty(n, ctx.num_bases, 3, dtype=torch.float32, device=dev)
+        _lib.check(lib.gg_shade_tail_bwd(n, ctx.num_bases, ctx.degrees_to_use, _ptr(viewdirs), _ptr(v_tail), stride,
+                                         _ptr(mask), _ptr(v_coeffs), 0, _ptr(v_depths), _ptr(v_normals),
+                                         _stream(dev)), "gg_shade_tail_bwd")
+        return None, None, v_coeffs, v_depths, v_normals
+
+
 # ------------------------------------------------------------------------------------------------
 # binning shared by the rasterize calls of one view
 # ------------------------------------------------------------------------------------------------

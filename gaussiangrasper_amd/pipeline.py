@@ -86,7 +86,7 @@ def rasterize_activated(act: Dict, view: ViewParams, ops, sh_degree_to_use: int 
     return out
 
 
-def fused_images(ops, xys, depths, radii, conics, num_tiles_hit, opac, h, w, feature, rgbs, normals):
+def fused_images(ops, xys, depths, radii, conics, num_tiles_hit, opac, h, w, feature, rgbs, normals, tail=None):
     """feature (D) | rgb (3) | depth (1, background 10) | normal (3) images from one binning.
     With `ops.rasterize_segments` (the product) the feature array and the 7-channel rgb|depth|normal array
     are two segments of ONE operator: no (N, D+7) concatenation, aligned feature rows, one set of
@@ -95,7 +95,8 @@ def fused_images(ops, xys, depths, radii, conics, num_tiles_hit, opac, h, w, fea
     dev = xys.device
     d = feature.shape[1]
     if hasattr(ops, "rasterize_segments"):
-        tail = torch.cat([rgbs, depths[:, None], normals], dim=1)
+        if tail is None:
+            tail = torch.cat([rgbs, depths[:, None], normals], dim=1)
         bg_tail = torch.zeros(7, device=dev)
         bg_tail[3] = 10.0
         feat_im, tail_im = ops.rasterize_segments(xys, depths, radii, conics, num_tiles_hit, opac, h, w,
@@ -126,11 +127,16 @@ def rasterize_activated_fused(act: Dict, view: ViewParams, ops, sh_degree_to_use
         view.projmat.to(dev), view.fx, view.fy, view.cx, view.cy, h, w, view.tile_bounds)
     if xys.requires_grad:
         xys.retain_grad()
-    rgbs = ops.SphericalHarmonics.apply(sh_degree_to_use, act["viewdirs"], act["sh"])
-    rgbs = torch.clamp(rgbs + 0.5, 0.0, 1.0)
-    d = act["feature"].shape[1]
+    if hasattr(ops, "ShadeTail") and hasattr(ops, "rasterize_segments"):
+        # SH + clamp + the (N, 7) rgb | depth | normal array in one kernel each way
+        rgbs = None
+        tail = ops.ShadeTail.apply(sh_degree_to_use, act["viewdirs"], act["sh"], depths, act["normals"])
+    else:
+        tail = None
+        rgbs = ops.SphericalHarmonics.apply(sh_degree_to_use, act["viewdirs"], act["sh"])
+        rgbs = torch.clamp(rgbs + 0.5, 0.0, 1.0)
     feature, rgb, depth, normal = fused_images(ops, xys, depths, radii, conics, num_tiles_hit, opac, h, w,
-                                               act["feature"], rgbs, act["normals"])
+                                               act["feature"], rgbs, act["normals"], tail=tail)
     return {"xys": xys, "radii": radii, "depths": depths, "conics": conics,
             "num_tiles_hit": num_tiles_hit, "feature": feature, "rgb": rgb, "depth": depth,
             "normal": normal}

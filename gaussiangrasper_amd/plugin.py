@@ -54,21 +54,27 @@ def fused_view(model, means, log_scales, quats, opacities, colors_all, feature, 
         return None
     if model.training:
         model.xys.retain_grad()                                    # :724-725
-    if model.config.sh_degree > 0:
-        if not fused_act:
-            viewdirs = means.detach() - cam_pos                    # :727-728
-            viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
-        rgbs = ops.SphericalHarmonics.apply(sh_degree_to_use, viewdirs, colors_all)
-        rgbs = torch.clamp(rgbs + 0.5, 0.0, 1.0)                   # :731
-    else:
-        rgbs = torch.sigmoid(colors_all[:, 0, :])
     if not fused_act:  # smallest-axis normals (:605-619) of the rendered subset
         rot = ops.quat_to_rotmat(quats)
         idx = log_scales.exp().min(dim=-1)[1][..., None, None].expand(-1, 3, -1)
         model.normals = rot.gather(2, idx).squeeze(dim=2)
+    tail = None
+    if model.config.sh_degree > 0:
+        if not fused_act:
+            viewdirs = means.detach() - cam_pos                    # :727-728
+            viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
+        if hasattr(ops, "ShadeTail") and hasattr(ops, "rasterize_segments"):
+            # SH, + 0.5, clamp (:730-731) and the rgb | depth | normal colour array in one kernel each way
+            rgbs = None
+            tail = ops.ShadeTail.apply(sh_degree_to_use, viewdirs, colors_all, depths, model.normals)
+        else:
+            rgbs = ops.SphericalHarmonics.apply(sh_degree_to_use, viewdirs, colors_all)
+            rgbs = torch.clamp(rgbs + 0.5, 0.0, 1.0)               # :731
+    else:
+        rgbs = torch.sigmoid(colors_all[:, 0, :])
     # feature | rgb | depth (background 10, :769) | normal from one binning (pipeline.fused_images)
     feat_im, rgb, depth_im, normal_im = fused_images(ops, model.xys, depths, model.radii, conics, num_tiles_hit,
-                                                     opac, H, W, feature, rgbs, model.normals)
+                                                     opac, H, W, feature, rgbs, model.normals, tail=tail)
     return {"rgb": rgb, "feature": feat_im, "depth": depth_im, "normal": normal_im}
 
 

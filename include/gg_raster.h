@@ -80,6 +80,21 @@ int gg_sh_bwd(int num_points, int num_bases, int degrees_to_use, const float *vi
 int gg_sh_bwd_accumulate(int num_points, int num_bases, int degrees_to_use, const float *viewdirs,
                          const float *v_colors, float *v_coeffs, gg_stream_t stream);
 
+/* gg_shade_tail_fwd / _bwd: the plugin route's 7-channel colour array in one pass each way —
+ * tail (N, 7) = [ clamp(SH(viewdirs, coeffs) + 0.5, 0, 1) | depth | normal ], i.e. the reference's
+ * `rgbs = torch.clamp(SphericalHarmonics.apply(n, viewdirs, colors) + 0.5, 0.0, 1.0)` (gaussian_splatting.py:
+ * 730-731) packed with the depth (:765) and normal (:779) colour arrays it rasterizes next.  clamp_mask (N bytes):
+ * bit c set = the gradient of colour c passes the clamp (0 <= x <= 1, torch.clamp's rule).
+ * Backward: v_tail rows are v_tail_stride >= 7 floats apart (the interleaved gradient record of the blend
+ * backward is read in place); v_coeffs (N, num_bases, 3) is written, or added to when accumulate != 0;
+ * v_depths (N,), v_normals (N, 3) are written. */
+int gg_shade_tail_fwd(int num_points, int num_bases, int degrees_to_use, const float *viewdirs,
+                      const float *coeffs, const float *depths, const float *normals, float *tail,
+                      uint8_t *clamp_mask, gg_stream_t stream);
+int gg_shade_tail_bwd(int num_points, int num_bases, int degrees_to_use, const float *viewdirs,
+                      const float *v_tail, int v_tail_stride, const uint8_t *clamp_mask, float *v_coeffs,
+                      int accumulate, float *v_depths, float *v_normals, gg_stream_t stream);
+
 /* ---- quat_to_rotmat ------------------------------------------------------------------------
  * Replace gsplat `_torch_impl.quat_to_rotmat` (differentiable torch code there: ~35 elementwise
  * launches forward, ~70 backward; reference call sites gaussian_splatting.py:516,614 — the

@@ -528,6 +528,56 @@ void NAME(sh_bwd)(int N, int K, int degrees_to_use, const REAL *viewdirs, const 
     }
 }
 
+/* shade_tail: the plugin route's 7-channel colour array [ clamp(SH + 0.5, 0, 1) | depth | normal ] — what the
+ * reference computes at gaussian_splatting.py:730-731 (`rgbs = torch.clamp(rgbs + 0.5, 0.0, 1.0)`) and passes,
+ * with the depth (:765) and normal (:779) arrays, to its rasterize calls.  mask bit c: the gradient of colour c
+ * passes the clamp (torch.clamp backward: min <= x <= max).  Pinned in tests/test_shade_tail.py against torch
+ * autograd of clamp / cat applied to this oracle's own sh_fwd. */
+void NAME(shade_tail_fwd)(int N, int K, int degrees_to_use, const REAL *viewdirs, const REAL *coeffs,
+                          const REAL *depths, const REAL *normals, REAL *tail, uint8_t *mask) {
+    int nb = sh_nbases(degrees_to_use);
+    if (nb > K) nb = K;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) {
+        REAL Y[GG_SH_MAX_BASES];
+        sh_basis(degrees_to_use, viewdirs[3 * i], viewdirs[3 * i + 1], viewdirs[3 * i + 2], Y);
+        const REAL *cf = coeffs + (size_t)i * K * 3;
+        unsigned bits = 0;
+        for (int c = 0; c < 3; ++c) {
+            REAL acc = Y[0] * cf[c];
+            for (int k = 1; k < nb; ++k) acc = FMA(Y[k], cf[3 * k + c], acc);
+            const REAL x = acc + R_(0.5f);
+            if (x >= 0 && x <= 1) bits |= 1u << c;
+            tail[7 * (size_t)i + c] = (x != x) ? x : (x < 0 ? 0 : (x > 1 ? 1 : x));
+        }
+        tail[7 * (size_t)i + 3] = depths[i];
+        for (int c = 0; c < 3; ++c) tail[7 * (size_t)i + 4 + c] = normals[3 * (size_t)i + c];
+        mask[i] = (uint8_t)bits;
+    }
+}
+void NAME(shade_tail_bwd)(int N, int K, int degrees_to_use, const REAL *viewdirs, const REAL *v_tail,
+                          int v_tail_stride, const uint8_t *mask, REAL *v_coeffs, int accumulate,
+                          REAL *v_depths, REAL *v_normals) {
+    int nb = sh_nbases(degrees_to_use);
+    if (nb > K) nb = K;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) {
+        REAL Y[GG_SH_MAX_BASES];
+        sh_basis(degrees_to_use, viewdirs[3 * i], viewdirs[3 * i + 1], viewdirs[3 * i + 2], Y);
+        const REAL *vt = v_tail + (size_t)i * v_tail_stride;
+        REAL vc3[3];
+        for (int c = 0; c < 3; ++c) vc3[c] = ((mask[i] >> c) & 1u) ? vt[c] : 0;
+        REAL *vc = v_coeffs + (size_t)i * K * 3;
+        for (int k = 0; k < K; ++k)
+            for (int c = 0; c < 3; ++c) {
+                const REAL g = (k < nb) ? Y[k] * vc3[c] : 0;
+                vc[3 * k + c] = accumulate ? vc[3 * k + c] + g : g;
+            }
+        v_depths[i] = vt[3];
+        for (int c = 0; c < 3; ++c) v_normals[3 * (size_t)i + c] = vt[4 + c];
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * Binning — gsplat rasterize.py compute_cumulative_intersects + bin_and_sort_gaussians (†),
  * forward.cu map_gaussian_to_intersects / get_tile_bin_edges, torch.sort on the int64 keys;

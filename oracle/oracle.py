@@ -137,6 +137,30 @@ def sh_bwd(degrees_to_use, num_bases, viewdirs, v_colors, dtype=np.float32):
     return out
 
 
+def shade_tail_fwd(degrees_to_use, viewdirs, coeffs, depths, normals, dtype=np.float32):
+    """-> tail (N, 7) = [clamp(SH + 0.5, 0, 1) | depth | normal], clamp mask (N,) uint8"""
+    lib, pre, _ = _lib(dtype)
+    viewdirs, coeffs, depths, normals = _c(viewdirs, dtype), _c(coeffs, dtype), _c(depths, dtype), _c(normals, dtype)
+    n, k = coeffs.shape[0], coeffs.shape[1]
+    tail, mask = np.zeros((n, 7), dtype), np.zeros(n, np.uint8)
+    getattr(lib, pre + "shade_tail_fwd")(C.c_int(n), C.c_int(k), C.c_int(degrees_to_use), _p(viewdirs), _p(coeffs),
+                                         _p(depths), _p(normals), _p(tail), _p(mask))
+    return tail, mask
+
+
+def shade_tail_bwd(degrees_to_use, num_bases, viewdirs, v_tail, mask, v_coeffs_in=None, dtype=np.float32):
+    """v_tail (N, stride >= 7) -> v_coeffs (N, K, 3) (added to v_coeffs_in when given), v_depths (N,), v_normals (N, 3)"""
+    lib, pre, _ = _lib(dtype)
+    viewdirs, v_tail, mask = _c(viewdirs, dtype), _c(v_tail, dtype), _c(mask, np.uint8)
+    n = viewdirs.shape[0]
+    out = np.zeros((n, num_bases, 3), dtype) if v_coeffs_in is None else _c(v_coeffs_in, dtype).copy()
+    vd, vn = np.zeros(n, dtype), np.zeros((n, 3), dtype)
+    getattr(lib, pre + "shade_tail_bwd")(C.c_int(n), C.c_int(num_bases), C.c_int(degrees_to_use), _p(viewdirs),
+                                         _p(v_tail), C.c_int(v_tail.shape[1]), _p(mask), _p(out),
+                                         C.c_int(0 if v_coeffs_in is None else 1), _p(vd), _p(vn))
+    return out, vd, vn
+
+
 def bin_and_sort(xys, depths, radii, num_tiles_hit, tile_bounds, dtype=np.float32):
     """compute_cumulative_intersects + bin_and_sort_gaussians.
     -> dict(num_intersects, cum_tiles_hit, isect_ids, gaussian_ids, isect_ids_sorted,

@@ -1,0 +1,99 @@
+"""gg_shade_tail (SH + 0.5 + clamp + rgb | depth | normal packing, reference gaussian_splatting.py:730-731, :765, :779):
+the oracle restatement against torch autograd of clamp / cat applied to the oracle's own SH (CPU), and the HIP kernels
+against the oracle (GPU, bit-exact both ways)."""
+import numpy as np
+import pytest
+import torch
+
+from gaussiangrasper_amd.ops import num_sh_bases
+
+
+def _inputs(n, k, seed=0):
+    rng = np.random.default_rng(seed)
+    viewdirs = rng.standard_normal((n, 3)).astype(np.float32)
+    viewdirs /= np.linalg.norm(viewdirs, axis=1, keepdims=True)
+    coeffs = (rng.standard_normal((n, k, 3)) * 0.6).astype(np.float32)     # plenty of values outside [-0.5, 0.5]
+    depths = rng.uniform(0.5, 9.0, n).astype(np.float32)
+    normals = rng.standard_normal((n, 3)).astype(np.float32)
+    return viewdirs, coeffs, depths, normals
+
+
+@pytest.mark.parametrize("k,deg", [(25, 4), (25, 2), (16, 3), (9, 2), (4, 1), (1, 0)])
+def test_oracle_shade_tail_matches_torch_autograd_of_the_callers_ops(oracle, k, deg):
+    n = 777
+    viewdirs, coeffs, depths, normals = _inputs(n, k)
+    tail, mask = oracle.shade_tail_fwd(deg, viewdirs, coeffs, depths, normals)
+    rgb = torch.from_numpy(oracle.sh_fwd(deg, viewdirs, coeffs)).requires_grad_(True)
+    d, nr = torch.from_numpy(depths).requires_grad_(True), torch.from_numpy(normals).requires_grad_(True)
+    ref = torch.cat([torch.clamp(rgb + 0.5, 0.0, 1.0), d[:, None], nr], dim=1)
+    np.testing.assert_array_equal(tail, ref.detach().numpy())
+    # cotangent rows inside a wider record, as the blend backward hands them over
+    rec = np.random.default_rng(3).standard_normal((n, 13)).astype(np.float32)
+    v_tail = rec[:, 6:]
+    ref.backward(torch.from_numpy(np.ascontiguousarray(v_tail)))
+    v_sh_ref = oracle.sh_bwd(deg, k, viewdirs, rgb.grad.numpy())
+    wide = np.zeros((n, 13), np.float32)
+    wide[:, :7] = v_tail
+    v_sh, v_d, v_n = oracle.shade_tail_bwd(deg, k, viewdirs, wide, mask)
+    np.testing.assert_array_equal(v_sh, v_sh_ref)
+    np.testing.assert_array_equal(v_d, d.grad.numpy())
+    np.testing.assert_array_equal(v_n, nr.grad.numpy())
+    assert 0 < int((mask != 7).sum()) < n          # some colours clamp, some do not
+    # accumulation adds to what is there
+    prior = np.random.default_rng(4).standard_normal((n, k, 3)).astype(np.float32)
+    v_acc, _, _ = oracle.shade_tail_bwd(deg, k, viewdirs, wide, mask, v_coeffs_in=prior)
+    np.testing.assert_array_equal(v_acc, prior + v_sh_ref)
+
+
+def test_clamp_boundaries_pass_the_gradient_like_torch(oracle):
+    # x = sh + 0.5 exactly 0 or 1: torch.clamp's backward passes the gradient (min <= x <= max)
+    viewdirs = np.array([[0.0, 0.0, 1.0]] * 4, np.float32)
+    c0 = 0.28209479177387814
+    coeffs = np.zeros((4, 1, 3), np.float32)
+    coeffs[0, 0] = -0.5 / c0          # x ~ 0
+    coeffs[1, 0] = 0.5 / c0           # x ~ 1
+    coeffs[2, 0] = -2.0               # below
+    coeffs[3, 0] = 3.0                # above
+    tail, mask = oracle.shade_tail_fwd(0, viewdirs, coeffs, np.ones(4, np.float32), np.zeros((4, 3), np.float32))
+    x = torch.from_numpy(oracle.sh_fwd(0, viewdirs, coeffs)).requires_grad_(True)
+    y = torch.clamp(x + 0.5, 0.0, 1.0)
+    y.backward(torch.ones_like(y))
+    np.testing.assert_array_equal(tail[:, :3], y.detach().numpy())
+    passes = (x.grad.numpy() != 0)
+    np.testing.assert_array_equal(((mask[:, None] >> np.arange(3)) & 1).astype(bool), passes)
+    assert not passes[2].any() and not passes[3].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k,deg", [(1, 25, 4), (63, 25, 4), (1000, 25, 4), (50000, 25, 4), (5000, 25, 2), (3000, 16, 3),
+                                     (3000, 9, 2), (3000, 4, 1), (3000, 1, 0)])
+def test_hip_shade_tail_bitexact_vs_oracle(oracle, n, k, deg):
+    from gaussiangrasper_amd import ops as P
+    dev = torch.device("cuda:0")
+    viewdirs, coeffs, depths, normals = _inputs(n, k, seed=5)
+    tail_ref, mask_ref = oracle.shade_tail_fwd(deg, viewdirs, coeffs, depths, normals)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    sh, d, nr = t(coeffs).requires_grad_(True), t(depths).requires_grad_(True), t(normals).requires_grad_(True)
+    tail = P.ShadeTail.apply(deg, t(viewdirs), sh, d, nr)
+    np.testing.assert_array_equal(tail.detach().cpu().numpy(), tail_ref)
+    rec = np.random.default_rng(9).standard_normal((n, 13)).astype(np.float32)
+    rec_t = t(rec)
+    tail.backward(rec_t[:, 6:])                       # a strided view: read in place
+    wide = np.zeros((n, 13), np.float32)
+    wide[:, :7] = rec[:, 6:]
+    v_sh, v_d, v_n = oracle.shade_tail_bwd(deg, k, viewdirs, wide, mask_ref)
+    np.testing.assert_array_equal(sh.grad.cpu().numpy(), v_sh)
+    np.testing.assert_array_equal(d.grad.cpu().numpy(), v_d)
+    np.testing.assert_array_equal(nr.grad.cpu().numpy(), v_n)
+    # gradient sink: the SH gradient is added into the registered buffer
+    sh2 = t(coeffs).requires_grad_(True)
+    prior = np.random.default_rng(10).standard_normal(coeffs.shape).astype(np.float32)
+    buf = t(prior).clone()
+    P.clear_grad_sinks()
+    P.register_grad_sink(sh2, buf)
+    try:
+        P.ShadeTail.apply(deg, t(viewdirs), sh2, t(depths), t(normals)).backward(rec_t[:, 6:])
+    finally:
+        P.clear_grad_sinks()
+    assert sh2.grad is None
+    np.testing.assert_array_equal(buf.cpu().numpy(), prior + v_sh)

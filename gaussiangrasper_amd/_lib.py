@@ -39,6 +39,8 @@ SIGNATURES = {
                             _P, _P, _P, _P, _P, _P, _P]),
     "gg_project_bwd": (_I, [_I, _P, _P, _F, _P, _P, _P, _F, _F, _F, _F, _I, _I, _P, _P, _P, _P, _P,
                             _P, _P, _P, _P]),
+    "gg_project_bwd_ex": (_I, [_I, _P, _P, _F, _P, _P, _P, _F, _F, _F, _F, _I, _I, _P, _P, _P, _I, _P, _P, _I,
+                               _P, _I, _P, _P, _P]),
     "gg_sh_fwd": (_I, [_I, _I, _I, _P, _P, _P, _P]),
     "gg_sh_bwd": (_I, [_I, _I, _I, _P, _P, _P, _P]),
     "gg_sh_bwd_accumulate": (_I, [_I, _I, _I, _P, _P, _P, _P]),
@@ -46,6 +48,7 @@ SIGNATURES = {
     "gg_quat_to_rotmat_bwd": (_I, [_I, _P, _P, _P, _P]),
     "gg_activate_fwd": (_I, [_I] + [_P] * 12),
     "gg_activate_bwd": (_I, [_I] + [_P] * 12),
+    "gg_activate_bwd_ex": (_I, [_I] + [_P] * 7 + [_I] + [_P] * 4 + [_I, _P]),
     "gg_mlp_fwd": (_I, [_I64, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "gg_mlp_bwd": (_I, [_I64, _I, _I, _I] + [_P] * 11),
     "gg_cosine_loss_fwd": (_I, [_I64, _I, _P, _P, _P, _P, _P, _P, _P]),

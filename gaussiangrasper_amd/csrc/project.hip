@@ -154,7 +154,9 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
     const int32_t *__restrict__ radii, const float *__restrict__ conics,
     const float *__restrict__ v_xy, const float *__restrict__ v_depth,
     const float *__restrict__ v_conic, float *__restrict__ v_mean3d, float *__restrict__ v_scale,
-    float *__restrict__ v_quat) {
+    float *__restrict__ v_quat, int xy_stride = 2, int conic_stride = 3, int acc_means = 0) {
+    // xy_stride / conic_stride: floats between the rows of v_xy / v_conic (gg_project_bwd_ex: the blend backward's
+    // interleaved gradient record is read in place); acc_means: v_mean3d += (a registered gradient buffer)
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     float vm[3] = {0, 0, 0}, vs[3] = {0, 0, 0}, vq4[4] = {0, 0, 0, 0};
@@ -171,8 +173,8 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
         float hy = ((P[4] * px + P[5] * py) + P[6] * pz) + P[7];
         float hw = ((P[12] * px + P[13] * py) + P[14] * pz) + P[15];
         float rw = 1.0f / (hw + GG_W_EPS);
-        float vnx = (0.5f * (float)img_w) * v_xy[2 * i];
-        float vny = (0.5f * (float)img_h) * v_xy[2 * i + 1];
+        float vnx = (0.5f * (float)img_w) * v_xy[(size_t)xy_stride * i];
+        float vny = (0.5f * (float)img_h) * v_xy[(size_t)xy_stride * i + 1];
         float vhx = vnx * rw, vhy = vny * rw;
 #if GG_VJP_GSPLAT_COMPAT
         float vhw = 0.0f * hx * hy;   // compat: the homogeneous-w path is dropped
@@ -187,7 +189,8 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
         for (int j = 0; j < 3; ++j) vm[j] += V[8 + j] * vz;
         // (3) conic -> cov2d
         float ca = conics[3 * i], cb = conics[3 * i + 1], cc = conics[3 * i + 2];
-        float ga = v_conic[3 * i], gb = v_conic[3 * i + 1], gc = v_conic[3 * i + 2];
+        const float *vcn = v_conic + (size_t)conic_stride * i;
+        float ga = vcn[0], gb = vcn[1], gc = vcn[2];
         float xg00 = ca * ga + cb * gb, xg01 = ca * gb + cb * gc;
         float xg10 = cb * ga + cc * gb, xg11 = cb * gb + cc * gc;
         float s00 = -(xg00 * ca + xg01 * cb), s01 = -(xg00 * cb + xg01 * cc);
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        v_mean3d[3 * (size_t)i + k] = vm[k];
+        v_mean3d[3 * (size_t)i + k] = acc_means ? v_mean3d[3 * (size_t)i + k] + vm[k] : vm[k];
         v_scale[3 * (size_t)i + k] = vs[k];
     }
     reinterpret_cast<float4 *>(v_quat)[i] = make_float4(vq4[0], vq4[1], vq4[2], vq4[3]);
@@ -483,6 +486,13 @@ extern "C" int gg_project_fwd(int N, const float *means3d, const float *scales, 
     return GG_OK;
 }
 
+extern "C" int gg_project_bwd_ex(int N, const float *means3d, const float *scales, float glob_scale,
+                                 const float *quats, const float *viewmat, const float *projmat,
+                                 float fx, float fy, float cx, float cy, int img_height,
+                                 int img_width, const int32_t *radii, const float *conics,
+                                 const float *v_xy, int v_xy_stride, const float *v_depth, const float *v_conic,
+                                 int v_conic_stride, float *v_mean3d, int accumulate_means, float *v_scale,
+                                 float *v_quat, gg_stream_t stream);
 extern "C" int gg_project_bwd(int N, const float *means3d, const float *scales, float glob_scale,
                               const float *quats, const float *viewmat, const float *projmat,
                               float fx, float fy, float cx, float cy, int img_height,
@@ -490,8 +500,20 @@ extern "C" int gg_project_bwd(int N, const float *means3d, const float *scales, 
                               const float *v_xy, const float *v_depth, const float *v_conic,
                               float *v_mean3d, float *v_scale, float *v_quat,
                               gg_stream_t stream) {
+    return gg_project_bwd_ex(N, means3d, scales, glob_scale, quats, viewmat, projmat, fx, fy, cx, cy, img_height,
+                             img_width, radii, conics, v_xy, 2, v_depth, v_conic, 3, v_mean3d, 0, v_scale, v_quat,
+                             stream);
+}
+extern "C" int gg_project_bwd_ex(int N, const float *means3d, const float *scales, float glob_scale,
+                                 const float *quats, const float *viewmat, const float *projmat,
+                                 float fx, float fy, float cx, float cy, int img_height,
+                                 int img_width, const int32_t *radii, const float *conics,
+                                 const float *v_xy, int v_xy_stride, const float *v_depth, const float *v_conic,
+                                 int v_conic_stride, float *v_mean3d, int accumulate_means, float *v_scale,
+                                 float *v_quat, gg_stream_t stream) {
     (void)cx;
     (void)cy;
+    GG_REQUIRE(v_xy_stride >= 2 && v_conic_stride >= 3, "v_xy rows hold 2 values, v_conic rows 3");
     GG_REQUIRE(N >= 0, "num_points < 0");
     if (N == 0) return GG_OK;
     GG_REQUIRE(means3d && scales && quats && viewmat && projmat && radii && conics && v_xy &&
@@ -501,7 +523,7 @@ extern "C" int gg_project_bwd(int N, const float *means3d, const float *scales, 
     hipLaunchKernelGGL(project_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, N, means3d, scales, glob_scale, quats, viewmat,
                        projmat, fx, fy, img_height, img_width, radii, conics, v_xy, v_depth,
-                       v_conic, v_mean3d, v_scale, v_quat);
+                       v_conic, v_mean3d, v_scale, v_quat, v_xy_stride, v_conic_stride, accumulate_means);
     gg_prof_end(GG_K_PROJECT_BWD, (hipStream_t)stream);
     GG_CHECK_LAUNCH();
     return GG_OK;
@@ -760,14 +782,21 @@ __global__ __launch_bounds__(256) void activate_bwd_kernel(
     int N, const float4 *__restrict__ quats, const float *__restrict__ scales, const float *__restrict__ opac,
     const int32_t *__restrict__ axis, const float *__restrict__ v_scales, const float4 *__restrict__ v_quats_n,
     const float *__restrict__ v_opac, const float *__restrict__ v_normals, float *__restrict__ v_log_scales,
-    float4 *__restrict__ v_quats, float *__restrict__ v_opacities) {
+    float4 *__restrict__ v_quats, float *__restrict__ v_opacities, int opac_stride = 1, int acc = 0) {
+    // opac_stride: floats between the entries of v_opac (read in place from the blend backward's record);
+    // acc: the three outputs are added to (registered gradient buffers) instead of written
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-        v_log_scales[3 * (size_t)i + k] = v_scales[3 * (size_t)i + k] * scales[3 * (size_t)i + k];
+    for (int k = 0; k < 3; ++k) {
+        const float g = v_scales[3 * (size_t)i + k] * scales[3 * (size_t)i + k];
+        v_log_scales[3 * (size_t)i + k] = acc ? v_log_scales[3 * (size_t)i + k] + g : g;
+    }
     const float s = opac[i];
-    v_opacities[i] = v_opac[i] * (s * (1.0f - s));
+    {
+        const float g = v_opac[(size_t)i * opac_stride] * (s * (1.0f - s));
+        v_opacities[i] = acc ? v_opacities[i] + g : g;
+    }
     // q / |q|
     const float4 q = quats[i];
     const float n = sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
@@ -801,6 +830,10 @@ __global__ __launch_bounds__(256) void activate_bwd_kernel(
         out.z += vy / d;
         out.w += vz / d;
     }
+    if (acc) {
+        const float4 p = v_quats[i];
+        out = make_float4(p.x + out.x, p.y + out.y, p.z + out.z, p.w + out.w);
+    }
     v_quats[i] = out;
 }
 
@@ -819,10 +852,22 @@ extern "C" int gg_activate_fwd(int N, const float *means, const float *log_scale
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
+extern "C" int gg_activate_bwd_ex(int N, const float *quats, const float *scales, const float *opac,
+                                  const int32_t *axis, const float *v_scales, const float *v_quats_n,
+                                  const float *v_opac, int v_opac_stride, const float *v_normals, float *v_log_scales,
+                                  float *v_quats, float *v_opacities, int accumulate, gg_stream_t stream);
 extern "C" int gg_activate_bwd(int N, const float *quats, const float *scales, const float *opac,
                                const int32_t *axis, const float *v_scales, const float *v_quats_n,
                                const float *v_opac, const float *v_normals, float *v_log_scales,
                                float *v_quats, float *v_opacities, gg_stream_t stream) {
+    return gg_activate_bwd_ex(N, quats, scales, opac, axis, v_scales, v_quats_n, v_opac, 1, v_normals, v_log_scales,
+                              v_quats, v_opacities, 0, stream);
+}
+extern "C" int gg_activate_bwd_ex(int N, const float *quats, const float *scales, const float *opac,
+                                  const int32_t *axis, const float *v_scales, const float *v_quats_n,
+                                  const float *v_opac, int v_opac_stride, const float *v_normals, float *v_log_scales,
+                                  float *v_quats, float *v_opacities, int accumulate, gg_stream_t stream) {
+    GG_REQUIRE(v_opac_stride >= 1, "v_opac_stride < 1");
     GG_REQUIRE(N >= 0, "num_points < 0");
     if (N == 0) return GG_OK;
     GG_REQUIRE(quats && scales && opac && axis && v_scales && v_quats_n && v_opac && v_normals && v_log_scales &&
@@ -831,7 +876,7 @@ extern "C" int gg_activate_bwd(int N, const float *quats, const float *scales, c
                "quaternion arrays must be 16-byte aligned");
     hipLaunchKernelGGL(activate_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N,
                        (const float4 *)quats, scales, opac, axis, v_scales, (const float4 *)v_quats_n, v_opac,
-                       v_normals, v_log_scales, (float4 *)v_quats, v_opacities);
+                       v_normals, v_log_scales, (float4 *)v_quats, v_opacities, v_opac_stride, accumulate);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }

@@ -167,6 +167,7 @@ class ProjectGaussians(Function):
         if viewmat.numel() < 12 or projmat.numel() != 16:
             raise ValueError("viewmat must hold >= 12 and projmat exactly 16 elements")
         dev = _require_hip(means3d, scales, quats, viewmat, projmat)
+        ctx.sink = _sink_for(means3d) if (means3d.dtype == torch.float32 and means3d.is_contiguous()) else None
         means3d, scales, quats = _f32(means3d), _f32(scales), _f32(quats)
         viewmat, projmat = _f32(viewmat), _f32(projmat)
         lib = _lib.load()
@@ -195,18 +196,25 @@ class ProjectGaussians(Function):
         glob_scale, fx, fy, cx, cy, img_height, img_width = ctx.scalars
         dev = means3d.device
         n = means3d.shape[0]
-        v_xys = torch.zeros(n, 2, device=dev) if v_xys is None else _f32(v_xys)
+        # v_xys / v_conics usually are columns of the blend backward's interleaved record: read in place
+        v_xys, xy_stride = (torch.zeros(n, 2, device=dev), 2) if v_xys is None else _rows_in_place(v_xys, 2)
+        v_conics, conic_stride = (torch.zeros(n, 3, device=dev), 3) if v_conics is None \
+            else _rows_in_place(v_conics, 3)
         v_depths = torch.zeros(n, device=dev) if v_depths is None else _f32(v_depths)
-        v_conics = torch.zeros(n, 3, device=dev) if v_conics is None else _f32(v_conics)
-        v_mean3d = torch.empty(n, 3, dtype=torch.float32, device=dev)
         v_scale = torch.empty(n, 3, dtype=torch.float32, device=dev)
         v_quat = torch.empty(n, 4, dtype=torch.float32, device=dev)
+        sink = ctx.sink
+        v_mean3d = sink[1] if sink is not None else torch.empty(n, 3, dtype=torch.float32, device=dev)
         lib = _lib.load()
-        _lib.check(lib.gg_project_bwd(
+        _lib.check(lib.gg_project_bwd_ex(
             n, _ptr(means3d), _ptr(scales), glob_scale, _ptr(quats), _ptr(viewmat), _ptr(projmat),
-            fx, fy, cx, cy, img_height, img_width, _ptr(radii), _ptr(conics), _ptr(v_xys),
-            _ptr(v_depths), _ptr(v_conics), _ptr(v_mean3d), _ptr(v_scale), _ptr(v_quat),
-            _stream(dev)), "gg_project_bwd")
+            fx, fy, cx, cy, img_height, img_width, _ptr(radii), _ptr(conics), _ptr(v_xys), xy_stride,
+            _ptr(v_depths), _ptr(v_conics), conic_stride, _ptr(v_mean3d), 1 if sink is not None else 0,
+            _ptr(v_scale), _ptr(v_quat), _stream(dev)), "gg_project_bwd_ex")
+        if sink is not None:          # the means' gradient went straight into the registered buffer
+            if sink[2] is not None:
+                sink[2](sink[0])
+            v_mean3d = None
         return (v_mean3d, v_scale, None, v_quat, None, None, None, None, None, None, None, None,
                 None, None)
 
@@ -254,6 +262,17 @@ class SphericalHarmonics(Function):
         _lib.check(lib.gg_sh_bwd(n, ctx.num_bases, ctx.degrees_to_use, _ptr(viewdirs),
                                  _ptr(v_colors), _ptr(v_coeffs), _stream(dev)), "gg_sh_bwd")
         return None, None, v_coeffs
+
+
+def _rows_in_place(t: Tensor, width: int):
+    """(tensor, row stride in floats) for a (N, width) fp32 cotangent whose rows can be read where they are — a
+    dense array or the columns of a wider record (the blend backward's interleaved gradient record); anything
+    else is copied to a dense array first."""
+    if t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == width and t.stride(1) == 1 \
+            and t.stride(0) >= width and t.data_ptr() % 4 == 0:
+        return t, t.stride(0)
+    t = _f32(t).reshape(-1, width)
+    return t, width
 
 
 class ShadeTail(Function):
@@ -635,6 +654,10 @@ class ActivateGaussians(Function):
                                                _stream(dev)), "gg_activate_fwd")
         ctx.save_for_backward(q, scales, opac, axis)
         ctx.opacity_shape = tuple(opacities.shape)
+        # all three registered, or none: one accumulate switch for the kernel
+        sinks = [_sink_for(t) if (t.dtype == torch.float32 and t.is_contiguous()) else None
+                 for t in (log_scales, quats, opacities)]
+        ctx.sinks = sinks if all(k is not None for k in sinks) else None
         ctx.mark_non_differentiable(viewdirs)
         return scales, quats_n, opac.reshape(ctx.opacity_shape), viewdirs, normals
 
@@ -644,13 +667,25 @@ class ActivateGaussians(Function):
         dev, n = q.device, q.shape[0]
         z = lambda t, *shape: torch.zeros(*shape, dtype=torch.float32, device=dev) if t is None else _f32(t)
         v_scales, v_quats_n = z(v_scales, n, 3), z(v_quats_n, n, 4)
-        v_opac, v_normals = z(v_opac, n, 1), z(v_normals, n, 3)
-        v_ls = torch.empty(n, 3, dtype=torch.float32, device=dev)
-        v_q = torch.empty(n, 4, dtype=torch.float32, device=dev)
-        v_o = torch.empty(n, 1, dtype=torch.float32, device=dev)
-        _lib.check(_lib.load().gg_activate_bwd(n, _ptr(q), _ptr(scales), _ptr(opac), _ptr(axis), _ptr(v_scales),
-                                               _ptr(v_quats_n), _ptr(v_opac), _ptr(v_normals), _ptr(v_ls), _ptr(v_q),
-                                               _ptr(v_o), _stream(dev)), "gg_activate_bwd")
+        v_normals = z(v_normals, n, 3)
+        # v_opac usually is column 5 of the blend backward's interleaved record: read in place
+        v_opac, opac_stride = (torch.zeros(n, 1, device=dev), 1) if v_opac is None \
+            else _rows_in_place(v_opac.reshape(n, 1), 1)
+        if ctx.sinks is not None:     # add straight into the registered gradient buffers
+            v_ls, v_q, v_o = (k[1] for k in ctx.sinks)
+        else:
+            v_ls = torch.empty(n, 3, dtype=torch.float32, device=dev)
+            v_q = torch.empty(n, 4, dtype=torch.float32, device=dev)
+            v_o = torch.empty(n, 1, dtype=torch.float32, device=dev)
+        _lib.check(_lib.load().gg_activate_bwd_ex(
+            n, _ptr(q), _ptr(scales), _ptr(opac), _ptr(axis), _ptr(v_scales), _ptr(v_quats_n), _ptr(v_opac),
+            opac_stride, _ptr(v_normals), _ptr(v_ls), _ptr(v_q), _ptr(v_o), 1 if ctx.sinks is not None else 0,
+            _stream(dev)), "gg_activate_bwd_ex")
+        if ctx.sinks is not None:
+            for param, _buf, notify in ctx.sinks:
+                if notify is not None:
+                    notify(param)
+            return None, None, None, None, None
         return None, v_ls, v_q, v_o.reshape(ctx.opacity_shape), None
 
 

@@ -65,6 +65,16 @@ int gg_project_bwd(int num_points, const float *means3d, const float *scales, fl
                    const int32_t *radii, const float *conics, const float *v_xy,
                    const float *v_depth, const float *v_conic, float *v_mean3d, float *v_scale,
                    float *v_quat, gg_stream_t stream);
+/* gg_project_bwd_ex: the same with v_xy / v_conic rows v_xy_stride / v_conic_stride floats apart (the blend
+ * backward's interleaved gradient record {xy, conic, opacity, ...} is read in place: no compaction copies) and,
+ * with accumulate_means != 0, v_mean3d added to instead of written (the caller's gradient buffer of the means,
+ * which enter the projection as a leaf). */
+int gg_project_bwd_ex(int num_points, const float *means3d, const float *scales, float glob_scale,
+                      const float *quats, const float *viewmat, const float *projmat, float fx, float fy, float cx,
+                      float cy, int img_height, int img_width, const int32_t *radii, const float *conics,
+                      const float *v_xy, int v_xy_stride, const float *v_depth, const float *v_conic,
+                      int v_conic_stride, float *v_mean3d, int accumulate_means, float *v_scale, float *v_quat,
+                      gg_stream_t stream);
 
 /* ---- spherical harmonics -----------------------------------------------------------------
  * Replace gsplat `_C.compute_sh_forward` / `_C.compute_sh_backward` (SphericalHarmonics;
@@ -119,6 +129,12 @@ int gg_activate_bwd(int num_points, const float *quats, const float *scales, con
                     const int32_t *axis, const float *v_scales, const float *v_quats_n,
                     const float *v_opac, const float *v_normals, float *v_log_scales, float *v_quats,
                     float *v_opacities, gg_stream_t stream);
+/* gg_activate_bwd_ex: v_opac entries v_opac_stride floats apart (column 5 of the blend backward's record, read in
+ * place); accumulate != 0: v_log_scales, v_quats, v_opacities are added to (registered gradient buffers). */
+int gg_activate_bwd_ex(int num_points, const float *quats, const float *scales, const float *opac,
+                       const int32_t *axis, const float *v_scales, const float *v_quats_n, const float *v_opac,
+                       int v_opac_stride, const float *v_normals, float *v_log_scales, float *v_quats,
+                       float *v_opacities, int accumulate, gg_stream_t stream);
 
 /* ---- binning -------------------------------------------------------------------------------
  * Together replace gsplat `compute_cumulative_intersects` + `bin_and_sort_gaussians`

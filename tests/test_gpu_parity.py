@@ -995,3 +995,48 @@ def test_deterministic_backward_through_segments_and_gradient_sinks(oracle):
         assert_bitexact(x, y, f"deterministic segments {name}: run 1 vs run 2")
         assert_bitexact(x, z, f"deterministic segments {name}: autograd buffer vs gradient sink")
         assert_close(x, r, f"deterministic segments vs atomics {name}", rtol=5e-5, atol_frac=1e-6)
+
+
+@pytest.mark.gpu
+def test_backward_kernels_read_record_columns_in_place_and_add_into_sinks(oracle):
+    """gg_project_bwd_ex / gg_activate_bwd_ex: cotangents handed over as columns of a wider record (the blend
+    backward's interleaved gradient record) give the bits of the dense call; with registered gradient sinks the
+    parameter gradients are prior + gradient, bit for bit, and autograd gets None."""
+    n, h, w = 20000, 150, 200
+    sc, v = _scene_view(n, h, w)
+    rng = np.random.default_rng(21)
+    rec = torch.from_numpy(rng.standard_normal((n, 13)).astype(np.float32)).to(DEV)
+    v_depth = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(DEV)
+    v_norm = torch.from_numpy(rng.standard_normal((n, 3)).astype(np.float32)).to(DEV)
+    cam = v.cam_pos.to(DEV)
+
+    def run(strided, sinks):
+        leaves = [t.detach().clone().to(DEV).requires_grad_(True)
+                  for t in (sc.means, sc.scales, sc.quats, sc.opacities)]
+        means, ls, q, o = leaves
+        bufs = [torch.full_like(t, 0.25) for t in leaves]
+        P.clear_grad_sinks()
+        if sinks:
+            for t, b in zip(leaves, bufs):
+                P.register_grad_sink(t, b)
+        try:
+            scales, quats_n, opac, viewdirs, normals = P.ActivateGaussians.apply(means, ls, q, o, cam)
+            xys, depths, radii, conics, nth, _ = P.ProjectGaussians.apply(
+                means, scales, 1, quats_n, v.viewmat[:3].to(DEV), v.projmat.to(DEV), v.fx, v.fy, v.cx, v.cy, h, w,
+                v.tile_bounds)
+            g = (lambda t: t) if strided else (lambda t: t.contiguous())
+            torch.autograd.backward(
+                [xys, conics, opac, depths, normals],
+                [g(rec[:, 0:2]), g(rec[:, 2:5]), g(rec[:, 5:6]), v_depth, v_norm])
+        finally:
+            P.clear_grad_sinks()
+        if sinks:
+            assert all(t.grad is None for t in leaves)
+            return [_np(b) for b in bufs]
+        return [_np(t.grad) for t in leaves]
+
+    dense = run(False, False)
+    for name, a, b in zip(("means", "scales", "quats", "opacities"), dense, run(True, False)):
+        assert_bitexact(b, a, f"{name}: record columns read in place vs dense cotangents")
+    for name, a, b in zip(("means", "scales", "quats", "opacities"), dense, run(True, True)):
+        assert_bitexact(b, (np.float32(0.25) + a).astype(np.float32), f"{name}: gradient sink = prior + gradient")

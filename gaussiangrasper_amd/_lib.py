@@ -64,7 +64,8 @@ SIGNATURES = {
     "gg_blend_bwd": (_I, [_I, _I, _I, _I] + [_P] * 14 + [_I, _I, _P, _SZ, _I, _P]),
     "gg_shade_tail_fwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "gg_shade_tail_bwd": (_I, [_I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P]),
-    "gg_blend_bwd_pair": (_I, [_I, _I, _I, _I, _I] + [_P] * 18 + [_I, _I, _I, _P, _SZ, _I, _P]),
+    "gg_blend_bwd_pair": (_I, [_I, _I, _I, _I, _I] + [_P] * 12 + [C.POINTER(_P), C.POINTER(_I), _I] + [_P] * 5
+                          + [_I, _I, _I, _P, _SZ, _I, _P]),
     "gg_blend_bwd_deterministic_workspace": (_SZ, [_I, _I, _I64]),
     "gg_blend_bwd_deterministic": (_I, [_I, _I, _I, _I] + [_P] * 14 + [_I, _I, _P, _SZ, _I, _I64, _P, _SZ, _P]),
     "gg_expf_array": (_I, [_I, _P, _P, _P]),

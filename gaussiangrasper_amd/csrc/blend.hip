@@ -65,7 +65,8 @@ void gg_launch_blend2_bwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
                                const int2 *bins, const GRec *rec, const float *colors, const float *background,
                                const float *final_Ts, const int32_t *final_idx, const float *v_out, float *v_xy,
                                float *v_conic, float *v_colors, float *v_opacity, int gstride, int cstride,
-                               const float *colors2, int C2, const float *background2, const float *v_out2,
+                               const float *colors2, int C2, const float *background2,
+                               const float *const *v_out2_parts, const int *v_out2_channels, int num_parts,
                                float *v_colors2, int cstride2, hipStream_t s);
 void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int ntiles, const int32_t *ids,
                                const int2 *bins, const GRec *rec, const float *colors, const float *background,
@@ -410,7 +411,8 @@ extern "C" int gg_blend_bwd_pair(int C, int C2, int N, int img_h, int img_w, con
                                  const int32_t *tile_bins, const float *xys, const float *conics,
                                  const float *colors, const float *colors2, const float *opacity,
                                  const float *background, const float *background2, const float *final_Ts,
-                                 const int32_t *final_idx, const float *v_out, const float *v_out2, float *v_xy,
+                                 const int32_t *final_idx, const float *v_out, const float *const *v_out2_parts,
+                                 const int *v_out2_channels, int num_parts, float *v_xy,
                                  float *v_conic, float *v_colors, float *v_colors2, float *v_opacity,
                                  int geom_stride, int color_stride, int color_stride2, void *ws, size_t ws_bytes,
                                  int flags, gg_stream_t stream) {
@@ -423,8 +425,18 @@ extern "C" int gg_blend_bwd_pair(int C, int C2, int N, int img_h, int img_w, con
     GG_REQUIRE(img_h > 0 && img_w > 0, "empty image");
     if (N == 0) return GG_OK;
     GG_REQUIRE(ids && tile_bins && xys && conics && colors && colors2 && opacity && background && background2 &&
-                   final_Ts && final_idx && v_out && v_out2 && v_xy && v_conic && v_colors && v_colors2 && v_opacity,
+                   final_Ts && final_idx && v_out && v_out2_parts && v_out2_channels && v_xy && v_conic && v_colors &&
+                   v_colors2 && v_opacity,
                "null pointer");
+    GG_REQUIRE(num_parts >= 1 && num_parts <= 3, "the second cotangent comes as 1..3 images");
+    {
+        int total = 0;
+        for (int k = 0; k < num_parts; ++k) {
+            GG_REQUIRE(v_out2_parts[k] != nullptr && v_out2_channels[k] >= 1, "empty part of the second cotangent");
+            total += v_out2_channels[k];
+        }
+        GG_REQUIRE(total == C2, "the parts of the second cotangent must add up to channels2");
+    }
     GG_REQUIRE(geom_stride == 0 || geom_stride >= 6, "geom_stride must be 0 (dense) or >= 6");
     GG_REQUIRE(color_stride == 0 || color_stride >= C, "color_stride must be 0 (dense) or >= channels");
     GG_REQUIRE(color_stride2 == 0 || color_stride2 >= C2, "color_stride2 must be 0 (dense) or >= channels2");
@@ -465,7 +477,8 @@ extern "C" int gg_blend_bwd_pair(int C, int C2, int N, int img_h, int img_w, con
     gg_prof_begin(GG_K_BLEND_BWD_PAIR, s);
     gg_launch_blend2_bwd_pair(C, img_h, img_w, tiles_x, ntiles, ids, (const int2 *)tile_bins, rec, colors, background,
                               final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, geom_stride,
-                              color_stride, colors2, C2, background2, v_out2, v_colors2, color_stride2, s);
+                              color_stride, colors2, C2, background2, v_out2_parts, v_out2_channels, num_parts,
+                              v_colors2, color_stride2, s);
     gg_prof_end(GG_K_BLEND_BWD_PAIR, s);
     for (int off = 32; off < C;) {   // further chunks of the first array: their own walks, adding to the same arrays
         const int w = chunk_width(C - off);

@@ -531,7 +531,8 @@ struct __attribute__((aligned(16))) WaveQueue {
 struct Seg2B {
     const float *colors;      // (N, C2)
     const float *background;  // (C2,)
-    const float *v_out;       // (H, W, C2)
+    const float *v_out[3];    // the (H, W, C2) cotangent, as up to three images of vo_w[k] consecutive channels
+    int vo_w[3];              // (the caller's rgb | depth | normal cotangents are read where they are)
     float *v_colors;          // gradient rows, cs2 floats apart
     int C2, nch2, cs2;
 };
@@ -593,7 +594,11 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
             float t8[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                t8[c] = (inside && c < seg2.nch2) ? seg2.v_out[p * seg2.C2 + c] : 0.0f;
+                // channel c lives in part a at column c - first channel of that part
+                const int w0 = seg2.vo_w[0], w01 = w0 + seg2.vo_w[1];
+                const int a = c < w0 ? 0 : (c < w01 ? 1 : 2);
+                const int col = c - (a == 0 ? 0 : (a == 1 ? w0 : w01));
+                t8[c] = (inside && c < seg2.nch2) ? seg2.v_out[a][p * seg2.vo_w[a] + col] : 0.0f;
                 if (c < seg2.nch2) Bsum = __builtin_fmaf(seg2.background[c], t8[c], Bsum);
             }
             reinterpret_cast<float4 *>(vt + lane * 8)[0] = make_float4(t8[0], t8[1], t8[2], t8[3]);
@@ -968,13 +973,17 @@ void gg_launch_blend2_bwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
                                const int2 *bins, const GRec *rec, const float *colors, const float *background,
                                const float *final_Ts, const int32_t *final_idx, const float *v_out, float *v_xy,
                                float *v_conic, float *v_colors, float *v_opacity, int gstride, int cstride,
-                               const float *colors2, int C2, const float *background2, const float *v_out2,
+                               const float *colors2, int C2, const float *background2,
+                               const float *const *v_out2_parts, const int *v_out2_channels, int num_parts,
                                float *v_colors2, int cstride2, hipStream_t s) {
     dim3 grid(gg_tile_grid(ntiles)), block(256);
     Seg2B seg2;
     seg2.colors = colors2;
     seg2.background = background2;
-    seg2.v_out = v_out2;
+    for (int k = 0; k < 3; ++k) {
+        seg2.v_out[k] = k < num_parts ? v_out2_parts[k] : v_out2_parts[0];
+        seg2.vo_w[k] = k < num_parts ? v_out2_channels[k] : 0;   // (channels >= channels2 are never read)
+    }
     seg2.v_colors = v_colors2;
     seg2.C2 = C2;
     seg2.nch2 = C2;

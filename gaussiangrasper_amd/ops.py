@@ -705,7 +705,7 @@ class RasterizeSegments(Function):
     Images are bit-identical to NDRasterizeGaussians on each array."""
 
     @staticmethod
-    def forward(ctx, xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, *segs):
+    def forward(ctx, xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, splits, *segs):
         if len(segs) < 2 or len(segs) % 2:
             raise ValueError("expected colors_0, background_0[, colors_1, background_1, ...]")
         if xys.ndimension() != 2 or xys.size(1) != 2:
@@ -756,16 +756,29 @@ class RasterizeSegments(Function):
         ctx.img = (img_height, img_width)
         ctx.opacity_shape = tuple(opacity.shape)
         ctx.nseg = len(cols_c)
+        # splits: {segment index: channel counts} — that segment's image is returned as several images (views of
+        # one buffer) and its cotangents come back separately (and are handed to the kernel as they are)
+        splits = dict(splits or {})
+        out_map = []
+        for i, c in enumerate(cols_c):
+            sizes = list(splits.get(i, [c.shape[1]]))
+            if sum(sizes) != c.shape[1] or min(sizes) < 1:
+                raise ValueError("split sizes must be positive and add up to the segment's channels")
+            start = 0
+            for sz in sizes:
+                out_map.append((i, start, start + sz))
+                start += sz
+        ctx.out_map = out_map
         if bins.num_intersects < 1:
             outs = [torch.ones(img_height, img_width, c.shape[1], device=dev) * b for c, b in zip(cols_c, bgs_c)]
             ctx.save_for_backward(xys_c, conics_c, opacity_c, *cols_c)
-            return tuple(outs)
-        ctx.save_for_backward(xys_c, conics_c, opacity_c, bins.gaussian_ids_sorted, bins.tile_bins, final_Ts,
-                              final_idx, ws, *cols_c, *bgs_c)
-        return tuple(outs)
+        else:
+            ctx.save_for_backward(xys_c, conics_c, opacity_c, bins.gaussian_ids_sorted, bins.tile_bins, final_Ts,
+                                  final_idx, ws, *cols_c, *bgs_c)
+        return tuple(outs[i] if (e - b) == outs[i].shape[2] else outs[i][..., b:e] for i, b, e in out_map)
 
     @staticmethod
-    def backward(ctx, *v_outs):
+    def backward(ctx, *v_parts):
         k = ctx.nseg
         img_height, img_width = ctx.img
         if ctx.num_intersects < 1:
@@ -775,7 +788,7 @@ class RasterizeSegments(Function):
             for c in cols:
                 grads += [torch.zeros_like(c), None]
             return (torch.zeros_like(xys), None, None, torch.zeros_like(conics), None,
-                    torch.zeros_like(opacity).reshape(ctx.opacity_shape), None, None, *grads)
+                    torch.zeros_like(opacity).reshape(ctx.opacity_shape), None, None, None, *grads)
         xys, conics, opacity, ids_sorted, tile_bins, final_Ts, final_idx, ws = ctx.saved_tensors[:8]
         cols, bgs = ctx.saved_tensors[8:8 + k], ctx.saved_tensors[8 + k:8 + 2 * k]
         dev, n = xys.device, xys.shape[0]
@@ -791,11 +804,20 @@ class RasterizeSegments(Function):
         grads = [None] * k
         first = True
 
+        def parts(i):
+            """cotangents of segment i as [(image, channels)] in channel order"""
+            out = []
+            for (seg, b, e), v in zip(ctx.out_map, v_parts):
+                if seg != i:
+                    continue
+                if v is None:
+                    v = torch.zeros(img_height, img_width, e - b, dtype=torch.float32, device=dev)
+                out.append((_f32(v), e - b))
+            return out
+
         def cotangent(i):
-            v = v_outs[i]
-            if v is None:
-                v = torch.zeros(img_height, img_width, cols[i].shape[1], dtype=torch.float32, device=dev)
-            return _f32(v)
+            p = parts(i)
+            return p[0][0] if len(p) == 1 else torch.cat([v for v, _ in p], dim=-1)
 
         # a >= 32-channel array carries the rider through its first backward walk (gg_blend_bwd_pair): one
         # walk computes alpha, T and the geometry gradients of both arrays
@@ -808,13 +830,17 @@ class RasterizeSegments(Function):
                 flags |= 2
             else:
                 v_colors = torch.empty(n, cols[wide].shape[1], dtype=torch.float32, device=dev)
-            vo_w, vo_r = cotangent(wide), cotangent(rider)
+            vo_w, rp = cotangent(wide), parts(rider)
+            if len(rp) > 3:
+                rp = [(cotangent(rider), cols[rider].shape[1])]
+            part_ptrs = (C.c_void_p * len(rp))(*[_ptr(v) for v, _ in rp])
+            part_chs = (C.c_int * len(rp))(*[c for _, c in rp])
             _lib.check(lib.gg_blend_bwd_pair(
                 cols[wide].shape[1], cols[rider].shape[1], n, img_height, img_width, _ptr(ids_sorted),
                 _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(cols[wide]), _ptr(cols[rider]), _ptr(opacity),
-                _ptr(bgs[wide]), _ptr(bgs[rider]), _ptr(final_Ts), _ptr(final_idx), _ptr(vo_w), _ptr(vo_r),
-                _ptr(v_xy), _ptr(v_conic), _ptr(v_colors), _ptr(rec_g[:, 6:]), _ptr(v_opacity), gstride, 0, gstride,
-                _ptr(ws), ws.numel(), flags, _stream(dev)), "gg_blend_bwd_pair")
+                _ptr(bgs[wide]), _ptr(bgs[rider]), _ptr(final_Ts), _ptr(final_idx), _ptr(vo_w), part_ptrs,
+                part_chs, len(rp), _ptr(v_xy), _ptr(v_conic), _ptr(v_colors), _ptr(rec_g[:, 6:]), _ptr(v_opacity),
+                gstride, 0, gstride, _ptr(ws), ws.numel(), flags, _stream(dev)), "gg_blend_bwd_pair")
             grads[rider] = rec_g[:, 6:]
             if flags & 2:
                 if sink[2] is not None:
@@ -847,16 +873,20 @@ class RasterizeSegments(Function):
         seg_grads = []
         for g in grads:
             seg_grads += [g, None]
-        return (v_xy, None, None, v_conic, None, v_opacity.reshape(ctx.opacity_shape), None, None, *seg_grads)
+        return (v_xy, None, None, v_conic, None, v_opacity.reshape(ctx.opacity_shape), None, None, None, *seg_grads)
 
 
 def rasterize_segments(xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, segments):
-    """segments: sequence of (colors (N, C_k), background (C_k,)) -> list of images (H, W, C_k)."""
-    flat = []
-    for c, b in segments:
-        flat += [c, b]
+    """segments: sequence of (colors (N, C_k), background (C_k,)[, split sizes]) -> list of images (H, W, C_k);
+    a segment given with split sizes (e.g. [3, 1, 3] for rgb | depth | normal) comes back as that many images
+    (views of one buffer, channel-sliced), and their cotangents go to the backward kernel without a concatenation."""
+    flat, splits = [], {}
+    for i, seg in enumerate(segments):
+        flat += [seg[0], seg[1]]
+        if len(seg) > 2 and seg[2] is not None:
+            splits[i] = tuple(int(x) for x in seg[2])
     return list(RasterizeSegments.apply(xys, depths, radii, conics, num_tiles_hit, opacity, img_height,
-                                        img_width, *flat))
+                                        img_width, tuple(sorted(splits.items())), *flat))
 
 
 # ------------------------------------------------------------------------------------------------

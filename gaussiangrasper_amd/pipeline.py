@@ -86,6 +86,26 @@ def rasterize_activated(act: Dict, view: ViewParams, ops, sh_degree_to_use: int 
     return out
 
 
+_CONSTANTS: Dict = {}
+
+
+def _zeros(d: int, dev) -> torch.Tensor:
+    """Cached constant backgrounds (read-only): no fill kernel per view."""
+    key = ("zeros", d, str(dev))
+    if key not in _CONSTANTS:
+        _CONSTANTS[key] = torch.zeros(d, device=dev)
+    return _CONSTANTS[key]
+
+
+def _tail_background(dev) -> torch.Tensor:
+    key = ("tail", str(dev))
+    if key not in _CONSTANTS:
+        bg = torch.zeros(7, device=dev)
+        bg[3] = 10.0                      # depth background (reference :769)
+        _CONSTANTS[key] = bg
+    return _CONSTANTS[key]
+
+
 def fused_images(ops, xys, depths, radii, conics, num_tiles_hit, opac, h, w, feature, rgbs, normals, tail=None):
     """feature (D) | rgb (3) | depth (1, background 10) | normal (3) images from one binning.
     With `ops.rasterize_segments` (the product) the feature array and the 7-channel rgb|depth|normal array
@@ -97,11 +117,10 @@ def fused_images(ops, xys, depths, radii, conics, num_tiles_hit, opac, h, w, fea
     if hasattr(ops, "rasterize_segments"):
         if tail is None:
             tail = torch.cat([rgbs, depths[:, None], normals], dim=1)
-        bg_tail = torch.zeros(7, device=dev)
-        bg_tail[3] = 10.0
-        feat_im, tail_im = ops.rasterize_segments(xys, depths, radii, conics, num_tiles_hit, opac, h, w,
-                                                  [(feature, torch.zeros(d, device=dev)), (tail, bg_tail)])
-        rgb, depth, normal = torch.split(tail_im, [3, 1, 3], dim=-1)
+        bg_tail = _tail_background(dev)
+        feat_im, rgb, depth, normal = ops.rasterize_segments(
+            xys, depths, radii, conics, num_tiles_hit, opac, h, w,
+            [(feature, _zeros(d, dev)), (tail, bg_tail, (3, 1, 3))])
         return feat_im, rgb, depth, normal
     colors = torch.cat([feature, rgbs, depths[:, None], normals], dim=1)
     background = torch.zeros(d + 7, device=dev)

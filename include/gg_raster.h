@@ -224,12 +224,16 @@ int gg_blend_bwd(int channels, int num_points, int img_height, int img_width,
  * the geometry gradients of BOTH arrays (what autograd would sum over two gg_blend_bwd calls); v_colors /
  * v_colors2 the colour gradients, rows color_stride / color_stride2 floats apart (0 = dense).  geom_stride as
  * in gg_blend_bwd; v_colors2 = v_xy + 6 with color_stride2 = geom_stride puts the second array's gradients
- * into the interleaved record.  flags: GG_BWD_WS_FROM_FORWARD, GG_BWD_ACCUMULATE_COLORS (for v_colors). */
+ * into the interleaved record.  The second cotangent (H, W, channels2) is handed over as num_parts (1..3) images
+ * of v_out_img2_channels[k] consecutive channels each (host arrays) — the caller's rgb | depth | normal cotangents
+ * are read where they are, not concatenated first.
+ * flags: GG_BWD_WS_FROM_FORWARD, GG_BWD_ACCUMULATE_COLORS (for v_colors). */
 int gg_blend_bwd_pair(int channels, int channels2, int num_points, int img_height, int img_width,
                       const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                       const float *conics, const float *colors, const float *colors2, const float *opacity,
                       const float *background, const float *background2, const float *final_Ts,
-                      const int32_t *final_idx, const float *v_out_img, const float *v_out_img2, float *v_xy,
+                      const int32_t *final_idx, const float *v_out_img, const float *const *v_out_img2_parts,
+                      const int *v_out_img2_channels, int num_parts, float *v_xy,
                       float *v_conic, float *v_colors, float *v_colors2, float *v_opacity, int geom_stride,
                       int color_stride, int color_stride2, void *ws, size_t ws_bytes, int flags,
                       gg_stream_t stream);

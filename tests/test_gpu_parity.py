@@ -1040,3 +1040,45 @@ def test_backward_kernels_read_record_columns_in_place_and_add_into_sinks(oracle
         assert_bitexact(b, a, f"{name}: record columns read in place vs dense cotangents")
     for name, a, b in zip(("means", "scales", "quats", "opacities"), dense, run(True, True)):
         assert_bitexact(b, (np.float32(0.25) + a).astype(np.float32), f"{name}: gradient sink = prior + gradient")
+
+
+@pytest.mark.gpu
+def test_split_segment_returns_channel_slices_and_takes_separate_cotangents(oracle):
+    """rasterize_segments with a segment given as (colors, background, (3, 1, 3)): the images are the channel
+    slices of the unsplit image, bit for bit, and the backward with three separate cotangents (handed to
+    gg_blend_bwd_pair as three images) matches the backward of the concatenated cotangent within the blend
+    tolerance — also when one of the cotangents is missing (None -> zeros)."""
+    n, h, w = 20000, 150, 200
+    xys, depths, radii, conics, nth, colors, opac, bg = _blend_inputs(oracle, n, h, w, 39, seed=12)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    rng = np.random.default_rng(2)
+    vf = t(rng.standard_normal((h, w, 32)).astype(np.float32))
+    vt = t(rng.standard_normal((h, w, 7)).astype(np.float32))
+
+    def run(split, drop_depth=False):
+        xt, ct, ot = t(xys).requires_grad_(True), t(conics).requires_grad_(True), t(opac).requires_grad_(True)
+        f, tl = t(colors[:, :32]).requires_grad_(True), t(colors[:, 32:]).requires_grad_(True)
+        P.clear_bin_cache()
+        seg = (tl, t(bg[32:]), (3, 1, 3)) if split else (tl, t(bg[32:]))
+        imgs = P.rasterize_segments(xt, t(depths), t(radii), ct, t(nth), ot, h, w, [(f, t(bg[:32])), seg])
+        if split:
+            outs, cots = [imgs[0], imgs[1], imgs[3]], [vf, vt[..., 0:3].contiguous(), vt[..., 4:7].contiguous()]
+            if not drop_depth:
+                outs.append(imgs[2])
+                cots.append(vt[..., 3:4].contiguous())
+            torch.autograd.backward(outs, cots)
+        else:
+            v = vt.clone()
+            if drop_depth:
+                v[..., 3] = 0
+            torch.autograd.backward(imgs, [vf, v])
+        return imgs, [_np(g) for g in (xt.grad, ct.grad, ot.grad, f.grad, tl.grad)]
+
+    for drop in (False, True):
+        whole, g_whole = run(False, drop)
+        parts, g_parts = run(True, drop)
+        assert_bitexact(_np(parts[0]), _np(whole[0]), "feature image")
+        for img, (b, e) in zip(parts[1:], ((0, 3), (3, 4), (4, 7))):
+            assert_bitexact(_np(img), _np(whole[1])[..., b:e], f"tail image channels {b}:{e}")
+        for name, a, b in zip(("v_xy", "v_conic", "v_opacity", "v_feature", "v_tail"), g_parts, g_whole):
+            assert_close(a, b, f"split cotangents vs concatenated: {name}", rtol=5e-5, atol_frac=1e-6)

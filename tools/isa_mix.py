@@ -21,7 +21,8 @@ KERNELS = {  # bench.py name -> mangled-name fragment
     "blend_fwd_pair_kernel<40>": "blend2_fwd_kernelILi32ELb1ELb1ELb1E",
     "blend_bwd_kernel<3>": "blend2_bwd_narrow_kernelILi3ELi0ELb0E",
     "blend_bwd_kernel<8>": "blend2_bwd_narrow_kernelILi8ELi0ELb0E",
-    "blend_bwd_kernel<32>": "blend2_bwd_wide_kernelILb1ELi0ELi32ELb0E",
+    "blend_bwd_kernel<32>": "blend2_bwd_wide_kernelILb1ELi0ELi32ELb0ELb0E",
+    "blend_bwd_pair_kernel<40>": "blend2_bwd_wide_kernelILb1ELi0ELi32ELb0ELb1E",
 }
 TRANS = ("v_rcp_", "v_exp_", "v_log_", "v_sqrt_", "v_rsq_", "v_sin_", "v_cos_")
 

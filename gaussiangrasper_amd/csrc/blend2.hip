@@ -647,7 +647,16 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
 
     // one batch: queue entries [base, base + n), n <= 32 (n < 32 only for the last batch of the walk, which
     // is followed by null records up to a multiple of GRP)
-    auto run_batch = [&](const int base, const int n) {
+    // records of the NEXT chunk, requested between a batch's walk and its flush: the vector memory counter is
+    // in order, so loads issued behind the flush's 24-32 atomic instructions wait for every one of them
+    float4 ra_p = make_float4(0.f, 0.f, 0.f, 0.f), rb_p = ra_p;
+    int g_nxt = 0;
+    auto run_batch = [&](const int base, const int n, const bool fetch_next) {
+        // (no old value of the prefetch registers to carry through the walk)
+        ra_p.x = __builtin_nondeterministic_value(ra_p.x); ra_p.y = __builtin_nondeterministic_value(ra_p.y);
+        ra_p.z = __builtin_nondeterministic_value(ra_p.z); ra_p.w = __builtin_nondeterministic_value(ra_p.w);
+        rb_p.x = __builtin_nondeterministic_value(rb_p.x); rb_p.y = __builtin_nondeterministic_value(rb_p.y);
+        rb_p.z = __builtin_nondeterministic_value(rb_p.z); rb_p.w = __builtin_nondeterministic_value(rb_p.w);
         if (ABL >= 6) { KEEP(n); return; }   // staging + queue only
         const int jl = lane & 31;
         const int cgid = (jl < n) ? __builtin_bit_cast(int, Q.b[base + jl].w) : -1;
@@ -772,6 +781,10 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
             }
             if (owner && my_gid >= 0 && mine != 0.0f) atomicAdd(my_base + (size_t)my_gid * my_stride, mine);
         }
+        if (fetch_next) {
+            ra_p = reinterpret_cast<const float4 *>(rec + g_nxt)[0];
+            rb_p = reinterpret_cast<const float4 *>(rec + g_nxt)[1];
+        }
         // flush: FAC[32 slots x 64 pixels] * V_OUT[64 x 32 channels]; rows outside slotmask still hold D and
         // are not written
         slotmask = __builtin_amdgcn_readfirstlane(slotmask);
@@ -833,13 +846,26 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
         const int e_ = top_ - 64 + lane;
         return (top_ > range.x && e_ >= range.x) ? ids[e_] : 0;
     };
-    int g_nxt = load_id(hi);
+    g_nxt = load_id(hi);
+    bool have_p = false;   // wave-uniform: ra_p / rb_p hold this chunk's records
     for (int top = hi; top > range.x; top -= 64) {
         const int e = top - 64 + lane;
         const bool valid = e >= range.x;
         const int g = g_nxt;
-        const float4 ra = reinterpret_cast<const float4 *>(rec + g)[0];
-        const float4 rb = reinterpret_cast<const float4 *>(rec + g)[1];
+        float4 ra, rb;
+        if (have_p) {
+            ra = ra_p;
+            rb = rb_p;
+        } else {
+            ra = reinterpret_cast<const float4 *>(rec + g)[0];
+            rb = reinterpret_cast<const float4 *>(rec + g)[1];
+        }
+        have_p = false;
+        // the prefetch registers are dead until the next request (no old value to carry through the walk)
+        ra_p.x = __builtin_nondeterministic_value(ra_p.x); ra_p.y = __builtin_nondeterministic_value(ra_p.y);
+        ra_p.z = __builtin_nondeterministic_value(ra_p.z); ra_p.w = __builtin_nondeterministic_value(ra_p.w);
+        rb_p.x = __builtin_nondeterministic_value(rb_p.x); rb_p.y = __builtin_nondeterministic_value(rb_p.y);
+        rb_p.z = __builtin_nondeterministic_value(rb_p.z); rb_p.w = __builtin_nondeterministic_value(rb_p.w);
         g_nxt = load_id(top - 64);
         const bool hit = valid && rec_hits_rect(ra, rb, xlo, xhi, ylo, yhi);
         const uint64_t m = __ballot(hit);
@@ -854,7 +880,10 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
         int done = 0;
         while (qn - done >= 28) {   // 28 or 32 (a multiple of GRP): at most 27 stay behind, BQ_CAP
             const int nb = min(32, (qn - done) & ~3);
-            run_batch(done, nb);
+            // (not in the pair build: 8 more registers across its two flushes spill 30 more, 1.30 -> 1.33 ms)
+            const bool last = !EX && (qn - done - nb < 28) && (top - 64 > range.x);   // staging comes next
+            run_batch(done, nb, last);
+            have_p = last;
             done += nb;
         }
         if (done > 0) {   // bring the left-over (< 28) to the front; source and destination do not overlap
@@ -873,7 +902,7 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
             Q.b[qn + lane] = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, -1));
         }
         __builtin_amdgcn_wave_barrier();
-        run_batch(0, qn);
+        run_batch(0, qn, false);
     }
 }
 

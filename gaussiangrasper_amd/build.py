@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libgg_raster.so")
-SOURCES = ["project.hip", "binning.hip", "blend.hip", "blend2.hip", "mlp.hip", "losses.hip", "densify.hip", "prof.hip"]
+SOURCES = ["project.hip", "binning.hip", "blend.hip", "blend2.hip", "mlp.hip", "losses.hip", "imgloss.hip", "densify.hip", "prof.hip"]
 # -fno-slp-vectorize: hipcc's SLP pass packs adjacent scalar fp32 operations into v_pk_*_f32 (15 % of the
 # blend loops' VALU instructions); on gfx950 a packed fp32 instruction is not cheaper than its two halves
 # (MI355X_MICROARCH.md "packed f32 VALU ... an anti-lever") and the packing costs 8-12 VGPRs per kernel, i.e.

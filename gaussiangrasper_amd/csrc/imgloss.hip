@@ -1,0 +1,293 @@
+// imgloss.hip — the image-space main loss of get_loss_dict (SURVEY 8f-4 tail), forward and backward:
+//
+//     Ll1 = torch.abs(gt_img[valid_mask, :] - outputs["rgb"][valid_mask, :]).mean()        (gaussian_splatting.py:882)
+//     gt_img[~valid_mask, :] = 0.0;  outputs["rgb"][~valid_mask, :] = 0.0                    (:883-884)
+//     simloss = 1 - self.ssim(gt_img ..., outputs["rgb"] ...)                                (:885; SSIM :284)
+//     main_loss = (1 - ssim_lambda) * Ll1 + ssim_lambda * simloss                            (:931)
+//
+// self.ssim is pytorch_msssim.SSIM(data_range=1.0, size_average=True, channel=3): Gaussian window of 11 taps,
+// sigma 1.5, `valid` separable filtering of X, Y, X^2, Y^2, XY.  In torch that is ten grouped conv2d launches over
+// five 3 x H x W images forward and as many again backward, each through HBM; here the forward is ONE pass over the
+// two images (16x16 output tiles, the 26x26 input windows and the row-filtered moments in LDS) that also leaves the
+// three partial-derivative maps of the SSIM (d/d mu_rgb, d/d E[rgb^2], d/d E[gt rgb]) for the backward, and the
+// backward is ONE pass that filters those maps back (transposed filter = the same symmetric window, zero outside)
+// and adds the L1 sign term.  HBM-bound stencil: 24 B/pixel read + 36 B/pixel of maps written (forward), 36 + 24
+// read + 12 written (backward); no atomics — per-workgroup partial sums, summed in a fixed order by one workgroup.
+//
+// The arithmetic follows oracle/gg_oracle.c:image_loss_* operation for operation (filter rows first, then columns;
+// -ffp-contract=off), so the maps and the gradient image are bit-identical to the oracle; the two scalar sums are
+// double sums in a different order and agree to 1e-7.
+#include "gg_common.h"
+
+#define IL_WIN 11
+#define IL_T 16                  // tile edge
+#define IL_IN (IL_T + IL_WIN - 1)  // 26: input window edge
+
+struct IlWindow {
+    float w[IL_WIN];
+};
+
+// header of the workspace (doubles): [0] sum of ssim over channels and positions, [1] sum |gt - rgb| over valid
+// pixels x 3, [2] number of valid pixels x 3; then per-workgroup partials (3 doubles each); then the maps
+#define IL_HEADER 8
+
+__device__ __forceinline__ float il_ssim_point(const float *m, float &g_b, float &g_yy, float &g_xy) {
+    const float C1 = (float)(0.01 * 0.01), C2 = (float)(0.03 * 0.03);
+    const float a = m[0], b = m[1];
+    const float s1 = m[2] - a * a, s2 = m[3] - b * b, s12 = m[4] - a * b;
+    const float ln = 2 * a * b + C1, ld = a * a + b * b + C1, cn = 2 * s12 + C2, cd = s1 + s2 + C2;
+    const float L = ln / ld, CS = cn / cd;
+    const float dL_db = (2 * a * ld - ln * 2 * b) / (ld * ld);
+    const float dCS_ds2 = -cn / (cd * cd), dCS_ds12 = 2 / cd;
+    g_b = CS * dL_db + L * (dCS_ds2 * (-2 * b) + dCS_ds12 * (-a));
+    g_yy = L * dCS_ds2;
+    g_xy = L * dCS_ds12;
+    return L * CS;
+}
+
+__global__ __launch_bounds__(256) void image_loss_fwd_kernel(int H, int W, const float *__restrict__ rgb,
+                                                             const float *__restrict__ gt,
+                                                             const uint8_t *__restrict__ valid, IlWindow win,
+                                                             double *__restrict__ partials,
+                                                             float *__restrict__ maps) {
+    __shared__ float sx[3][IL_IN][IL_IN + 1], sy[3][IL_IN][IL_IN + 1];     // gt, rgb (masked)
+    __shared__ float hb[5][3][IL_IN][IL_T + 1];                            // row-filtered moments
+    __shared__ double red[3][4];
+    const int Ho = H - IL_WIN + 1, Wo = W - IL_WIN + 1;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int x0 = blockIdx.x * IL_T, y0 = blockIdx.y * IL_T;
+    for (int idx = tid; idx < IL_IN * IL_IN; idx += 256) {
+        const int r = idx / IL_IN, c = idx - r * IL_IN;
+        const int y = y0 + r, x = x0 + c;
+        float vx[3] = {0.f, 0.f, 0.f}, vy[3] = {0.f, 0.f, 0.f};
+        if (y < H && x < W) {
+            const size_t p = (size_t)y * W + x;
+            if (!valid || valid[p]) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) { vx[ch] = gt[3 * p + ch]; vy[ch] = rgb[3 * p + ch]; }
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) { sx[ch][r][c] = vx[ch]; sy[ch][r][c] = vy[ch]; }
+    }
+    // L1 over this tile's own 16 x 16 input pixels (the masked images are zero where invalid, but so is the
+    // difference only if both are masked: count validity explicitly)
+    double l1 = 0.0, cnt = 0.0;
+    {
+        const int y = y0 + ty, x = x0 + tx;
+        if (y < H && x < W) {
+            const size_t p = (size_t)y * W + x;
+            if (!valid || valid[p]) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) l1 += (double)fabsf(gt[3 * p + ch] - rgb[3 * p + ch]);
+                cnt = 3.0;
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 3 * IL_IN * IL_T; idx += 256) {
+        const int ch = idx / (IL_IN * IL_T), rem = idx - ch * (IL_IN * IL_T);
+        const int r = rem / IL_T, c = rem - r * IL_T;
+        float rx = 0.f, ry = 0.f, rxx = 0.f, ryy = 0.f, rxy = 0.f;
+#pragma unroll
+        for (int b = 0; b < IL_WIN; ++b) {
+            const float x = sx[ch][r][c + b], y = sy[ch][r][c + b], w = win.w[b];
+            rx += w * x; ry += w * y; rxx += w * (x * x); ryy += w * (y * y); rxy += w * (x * y);
+        }
+        hb[0][ch][r][c] = rx; hb[1][ch][r][c] = ry; hb[2][ch][r][c] = rxx; hb[3][ch][r][c] = ryy;
+        hb[4][ch][r][c] = rxy;
+    }
+    __syncthreads();
+    double ss = 0.0;
+    const int i = y0 + ty, j = x0 + tx;
+    if (i < Ho && j < Wo) {
+        const size_t plane = (size_t)Ho * Wo, o = (size_t)i * Wo + j;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < IL_WIN; ++a) {
+                const float w = win.w[a];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) m[q] += w * hb[q][ch][ty + a][tx];
+            }
+            float gb, gyy, gxy;
+            ss += (double)il_ssim_point(m, gb, gyy, gxy);
+            maps[(3 * ch + 0) * plane + o] = gb;
+            maps[(3 * ch + 1) * plane + o] = gyy;
+            maps[(3 * ch + 2) * plane + o] = gxy;
+        }
+    }
+    // workgroup sums, fixed order: lanes of a wave by shuffle, the four waves through LDS
+    double v[3] = {ss, l1, cnt};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) red[k][tid >> 6] = v[k];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) partials[3 * blk + k] = ((red[k][0] + red[k][1]) + red[k][2]) + red[k][3];
+    }
+}
+
+// one workgroup: the partials in index order -> header sums and the three scalars
+__global__ __launch_bounds__(256) void image_loss_finish_kernel(int nblocks, int Ho, int Wo, float ssim_lambda,
+                                                                const double *__restrict__ partials,
+                                                                double *__restrict__ header,
+                                                                float *__restrict__ out3) {
+    __shared__ double red[3][256];
+    const int tid = threadIdx.x;
+    double v[3] = {0.0, 0.0, 0.0};
+    for (int b = tid; b < nblocks; b += 256)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] += partials[3 * (size_t)b + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) red[k][tid] = v[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) red[k][tid] += red[k][tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        header[0] = red[0][0];
+        header[1] = red[1][0];
+        header[2] = red[2][0];
+        const float Ll1 = (float)(red[1][0] / red[2][0]);
+        const float ssim = (float)(red[0][0] / (3.0 * Ho * Wo));
+        out3[0] = (1 - ssim_lambda) * Ll1 + ssim_lambda * (1 - ssim);
+        out3[1] = Ll1;
+        out3[2] = ssim;
+    }
+}
+
+__global__ __launch_bounds__(256) void image_loss_bwd_kernel(int H, int W, const float *__restrict__ rgb,
+                                                             const float *__restrict__ gt,
+                                                             const uint8_t *__restrict__ valid, IlWindow win,
+                                                             float ssim_lambda, const float *__restrict__ v_main,
+                                                             const double *__restrict__ header,
+                                                             const float *__restrict__ maps,
+                                                             float *__restrict__ v_rgb) {
+    __shared__ float sg[9][IL_IN][IL_IN + 1];          // the maps around the tile (zero outside their domain)
+    __shared__ float hb[9][IL_IN][IL_T + 1];
+    const int Ho = H - IL_WIN + 1, Wo = W - IL_WIN + 1;
+    const size_t plane = (size_t)Ho * Wo;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int x0 = blockIdx.x * IL_T, y0 = blockIdx.y * IL_T;
+    // pixel (y, x) gathers the outputs (y - a, x - b), a, b in 0..10: window origin (y0 - 10, x0 - 10)
+    for (int idx = tid; idx < IL_IN * IL_IN; idx += 256) {
+        const int r = idx / IL_IN, c = idx - r * IL_IN;
+        const int i = y0 - (IL_WIN - 1) + r, j = x0 - (IL_WIN - 1) + c;
+        const bool in = i >= 0 && i < Ho && j >= 0 && j < Wo;
+        const size_t o = in ? (size_t)i * Wo + j : 0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) sg[q][r][c] = in ? maps[q * plane + o] : 0.0f;
+    }
+    __syncthreads();
+    // rows: h[r][tx] = sum_b w[b] g[r][x - b]  (window column of x - b: tx + 10 - b)
+    for (int idx = tid; idx < 9 * IL_IN * IL_T; idx += 256) {
+        const int q = idx / (IL_IN * IL_T), rem = idx - q * (IL_IN * IL_T);
+        const int r = rem / IL_T, c = rem - r * IL_T;
+        float acc = 0.f;
+#pragma unroll
+        for (int b = 0; b < IL_WIN; ++b) {
+            const int j = x0 + c - b;                       // outputs outside their domain are skipped by the
+            if (j >= 0 && j < Wo) acc += win.w[b] * sg[q][r][c + (IL_WIN - 1) - b];   // oracle, not added as zeros
+        }
+        hb[q][r][c] = acc;
+    }
+    __syncthreads();
+    const int y = y0 + ty, x = x0 + tx;
+    if (y >= H || x >= W) return;
+    const size_t p = (size_t)y * W + x;
+    const bool ok = !valid || valid[p];
+    const float vm = v_main[0];
+    const float ks = -ssim_lambda * vm / (float)(3.0 * Ho * Wo);
+    const float kl = (1 - ssim_lambda) * vm / (float)header[2];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        if (!ok) { v_rgb[3 * p + ch] = 0.0f; continue; }
+        float G[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < IL_WIN; ++a) {
+            const int i = y - a;
+            if (i < 0 || i >= Ho) continue;
+            const float w = win.w[a];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) G[k] += w * hb[3 * ch + k][ty + (IL_WIN - 1) - a][tx];
+        }
+        const float Y = rgb[3 * p + ch], X = gt[3 * p + ch];
+        const float d = Y - X;
+        const float sgn = d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.0f);
+        v_rgb[3 * p + ch] = ks * (G[0] + 2 * Y * G[1] + X * G[2]) + kl * sgn;
+    }
+}
+
+static IlWindow il_window() {
+    IlWindow win;
+    float sum = 0.f;
+    for (int k = 0; k < IL_WIN; ++k) {
+        const float c = (float)(k - IL_WIN / 2);
+        win.w[k] = (float)exp(-(double)(c * c) / (2.0 * 1.5 * 1.5));
+        sum += win.w[k];
+    }
+    for (int k = 0; k < IL_WIN; ++k) win.w[k] /= sum;
+    return win;
+}
+static size_t il_blocks(int H, int W) {
+    return (size_t)((H + IL_T - 1) / IL_T) * (size_t)((W + IL_T - 1) / IL_T);
+}
+
+extern "C" size_t gg_image_loss_workspace(int img_height, int img_width) {
+    if (img_height < IL_WIN || img_width < IL_WIN) return 0;
+    const size_t Ho = (size_t)(img_height - IL_WIN + 1), Wo = (size_t)(img_width - IL_WIN + 1);
+    return gg_align_up(sizeof(double) * (IL_HEADER + 3 * il_blocks(img_height, img_width)), 256) +
+           gg_align_up(sizeof(float) * 9 * Ho * Wo, 256);
+}
+
+extern "C" int gg_image_loss_fwd(int H, int W, const float *rgb, const float *gt, const uint8_t *valid,
+                                 float ssim_lambda, float *out3, void *ws, size_t ws_bytes, gg_stream_t stream) {
+    GG_REQUIRE(H >= IL_WIN && W >= IL_WIN, "image smaller than the 11 x 11 SSIM window");
+    GG_REQUIRE(rgb && gt && out3, "null pointer");
+    if (ws == nullptr || ws_bytes < gg_image_loss_workspace(H, W)) {
+        gg_set_error("gg_image_loss_fwd: workspace too small");
+        return GG_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    double *header = (double *)ws;
+    double *partials = header + IL_HEADER;
+    const size_t nblk = il_blocks(H, W);
+    float *maps = (float *)((char *)ws + gg_align_up(sizeof(double) * (IL_HEADER + 3 * nblk), 256));
+    const dim3 grid((W + IL_T - 1) / IL_T, (H + IL_T - 1) / IL_T);
+    hipLaunchKernelGGL(image_loss_fwd_kernel, grid, dim3(256), 0, s, H, W, rgb, gt, valid, il_window(), partials,
+                       maps);
+    hipLaunchKernelGGL(image_loss_finish_kernel, dim3(1), dim3(256), 0, s, (int)nblk, H - IL_WIN + 1,
+                       W - IL_WIN + 1, ssim_lambda, partials, header, out3);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+extern "C" int gg_image_loss_bwd(int H, int W, const float *rgb, const float *gt, const uint8_t *valid,
+                                 float ssim_lambda, const float *v_main, const void *ws, size_t ws_bytes,
+                                 float *v_rgb, gg_stream_t stream) {
+    GG_REQUIRE(H >= IL_WIN && W >= IL_WIN, "image smaller than the 11 x 11 SSIM window");
+    GG_REQUIRE(rgb && gt && v_main && v_rgb, "null pointer");
+    if (ws == nullptr || ws_bytes < gg_image_loss_workspace(H, W)) {
+        gg_set_error("gg_image_loss_bwd: workspace too small (it must be the forward's)");
+        return GG_ERR_WORKSPACE;
+    }
+    const double *header = (const double *)ws;
+    const size_t nblk = il_blocks(H, W);
+    const float *maps = (const float *)((const char *)ws + gg_align_up(sizeof(double) * (IL_HEADER + 3 * nblk), 256));
+    const dim3 grid((W + IL_T - 1) / IL_T, (H + IL_T - 1) / IL_T);
+    hipLaunchKernelGGL(image_loss_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, rgb, gt, valid,
+                       il_window(), ssim_lambda, v_main, header, maps, v_rgb);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}

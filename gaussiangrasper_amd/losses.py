@@ -1,4 +1,7 @@
-"""Cosine-similarity loss of the feature field: host-side mirror of the reference's
+"""Losses of the reference's get_loss_dict on the HIP kernels: the cosine-similarity loss of the feature field
+(below) and the image-space main loss (L1 + SSIM, `main_loss` at the end of the file).
+
+Cosine-similarity loss: host-side mirror of the reference's
 `cosine_similarity_loss(embeddings1, embeddings2)` (nerfstudio/models/gaussian_splatting.py:113-118):
 
     e1 = F.normalize(embeddings1, dim=0); e2 = F.normalize(embeddings2, dim=0)
@@ -50,3 +53,57 @@ class _CosineLoss(Function):
 def cosine_similarity_loss(embeddings1: Tensor, embeddings2: Tensor) -> Tensor:
     """Drop-in for the reference function: embeddings (C, M), normalised along dim 0."""
     return _CosineLoss.apply(embeddings1.permute(1, 0), embeddings2.permute(1, 0))
+
+
+# ------------------------------------------------------------------------------------------------
+# image-space main loss: (1 - lambda) L1 + lambda (1 - SSIM)   (SURVEY.md §8f-4 tail)
+# ------------------------------------------------------------------------------------------------
+class _MainLoss(Function):
+    @staticmethod
+    def forward(ctx, rgb: Tensor, gt: Tensor, valid, ssim_lambda: float):
+        dev = _require_hip(rgb, gt)
+        if rgb.dim() != 3 or rgb.shape[2] != 3 or gt.shape != rgb.shape:
+            raise ValueError(f"rgb and gt must be (H, W, 3), got {tuple(rgb.shape)} and {tuple(gt.shape)}")
+        h, w = rgb.shape[:2]
+        if h < 11 or w < 11:
+            raise ValueError("image smaller than the 11 x 11 SSIM window")
+        r, g = _f32(rgb), _f32(gt)
+        if valid is not None:
+            if tuple(valid.shape) != (h, w):
+                raise ValueError("valid_mask must be (H, W)")
+            valid = valid.to(device=dev, dtype=torch.uint8).contiguous()
+        lib = _lib.load()
+        ws = torch.empty(lib.gg_image_loss_workspace(h, w), dtype=torch.uint8, device=dev)
+        out3 = torch.empty(3, dtype=torch.float32, device=dev)
+        _lib.check(lib.gg_image_loss_fwd(h, w, _ptr(r), _ptr(g), _ptr(valid) if valid is not None else None,
+                                         float(ssim_lambda), _ptr(out3), _ptr(ws), ws.numel(), _stream(dev)),
+                   "gg_image_loss_fwd")
+        ctx.save_for_backward(r, g, ws) if valid is None else ctx.save_for_backward(r, g, ws, valid)
+        ctx.ssim_lambda = float(ssim_lambda)
+        main, l1, ssim = out3[0], out3[1], out3[2]
+        ctx.mark_non_differentiable(l1, ssim)
+        return main, l1, ssim
+
+    @staticmethod
+    def backward(ctx, v_main, _v_l1, _v_ssim):
+        saved = ctx.saved_tensors
+        r, g, ws = saved[:3]
+        valid = saved[3] if len(saved) > 3 else None
+        dev = r.device
+        h, w = r.shape[:2]
+        v_rgb = torch.empty_like(r)
+        vm = _f32(v_main).reshape(1)
+        _lib.check(_lib.load().gg_image_loss_bwd(h, w, _ptr(r), _ptr(g), _ptr(valid) if valid is not None else None,
+                                                 ctx.ssim_lambda, _ptr(vm), _ptr(ws), ws.numel(), _ptr(v_rgb),
+                                                 _stream(dev)), "gg_image_loss_bwd")
+        return v_rgb, None, None, None
+
+
+def main_loss(rgb: Tensor, gt_img: Tensor, valid_mask=None, ssim_lambda: float = 0.2):
+    """The reference's `main_loss` (nerfstudio/models/gaussian_splatting.py:882-885, :931) in one forward and one
+    backward pass: returns (main_loss, Ll1, ssim) with
+        Ll1 = |gt_img[valid_mask] - rgb[valid_mask]|.mean(),  ssim = SSIM(gt_img, rgb) on the images zeroed where
+        invalid,  main_loss = (1 - ssim_lambda) Ll1 + ssim_lambda (1 - ssim);
+    only main_loss carries a gradient (to rgb).  Unlike the reference it does not modify `gt_img` / `rgb` in place
+    (the reference zeroes both at the invalid pixels as a side effect of computing the loss)."""
+    return _MainLoss.apply(rgb, gt_img, valid_mask, ssim_lambda)

@@ -579,6 +579,143 @@ void NAME(shade_tail_bwd)(int N, int K, int degrees_to_use, const REAL *viewdirs
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Image-space main loss (SURVEY 8f-4 tail) — get_loss_dict, gaussian_splatting.py:882-885, :931:
+ *     Ll1 = torch.abs(gt_img[valid_mask, :] - outputs["rgb"][valid_mask, :]).mean()
+ *     gt_img[~valid_mask, :] = 0.0;  outputs["rgb"][~valid_mask, :] = 0.0
+ *     simloss = 1 - self.ssim(gt_img ..., outputs["rgb"] ...)
+ *     main_loss = (1 - ssim_lambda) * Ll1 + ssim_lambda * simloss
+ * with self.ssim = pytorch_msssim.SSIM(data_range=1.0, size_average=True, channel=3) (:284).  pytorch-msssim
+ * (requirements.txt:199, ==1.0.0) is NOT in the tree and not installed: its published algorithm is restated —
+ * 1-D Gaussian window of 11 taps, sigma 1.5, normalised; `valid` separable filtering of X, Y, X^2, Y^2, XY;
+ * K1 = 0.01, K2 = 0.03; ssim_map = (2 mu1 mu2 + C1)/(mu1^2 + mu2^2 + C1) * (2 s12 + C2)/(s1 + s2 + C2); mean over
+ * channels and positions.  Pinned in tests/test_image_loss.py against torch autograd of that published
+ * algorithm written with F.conv2d ("parity unpinned" against the absent package itself).
+ * Images (H, W, 3) as the model returns them; valid (H, W) bytes, NULL = all valid.
+ * ---------------------------------------------------------------------------------------- */
+#define GG_SSIM_WIN 11
+static void ssim_window(REAL *w) {
+    REAL sum = 0;
+    for (int k = 0; k < GG_SSIM_WIN; ++k) {
+        const REAL c = (REAL)(k - GG_SSIM_WIN / 2);
+        w[k] = (REAL)exp(-(double)(c * c) / (2.0 * 1.5 * 1.5));
+        sum += w[k];
+    }
+    for (int k = 0; k < GG_SSIM_WIN; ++k) w[k] /= sum;
+}
+/* the five filtered moments at output (i, j) of channel c; X = gt, Y = rgb, both zeroed where invalid */
+static void ssim_moments(int W, const REAL *rgb, const REAL *gt, const uint8_t *valid, const REAL *w,
+                         int i, int j, int c, REAL *m) {
+    REAL mx = 0, my = 0, mxx = 0, myy = 0, mxy = 0;
+    for (int a = 0; a < GG_SSIM_WIN; ++a) {
+        REAL rx = 0, ry = 0, rxx = 0, ryy = 0, rxy = 0;
+        for (int b = 0; b < GG_SSIM_WIN; ++b) {
+            const size_t p = (size_t)(i + a) * W + (j + b);
+            const int ok = valid ? valid[p] != 0 : 1;
+            const REAL x = ok ? gt[3 * p + c] : 0, y = ok ? rgb[3 * p + c] : 0;
+            rx += w[b] * x; ry += w[b] * y; rxx += w[b] * (x * x); ryy += w[b] * (y * y); rxy += w[b] * (x * y);
+        }
+        mx += w[a] * rx; my += w[a] * ry; mxx += w[a] * rxx; myy += w[a] * ryy; mxy += w[a] * rxy;
+    }
+    m[0] = mx; m[1] = my; m[2] = mxx; m[3] = myy; m[4] = mxy;
+}
+/* ssim value and its partial derivatives with respect to mu2 (total, through s2 and s12 too), E[Y^2], E[XY] */
+static REAL ssim_point(const REAL *m, REAL *g_b, REAL *g_yy, REAL *g_xy) {
+    const REAL C1 = (REAL)(0.01 * 0.01), C2 = (REAL)(0.03 * 0.03);
+    const REAL a = m[0], b = m[1];
+    const REAL s1 = m[2] - a * a, s2 = m[3] - b * b, s12 = m[4] - a * b;
+    const REAL ln = 2 * a * b + C1, ld = a * a + b * b + C1, cn = 2 * s12 + C2, cd = s1 + s2 + C2;
+    const REAL L = ln / ld, CS = cn / cd;
+    if (g_b) {
+        const REAL dL_db = (2 * a * ld - ln * 2 * b) / (ld * ld);
+        const REAL dCS_ds2 = -cn / (cd * cd), dCS_ds12 = 2 / cd;
+        *g_b = CS * dL_db + L * (dCS_ds2 * (-2 * b) + dCS_ds12 * (-a));
+        *g_yy = L * dCS_ds2;
+        *g_xy = L * dCS_ds12;
+    }
+    return L * CS;
+}
+/* out3 = {main_loss, Ll1, ssim} */
+void NAME(image_loss_fwd)(int H, int W, const REAL *rgb, const REAL *gt, const uint8_t *valid, REAL ssim_lambda,
+                          REAL *out3) {
+    REAL w[GG_SSIM_WIN];
+    ssim_window(w);
+    double l1 = 0, cnt = 0;
+    for (size_t p = 0; p < (size_t)H * W; ++p)
+        if (!valid || valid[p]) {
+            for (int c = 0; c < 3; ++c) l1 += fabs((double)(gt[3 * p + c] - rgb[3 * p + c]));
+            cnt += 3;
+        }
+    const int Ho = H - GG_SSIM_WIN + 1, Wo = W - GG_SSIM_WIN + 1;
+    double ss = 0;
+#pragma omp parallel for schedule(static) reduction(+ : ss)
+    for (int i = 0; i < Ho; ++i)
+        for (int j = 0; j < Wo; ++j)
+            for (int c = 0; c < 3; ++c) {
+                REAL m[5];
+                ssim_moments(W, rgb, gt, valid, w, i, j, c, m);
+                ss += (double)ssim_point(m, NULL, NULL, NULL);
+            }
+    const REAL Ll1 = (REAL)(l1 / cnt), ssim = (REAL)(ss / (3.0 * Ho * Wo));
+    out3[0] = (1 - ssim_lambda) * Ll1 + ssim_lambda * (1 - ssim);
+    out3[1] = Ll1;
+    out3[2] = ssim;
+}
+/* v_rgb (H, W, 3) = v_main * d main_loss / d rgb (zero at invalid pixels) */
+void NAME(image_loss_bwd)(int H, int W, const REAL *rgb, const REAL *gt, const uint8_t *valid, REAL ssim_lambda,
+                          REAL v_main, REAL *v_rgb) {
+    REAL w[GG_SSIM_WIN];
+    ssim_window(w);
+    const int Ho = H - GG_SSIM_WIN + 1, Wo = W - GG_SSIM_WIN + 1;
+    double cnt = 0;
+    for (size_t p = 0; p < (size_t)H * W; ++p)
+        if (!valid || valid[p]) cnt += 3;
+    REAL *g = (REAL *)malloc(sizeof(REAL) * 9 * (size_t)Ho * Wo);   /* [c][3 maps][Ho][Wo] */
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < Ho; ++i)
+        for (int j = 0; j < Wo; ++j)
+            for (int c = 0; c < 3; ++c) {
+                REAL m[5], gb, gyy, gxy;
+                ssim_moments(W, rgb, gt, valid, w, i, j, c, m);
+                ssim_point(m, &gb, &gyy, &gxy);
+                const size_t o = (size_t)i * Wo + j, plane = (size_t)Ho * Wo;
+                g[(3 * c + 0) * plane + o] = gb;
+                g[(3 * c + 1) * plane + o] = gyy;
+                g[(3 * c + 2) * plane + o] = gxy;
+            }
+    const REAL ks = -ssim_lambda * v_main / (REAL)(3.0 * Ho * Wo);      /* d(lambda (1 - mean ssim)) */
+    const REAL kl = (1 - ssim_lambda) * v_main / (REAL)cnt;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const size_t p = (size_t)y * W + x;
+            const int ok = valid ? valid[p] != 0 : 1;
+            for (int c = 0; c < 3; ++c) {
+                if (!ok) { v_rgb[3 * p + c] = 0; continue; }
+                REAL Gb = 0, Gyy = 0, Gxy = 0;
+                for (int a = 0; a < GG_SSIM_WIN; ++a) {
+                    const int i = y - a;
+                    if (i < 0 || i >= Ho) continue;
+                    REAL rb = 0, ryy = 0, rxy = 0;
+                    for (int b = 0; b < GG_SSIM_WIN; ++b) {
+                        const int j = x - b;
+                        if (j < 0 || j >= Wo) continue;
+                        const size_t o = (size_t)i * Wo + j, plane = (size_t)Ho * Wo;
+                        rb += w[b] * g[(3 * c + 0) * plane + o];
+                        ryy += w[b] * g[(3 * c + 1) * plane + o];
+                        rxy += w[b] * g[(3 * c + 2) * plane + o];
+                    }
+                    Gb += w[a] * rb; Gyy += w[a] * ryy; Gxy += w[a] * rxy;
+                }
+                const REAL Y = rgb[3 * p + c], X = gt[3 * p + c];
+                const REAL d = Y - X;
+                const REAL sgn = d > 0 ? (REAL)1 : (d < 0 ? (REAL)-1 : (REAL)0);   /* torch.abs' gradient: sign */
+                v_rgb[3 * p + c] = ks * (Gb + 2 * Y * Gyy + X * Gxy) + kl * sgn;
+            }
+        }
+    free(g);
+}
+
+/* ------------------------------------------------------------------------------------------
  * Binning — gsplat rasterize.py compute_cumulative_intersects + bin_and_sort_gaussians (†),
  * forward.cu map_gaussian_to_intersects / get_tile_bin_edges, torch.sort on the int64 keys;
  * run inside every Rasterize*.forward (gaussian_splatting.py:735,747,759,773).

@@ -161,6 +161,29 @@ def shade_tail_bwd(degrees_to_use, num_bases, viewdirs, v_tail, mask, v_coeffs_i
     return out, vd, vn
 
 
+def image_loss_fwd(rgb, gt, valid, ssim_lambda=0.2, dtype=np.float32):
+    """-> (main_loss, Ll1, ssim) of get_loss_dict :882-885, :931; rgb, gt (H, W, 3); valid (H, W) bool or None"""
+    lib, pre, RT = _lib(dtype)
+    rgb, gt = _c(rgb, dtype), _c(gt, dtype)
+    h, w = rgb.shape[:2]
+    v = None if valid is None else _c(np.asarray(valid).astype(np.uint8), np.uint8)
+    out = np.zeros(3, dtype)
+    getattr(lib, pre + "image_loss_fwd")(C.c_int(h), C.c_int(w), _p(rgb), _p(gt), _p(v) if v is not None else None,
+                                         RT(ssim_lambda), _p(out))
+    return out
+
+
+def image_loss_bwd(rgb, gt, valid, ssim_lambda=0.2, v_main=1.0, dtype=np.float32):
+    lib, pre, RT = _lib(dtype)
+    rgb, gt = _c(rgb, dtype), _c(gt, dtype)
+    h, w = rgb.shape[:2]
+    v = None if valid is None else _c(np.asarray(valid).astype(np.uint8), np.uint8)
+    out = np.zeros((h, w, 3), dtype)
+    getattr(lib, pre + "image_loss_bwd")(C.c_int(h), C.c_int(w), _p(rgb), _p(gt), _p(v) if v is not None else None,
+                                         RT(ssim_lambda), RT(v_main), _p(out))
+    return out
+
+
 def bin_and_sort(xys, depths, radii, num_tiles_hit, tile_bounds, dtype=np.float32):
     """compute_cumulative_intersects + bin_and_sort_gaussians.
     -> dict(num_intersects, cum_tiles_hit, isect_ids, gaussian_ids, isect_ids_sorted,

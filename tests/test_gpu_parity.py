@@ -566,6 +566,18 @@ def test_full_size_vs_oracle(oracle, n, cfg, min_visible):
         assert_bitexact(_np(out_g[k]), _np(out_c[k]), f"image.{k}")
     for name in ("means", "scales", "quats", "opac", "sh", "feature", "normals"):
         assert_close(_np(a_g[name].grad), _np(a_c[name].grad), f"grad.{name}", rtol=3e-4, atol_frac=1e-5)
+    # the plugin route on the same inputs: ShadeTail + ONE RasterizeSegments operator (pair forward / pair
+    # backward kernels) against the same oracle run of the four separate calls
+    from gaussiangrasper_amd.pipeline import rasterize_activated_fused
+    a_f = _activated_leaves(act, DEV)
+    P.clear_bin_cache()
+    out_f = rasterize_activated_fused(a_f, v, P)
+    backward_view(out_f, {k: t.to(DEV) for k, t in cot.items()})
+    for k in ("rgb", "feature", "depth", "normal"):
+        assert_bitexact(_np(out_f[k]), _np(out_c[k]), f"plugin route image.{k}")
+    for name in ("means", "scales", "quats", "opac", "sh", "feature", "normals"):
+        assert_close(_np(a_f[name].grad), _np(a_c[name].grad), f"plugin route grad.{name}", rtol=3e-4,
+                     atol_frac=1e-5)
 
 
 def test_quat_to_rotmat_hip_vs_oracle_and_torch(oracle):

@@ -445,8 +445,12 @@ def run_render_only(args, rank, world, dev, ops, lib, barrier, max_over_ranks) -
     views = ring_cameras(total_views, args.height, args.width, device=dev)
     my_views = shard_views(total_views, rank, world)
 
+    fused = args.route == "plugin" and hasattr(ops, "rasterize_segments")
+
     def render(v):
-        out = render_view(scene, views[v], ops)
+        # plugin route: the model subclass's get_outputs (ShadeTail + one RasterizeSegments forward);
+        # shim route: the reference's four rasterize forwards
+        out = render_view(scene, views[v], ops, fused=fused)
         clip = fea_up(out["feature"])
         return out, clip
 
@@ -485,10 +489,13 @@ def run_render_only(args, rank, world, dev, ops, lib, barrier, max_over_ranks) -
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE config 5 per-GPU share (render.sh body): %d Gaussians, %dx%d, "
-                               "SH deg 4 rgb + %d-ch feature + depth + normal forwards and the "
+                               "SH deg 4 rgb + %d-ch feature + depth + normal forwards (%s) and the "
                                "fea_up MLP %d->128->512 on every pixel, render-only, %d views/step/GPU"
                                % (args.points, args.width, args.height, args.feature_dim,
+                                  "plugin route: one fused rasterize operator" if fused
+                                  else "shim route: the reference's 4 rasterize calls",
                                   args.feature_dim, args.views_per_step),
+                   "route": "plugin" if fused else "shim",
                    "num_gaussians": args.points, "image": [args.height, args.width],
                    "feature_dim": args.feature_dim, "views_per_step_per_gpu": args.views_per_step,
                    "n_visible": n_vis, "num_intersects": n_isect,

@@ -47,10 +47,12 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
 ABL_OUT = os.path.join(HERE, "libgg_raster_abl.so")
 
 
-def build_ablation(verbose: bool = False) -> str:
+def build_ablation(verbose: bool = False, walk_stats: bool = False) -> str:
     """Measurement-only twin of the library (tools/kbench.py): the same sources with -DGG_ABLATION,
-    which adds the ablated backward kernels and `gg_debug_set_ablation`.  Never loaded by the product."""
-    return build(force=True, verbose=verbose, extra_flags=("-DGG_ABLATION",), out=ABL_OUT)
+    which adds the ablated kernels and the `gg_debug_*` switches; walk_stats (tools/walkstats.py) also counts
+    what the forward walks (the counters make that kernel ~100x slower).  Never loaded by the product."""
+    flags = ("-DGG_ABLATION", "-DGG_WALK_STATS") if walk_stats else ("-DGG_ABLATION",)
+    return build(force=True, verbose=verbose, extra_flags=flags, out=ABL_OUT)
 
 
 COMPAT_OUT = os.path.join(HERE, "libgg_raster_compat.so")

@@ -27,6 +27,7 @@
 #include "blend_common.h"
 
 #define GRP 4          // survivors per loop iteration
+#define KEEP(x) asm volatile("" ::"v"(x))   // measurement builds: keep a value alive
 
 #ifdef GG_ABLATION
 // measurement twin only: walk statistics of the forward kernel (tools/walkstats.py)
@@ -41,7 +42,19 @@ extern "C" int gg_debug_walk_stats(unsigned long long *out8, int reset) {
     }
     return 0;
 }
+#ifdef GG_WALK_STATS   // the counters cost 100x the kernel: only tools/walkstats.py builds with them
 #define WALK_STAT(i, v) do { if (lane == 0) atomicAdd(&g_walk_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define WALK_STAT(i, v) do { } while (0)
+#endif
+// forward ablation of the pair kernel (tools/kbench.py; template parameter FABL): 1 no MFMAs, 2 also no
+// colour-row loads, 3 also no second-array fma, 4 staging only
+static int g_fwd_abl = 0;
+extern "C" int gg_debug_set_fwd_ablation(int level) {
+    const int prev = g_fwd_abl;
+    g_fwd_abl = level;
+    return prev;
+}
 #else
 #define WALK_STAT(i, v) do { } while (0)
 #endif
@@ -141,7 +154,7 @@ __device__ __forceinline__ int stage_chunk(LIST &L, int lane, int e, bool valid,
 // =============================================================================================
 // EX: a second colour array of <= 8 channels (Seg2) is blended in the same walk as this 32-channel chunk
 // (gg_blend_fwd_pair: the plugin's feature | rgb+depth+normal forward in one walk instead of two)
-template <int CH, bool WIDE, bool FULL, bool EX = false>
+template <int CH, bool WIDE, bool FULL, bool EX = false, int FABL = 0>
 __global__ __launch_bounds__(256) void blend2_fwd_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
@@ -187,6 +200,8 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
         const int cnt = stage_chunk<CH, WIDE, false, LIST>(L, lane, e, e < range.y, g_cur, rec, colors, C,
                                                            ch_off, nch, xlo, xhi, ylo, yhi, EX ? &seg2 : nullptr);
         WALK_STAT(0, min(64, range.y - base));
+        constexpr int fabl = FABL;
+        if (fabl >= 4) { KEEP(cnt); continue; }
         for (int k = 0; k < cnt; k += GRP) {
             if (k > 0 && __ballot(!done) == 0ull) break;
             WALK_STAT(1, min(GRP, cnt - k));
@@ -204,7 +219,7 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
                 for (int pr = 0; pr < GRP / 2; ++pr) {
                     // lanes 0-31 fetch the colour row of the even Gaussian, 32-63 of the odd one
                     const int gid = __builtin_bit_cast(int, L.c[GRP + k + 2 * pr + half].x);
-                    colB[pr] = wch_ok ? colors[(size_t)gid * C + ch_off + wch] : 0.0f;
+                    colB[pr] = (wch_ok && fabl < 2) ? colors[(size_t)gid * C + ch_off + wch] : 0.0f;
                 }
             }
             float alpha[GRP];
@@ -225,7 +240,7 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
                 const bool stop = live && (next_T <= GG_T_EPS);
                 const bool blend = live && !stop;
                 vis[q] = blend ? alpha[q] * T : 0.0f;
-#ifdef GG_ABLATION
+#ifdef GG_WALK_STATS
                 {
                     const unsigned long long bm = __ballot(blend), pm = __ballot(pass[q]), lm = __ballot(!done);
                     WALK_STAT(2, bm != 0ull);
@@ -237,7 +252,7 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
                 T = blend ? next_T : T;
                 last = blend ? __builtin_bit_cast(int, N8 ? A[q].w : Cc[q].w) : last;
                 done = done || stop;
-                if (EX) {   // the second array's colours: read from the record right where they are used
+                if (EX && fabl < 3) {   // the second array's colours: read from the record right where they are used
                     const float4 xd = L.d[GRP + k + q], xe = L.e[GRP + k + q];
                     acc2[0] = __builtin_fmaf(xd.x, vis[q], acc2[0]);
                     acc2[EX ? 1 : 0] = __builtin_fmaf(xd.y, vis[q], acc2[EX ? 1 : 0]);
@@ -261,7 +276,14 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
                     }
                 }
             }
-            if (WIDE) {
+            if (WIDE && fabl >= 1) {
+#pragma unroll
+                for (int q = 0; q < GRP; ++q) KEEP(vis[q]);
+#pragma unroll
+                for (int pr = 0; pr < GRP / 2; ++pr) KEEP(colB[pr]);
+            } else if (WIDE) {
+                // (handing these four dependent MFMAs to the pipe at the top of the NEXT iteration, in front of that
+                // group's arithmetic, measures the same for the pair kernel and +8 % for the plain one: 20 more VGPRs)
 #pragma unroll
                 for (int pr = 0; pr < GRP / 2; ++pr) {
                     auto r = __builtin_amdgcn_permlane32_swap(
@@ -326,7 +348,6 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
 // under -DGG_ABLATION, i.e. in libgg_raster_abl.so, never in the product library:
 //   1 = no global atomics, 2 = also no butterfly, 3 = also no recurrence/partials (geometry only),
 //   4 = staging + cull only (no group loop)
-#define KEEP(x) asm volatile("" ::"v"(x))
 template <int CH, int ABL = 0, bool DET = false>
 __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
@@ -941,8 +962,18 @@ void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
     seg2.out_img = out_img2;
     seg2.C2 = C2;
     seg2.nch2 = C2;
-    hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, true>), grid, block, 0, s, C, 0, 32, img_h, img_w,
-                       tiles_x, ntiles, ids, bins, rec, colors, background, out_img, final_Ts, final_idx, 1, seg2);
+#define B2_FPAIR(L) hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, true, L>), grid, block, 0, s, C, 0, 32, \
+        img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, out_img, final_Ts, final_idx, 1, seg2)
+#ifdef GG_ABLATION
+    switch (g_fwd_abl) {   // measurement twin: wrong images on purpose
+        case 1: B2_FPAIR(1); return;
+        case 2: B2_FPAIR(2); return;
+        case 3: B2_FPAIR(3); return;
+        case 4: B2_FPAIR(4); return;
+        default: break;
+    }
+#endif
+    B2_FPAIR(0);
 }
 
 #define B2_BWDW_ARGS C, off, n, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, \

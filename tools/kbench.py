@@ -35,9 +35,7 @@ def main():
     args = ap.parse_args()
     dev = "cuda:0"
     # the ablated kernels live only in the measurement twin of the library (-DGG_ABLATION)
-    if not os.path.exists(gg_build.ABL_OUT) or \
-            os.path.getmtime(gg_build.ABL_OUT) < os.path.getmtime(gg_build.OUT):
-        gg_build.build_ablation()
+    gg_build.build_ablation()       # always: tools/walkstats.py leaves a twin with the (slow) walk counters
     _lib.LIB_PATH = gg_build.ABL_OUT
     lib = _lib.load()
     lib.gg_debug_set_ablation.restype, lib.gg_debug_set_ablation.argtypes = ctypes.c_int, [ctypes.c_int]
@@ -101,6 +99,27 @@ def main():
         lib.gg_prof_enable(0)
         r = prof(lib)
         print(label, {k: round(v, 4) for k, v in r.items() if "bwd" in k and "blend" in k}, flush=True)
+
+    def run_pair_fwd(label):
+        f, t = feat.detach(), tail.detach()
+        lib.gg_prof_reset()
+        lib.gg_prof_enable(1)
+        with torch.no_grad():
+            for _ in range(args.reps):
+                ops.clear_bin_cache()
+                ops.rasterize_segments(xys.detach(), depths, radii, conics.detach(), nth, opac.detach(), h, w,
+                                       [(f, torch.zeros(32, device=dev)), (t, torch.zeros(7, device=dev))])
+        torch.cuda.synchronize()
+        lib.gg_prof_enable(0)
+        r = prof(lib)
+        print(label, {k: round(v, 4) for k, v in r.items() if "fwd_pair" in k}, flush=True)
+
+    lib.gg_debug_set_fwd_ablation.restype, lib.gg_debug_set_fwd_ablation.argtypes = ctypes.c_int, [ctypes.c_int]
+    run_pair_fwd("fwd pair full")
+    for lvl, name in ((1, "no MFMAs"), (2, "no colour-row loads"), (3, "no second-array fma"), (4, "staging only")):
+        lib.gg_debug_set_fwd_ablation(lvl)
+        run_pair_fwd(f"fwd pair abl{lvl} {name}")
+    lib.gg_debug_set_fwd_ablation(0)
 
     run_pair("pair full  ")
     for lvl, name in ((1, "no colour atomics"), (2, "no flushes"), (3, "no butterfly"), (4, "no D product"),

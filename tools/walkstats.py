@@ -9,7 +9,7 @@ import torch
 from gaussiangrasper_amd import _lib, build as gg_build, ops
 from gaussiangrasper_amd.camera import ring_cameras
 from gaussiangrasper_amd.scene import make_scene
-gg_build.build_ablation()
+gg_build.build_ablation(walk_stats=True)
 _lib.LIB_PATH = gg_build.ABL_OUT
 lib = _lib.load()
 dev = "cuda:0"

@@ -7,7 +7,7 @@ import csv, glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-NAMES = {"blend2_fwd_kernel<32, true, true, true>": "blend_fwd_pair_kernel<40>",
+NAMES = {"blend2_fwd_kernel<32, true, true, true": "blend_fwd_pair_kernel<40>",
          "blend2_fwd_kernel<3,": "blend_fwd_kernel<3>", "blend2_fwd_kernel<8,": "blend_fwd_kernel<8>",
          "blend2_fwd_kernel<32,": "blend_fwd_kernel<32>", "blend2_bwd_narrow_kernel<3,": "blend_bwd_kernel<3>",
          "blend2_bwd_narrow_kernel<8,": "blend_bwd_kernel<8>", "blend2_bwd_wide_kernel<true, 0, 32, false, false>": "blend_bwd_kernel<32>",

@@ -166,30 +166,88 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// waves stride over the points and add ONE total per wave to sim_sum (a point-per-atomic form serialises on that
+// address: 140 ms for the 1.7 M masked pixels of the reference's normal loss, :879)
 __global__ __launch_bounds__(256) void cosine_fwd_kernel(long M, int C, const float *__restrict__ a,
                                                          const float *__restrict__ b, float *__restrict__ sim,
                                                          float *__restrict__ na, float *__restrict__ nb,
                                                          float *__restrict__ sim_sum) {
     const int lane = threadIdx.x & 63;
-    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= M) return;
-    float dot = 0.f, sa = 0.f, sb = 0.f;
-    for (int c = lane; c < C; c += 64) {
-        const float u = a[(size_t)m * C + c], v = b[(size_t)m * C + c];
-        dot = __builtin_fmaf(u, v, dot);
-        sa = __builtin_fmaf(u, u, sa);
-        sb = __builtin_fmaf(v, v, sb);
+    const long nwaves = (long)gridDim.x * 4;
+    float total = 0.f;   // lane 0's
+    for (long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += nwaves) {
+        float dot = 0.f, sa = 0.f, sb = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float u = a[(size_t)m * C + c], v = b[(size_t)m * C + c];
+            dot = __builtin_fmaf(u, v, dot);
+            sa = __builtin_fmaf(u, u, sa);
+            sb = __builtin_fmaf(v, v, sb);
+        }
+        dot = wave_sum(dot);
+        sa = wave_sum(sa);
+        sb = wave_sum(sb);
+        if (lane == 0) {
+            const float n1 = sqrtf(sa), n2 = sqrtf(sb);
+            const float s = dot / (fmaxf(n1, CL_EPS) * fmaxf(n2, CL_EPS));
+            na[m] = n1;
+            nb[m] = n2;
+            sim[m] = s;
+            total += s;
+        }
     }
-    dot = wave_sum(dot);
-    sa = wave_sum(sa);
-    sb = wave_sum(sb);
-    if (lane == 0) {
+    if (lane == 0) atomicAdd(sim_sum, total);
+}
+
+// <= 16 channels (the reference's normal loss: 3 channels x every masked pixel): one LANE per point
+template <int CMAX>
+__global__ __launch_bounds__(256) void cosine_fwd_small_kernel(long M, int C, const float *__restrict__ a,
+                                                               const float *__restrict__ b,
+                                                               float *__restrict__ sim, float *__restrict__ na,
+                                                               float *__restrict__ nb, float *__restrict__ sim_sum) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    float total = 0.f;
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += stride) {
+        float dot = 0.f, sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C) {
+                const float u = a[(size_t)m * C + c], v = b[(size_t)m * C + c];
+                dot = __builtin_fmaf(u, v, dot);
+                sa = __builtin_fmaf(u, u, sa);
+                sb = __builtin_fmaf(v, v, sb);
+            }
         const float n1 = sqrtf(sa), n2 = sqrtf(sb);
         const float s = dot / (fmaxf(n1, CL_EPS) * fmaxf(n2, CL_EPS));
         na[m] = n1;
         nb[m] = n2;
         sim[m] = s;
-        atomicAdd(sim_sum, s);
+        total += s;
+    }
+    total = wave_sum(total);
+    if ((threadIdx.x & 63) == 0) atomicAdd(sim_sum, total);
+}
+template <int CMAX>
+__global__ __launch_bounds__(256) void cosine_bwd_small_kernel(long M, int C, const float *__restrict__ a,
+                                                               const float *__restrict__ b,
+                                                               const float *__restrict__ sim,
+                                                               const float *__restrict__ na,
+                                                               const float *__restrict__ nb,
+                                                               const float *__restrict__ v_loss,
+                                                               float *__restrict__ v_a, float *__restrict__ v_b) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const float s = -v_loss[0] / (float)M;
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += stride) {
+        const float n1 = na[m], n2 = nb[m], sm = sim[m];
+        const float ca = fmaxf(n1, CL_EPS), cb = fmaxf(n2, CL_EPS);
+        const bool fa = n1 > CL_EPS, fb = n2 > CL_EPS;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C) {
+                const float u = a[(size_t)m * C + c], v = b[(size_t)m * C + c];
+                const float ua = u / ca, vb = v / cb;
+                v_a[(size_t)m * C + c] = s * (vb - (fa ? sm * ua : 0.0f)) / ca;
+                v_b[(size_t)m * C + c] = s * (ua - (fb ? sm * vb : 0.0f)) / cb;
+            }
     }
 }
 
@@ -224,8 +282,15 @@ extern "C" int gg_cosine_loss_fwd(int64_t num_points, int channels, const float 
     if (hipMemsetAsync(sim_sum, 0, sizeof(float), s) != hipSuccess) return GG_ERR_LAUNCH;
     if (num_points == 0) return GG_OK;
     GG_REQUIRE(a && b && sim && norm_a && norm_b, "null pointer");
-    hipLaunchKernelGGL(cosine_fwd_kernel, dim3((unsigned)((num_points + 3) / 4)), dim3(256), 0, s,
-                       (long)num_points, channels, a, b, sim, norm_a, norm_b, sim_sum);
+    if (channels <= 16) {
+        const unsigned nb = (unsigned)((num_points + 255) / 256 < 4096 ? (num_points + 255) / 256 : 4096);
+        hipLaunchKernelGGL(cosine_fwd_small_kernel<16>, dim3(nb), dim3(256), 0, s, (long)num_points, channels, a, b,
+                           sim, norm_a, norm_b, sim_sum);
+    } else {
+        const unsigned nb = (unsigned)((num_points + 3) / 4 < 8192 ? (num_points + 3) / 4 : 8192);
+        hipLaunchKernelGGL(cosine_fwd_kernel, dim3(nb), dim3(256), 0, s, (long)num_points, channels, a, b, sim,
+                           norm_a, norm_b, sim_sum);
+    }
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
@@ -236,9 +301,15 @@ extern "C" int gg_cosine_loss_bwd(int64_t num_points, int channels, const float 
     GG_REQUIRE(num_points >= 0 && channels >= 1, "bad size");
     if (num_points == 0) return GG_OK;
     GG_REQUIRE(a && b && sim && norm_a && norm_b && v_loss && v_a && v_b, "null pointer");
-    hipLaunchKernelGGL(cosine_bwd_kernel, dim3((unsigned)((num_points + 3) / 4)), dim3(256), 0,
-                       (hipStream_t)stream, (long)num_points, channels, a, b, sim, norm_a, norm_b, v_loss, v_a,
-                       v_b);
+    if (channels <= 16) {
+        const unsigned nb = (unsigned)((num_points + 255) / 256 < 4096 ? (num_points + 255) / 256 : 4096);
+        hipLaunchKernelGGL(cosine_bwd_small_kernel<16>, dim3(nb), dim3(256), 0, (hipStream_t)stream,
+                           (long)num_points, channels, a, b, sim, norm_a, norm_b, v_loss, v_a, v_b);
+    } else {
+        hipLaunchKernelGGL(cosine_bwd_kernel, dim3((unsigned)((num_points + 3) / 4)), dim3(256), 0,
+                           (hipStream_t)stream, (long)num_points, channels, a, b, sim, norm_a, norm_b, v_loss, v_a,
+                           v_b);
+    }
     GG_CHECK_LAUNCH();
     return GG_OK;
 }

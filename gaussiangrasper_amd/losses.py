@@ -107,3 +107,80 @@ def main_loss(rgb: Tensor, gt_img: Tensor, valid_mask=None, ssim_lambda: float =
     only main_loss carries a gradient (to rgb).  Unlike the reference it does not modify `gt_img` / `rgb` in place
     (the reference zeroes both at the invalid pixels as a side effect of computing the loss)."""
     return _MainLoss.apply(rgb, gt_img, valid_mask, ssim_lambda)
+
+
+# ------------------------------------------------------------------------------------------------
+# depth and normal losses over the masked pixels   (SURVEY.md §8f-4 tail; reference :879-880)
+# ------------------------------------------------------------------------------------------------
+def _pixel_layout(t: Tensor, h: int, w: int, channels: int):
+    """(tensor, pixel stride, channel stride) in elements for an image given pixel-major (H, W, C) — possibly a
+    channel slice of a wider image — or channel-major (C, H, W); anything else is made contiguous pixel-major."""
+    if t.dtype == torch.float32:
+        if t.dim() == 3 and tuple(t.shape) == (h, w, channels) and t.stride(0) == w * t.stride(1):
+            return t, t.stride(1), t.stride(2) if channels > 1 else 1
+        if t.dim() == 3 and tuple(t.shape) == (channels, h, w) and t.stride(1) == w * t.stride(2) and (h, w) != (w, channels):
+            return t, t.stride(2), t.stride(0)
+        if channels == 1 and t.dim() == 2 and tuple(t.shape) == (h, w) and t.stride(0) == w * t.stride(1):
+            return t, t.stride(1), 1
+    if t.dim() == 3 and tuple(t.shape) == (channels, h, w) and (h, w) != (w, channels):
+        t = t.permute(1, 2, 0)
+    t = _f32(t).reshape(h, w, channels)
+    return t, channels, 1
+
+
+class _DepthNormalLoss(Function):
+    @staticmethod
+    def forward(ctx, depth, gt_depth, normal, gt_normal, mask, h, w):
+        dev = _require_hip(depth, gt_depth, normal, gt_normal)
+        d, ds, _ = _pixel_layout(depth, h, w, 1)
+        gd, gds, _ = _pixel_layout(gt_depth, h, w, 1)
+        n, nps, ncs = _pixel_layout(normal, h, w, 3)
+        gn, gps, gcs = _pixel_layout(gt_normal, h, w, 3)
+        m = None if mask is None else mask.reshape(h, w).to(device=dev, dtype=torch.uint8).contiguous()
+        lib = _lib.load()
+        ws = torch.empty(lib.gg_geom_loss_workspace(), dtype=torch.uint8, device=dev)
+        out3 = torch.empty(3, dtype=torch.float32, device=dev)
+        _lib.check(lib.gg_geom_loss_fwd(h * w, _ptr(d), ds, _ptr(gd), gds, _ptr(n), nps, ncs, _ptr(gn), gps, gcs,
+                                        _ptr(m) if m is not None else None, _ptr(out3), _ptr(ws), ws.numel(),
+                                        _stream(dev)), "gg_geom_loss_fwd")
+        ctx.layout = (h, w, ds, gds, nps, ncs, gps, gcs, tuple(depth.shape))
+        ctx.has_mask = m is not None
+        ctx.save_for_backward(*([d, gd, n, gn, ws] + ([m] if m is not None else [])))
+        return out3[0], out3[1]
+
+    @staticmethod
+    def backward(ctx, v_dl, v_nl):
+        saved = ctx.saved_tensors
+        d, gd, n, gn, ws = saved[:5]
+        m = saved[5] if ctx.has_mask else None
+        h, w, ds, gds, nps, ncs, gps, gcs, dshape = ctx.layout
+        dev = d.device
+        z = lambda v: torch.zeros(1, dtype=torch.float32, device=dev) if v is None else _f32(v).reshape(1)
+        v_depth = torch.empty(h * w, dtype=torch.float32, device=dev)
+        v_normal = torch.empty(h, w, 3, dtype=torch.float32, device=dev)
+        vd, vn = z(v_dl), z(v_nl)
+        _lib.check(_lib.load().gg_geom_loss_bwd(h * w, _ptr(d), ds, _ptr(gd), gds, _ptr(n), nps, ncs, _ptr(gn), gps,
+                                                gcs, _ptr(m) if m is not None else None, _ptr(vd), _ptr(vn),
+                                                _ptr(ws), ws.numel(), _ptr(v_depth), _ptr(v_normal), _stream(dev)),
+                   "gg_geom_loss_bwd")
+        return v_depth.reshape(dshape), None, v_normal, None, None, None, None
+
+
+def depth_normal_loss(depth: Tensor, gt_depth: Tensor, normal: Tensor, gt_normal: Tensor, depth_mask=None):
+    """The reference's `depth_loss` and `normal_loss` (nerfstudio/models/gaussian_splatting.py:879-880) in one pass
+    each way, without gathering the masked pixels:
+        depth_loss  = F.l1_loss(depth[m], gt_depth[m])
+        normal_loss = 0.5 F.mse_loss(normal[:, m], gt_normal[:, m]) + 0.5 cosine_similarity_loss(normal[:, m], gt_normal[:, m])
+    depth (H, W, 1) and normal (H, W, 3) as the model returns them (channel slices of a wider image are read in
+    place); gt_depth (H, W) / (1, H, W) / (H, W, 1); gt_normal (3, H, W) as the reference prepares it, or (H, W, 3);
+    depth_mask (H, W) or (1, H, W) bool, None = every pixel.  Returns (depth_loss, normal_loss)."""
+    if normal.dim() != 3:
+        raise ValueError("normal must be (H, W, 3)")
+    h, w = normal.shape[:2]
+    if normal.shape[2] != 3 or depth.numel() != h * w or gt_depth.numel() != h * w or gt_normal.numel() != 3 * h * w:
+        raise ValueError("expected depth (H, W, 1), gt_depth (H, W), normal (H, W, 3), gt_normal (3, H, W)")
+    if depth_mask is not None and depth_mask.numel() != h * w:
+        raise ValueError("depth_mask must be (H, W)")
+    depth3 = depth if depth.dim() == 3 else depth.reshape(h, w, 1)
+    gd = gt_depth.reshape(h, w) if gt_depth.is_contiguous() else gt_depth.contiguous().reshape(h, w)
+    return _DepthNormalLoss.apply(depth3, gd, normal, gt_normal, depth_mask, h, w)

@@ -304,6 +304,25 @@ int gg_image_loss_bwd(int img_height, int img_width, const float *rgb, const flo
                       float ssim_lambda, const float *v_main, const void *ws, size_t ws_bytes, float *v_rgb,
                       gg_stream_t stream);
 
+/* Depth and normal losses of get_loss_dict (gaussian_splatting.py:879-880) over the pixels where mask != 0:
+ *     depth_loss  = F.l1_loss(depth[m], gt_depth[m])
+ *     normal_loss = 0.5 F.mse_loss(normal[:, m], gt_normal[:, m]) + 0.5 cosine_similarity_loss(normal[:, m], gt_normal[:, m])
+ * depth / gt_depth: element p at base[p * stride]; normal / gt_normal: channel c of pixel p at
+ * base[p * pixel_stride + c * channel_stride] (the model's images are pixel-major, the reference's ground truth
+ * channel-major).  out3 = {depth_loss, normal_loss, number of masked pixels} (device).  The backward takes the
+ * forward's workspace (gg_geom_loss_workspace bytes), the two loss cotangents from device memory (1 float each) and
+ * writes dense v_depth (num_pixels,), v_normal (num_pixels, 3), zero outside the mask. */
+size_t gg_geom_loss_workspace(void);
+int gg_geom_loss_fwd(int64_t num_pixels, const float *depth, int depth_stride, const float *gt_depth,
+                     int gt_depth_stride, const float *normal, int normal_pixel_stride, int normal_channel_stride,
+                     const float *gt_normal, int gt_normal_pixel_stride, int gt_normal_channel_stride,
+                     const uint8_t *mask, float *out3, void *ws, size_t ws_bytes, gg_stream_t stream);
+int gg_geom_loss_bwd(int64_t num_pixels, const float *depth, int depth_stride, const float *gt_depth,
+                     int gt_depth_stride, const float *normal, int normal_pixel_stride, int normal_channel_stride,
+                     const float *gt_normal, int gt_normal_pixel_stride, int gt_normal_channel_stride,
+                     const uint8_t *mask, const float *v_depth_loss, const float *v_normal_loss, const void *ws,
+                     size_t ws_bytes, float *v_depth, float *v_normal, gg_stream_t stream);
+
 /* ---- densification, culling and the optimizer step ---------------------------------
  * The per-Gaussian optimizer-side work of the reference model, which it does with torch indexing,
  * torch.cat and one torch.optim.Adam per parameter group:

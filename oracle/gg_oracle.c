@@ -716,6 +716,78 @@ void NAME(image_loss_bwd)(int H, int W, const REAL *rgb, const REAL *gt, const u
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Depth and normal losses of get_loss_dict (gaussian_splatting.py:879-880), P = H*W pixels, mask = depth_mask:
+ *     normal_loss = 0.5 * F.mse_loss(normal[:, m], gt_normal[:, m]) + 0.5 * cosine_similarity_loss(normal[:, m], gt_normal[:, m])
+ *     depth_loss  = F.l1_loss(depth[m], gt_depth[m])
+ * cosine_similarity_loss (:113-118) normalises over the 3 channels with F.normalize's eps 1e-12.  Plain torch in
+ * the reference: pinned in tests/test_image_loss.py against torch autograd of these lines.
+ * normal / gt_normal are addressed as base[p * pstride + c * cstride] (the model's image is pixel-major, the
+ * reference's ground truth channel-major); depth as base[p * stride].
+ * ---------------------------------------------------------------------------------------- */
+static inline REAL geom_max(REAL a, REAL b) { return a > b ? a : b; }
+/* out3 = {depth_loss, normal_loss, number of masked pixels} */
+void NAME(geom_loss_fwd)(int64_t P, const REAL *depth, int d_stride, const REAL *gt_depth, int gd_stride,
+                         const REAL *normal, int n_pstride, int n_cstride, const REAL *gt_normal, int g_pstride,
+                         int g_cstride, const uint8_t *mask, REAL *out3) {
+    const REAL eps = (REAL)1e-12;
+    double l1 = 0, mse = 0, cs = 0, cnt = 0;
+    for (int64_t p = 0; p < P; ++p) {
+        if (mask && !mask[p]) continue;
+        l1 += fabs((double)(depth[p * d_stride] - gt_depth[p * gd_stride]));
+        REAL dot = 0, sa = 0, sb = 0;
+        for (int c = 0; c < 3; ++c) {
+            const REAL u = normal[p * n_pstride + c * n_cstride], v = gt_normal[p * g_pstride + c * g_cstride];
+            const REAL d = u - v;
+            mse += (double)(d * d);
+            dot = FMA(u, v, dot); sa = FMA(u, u, sa); sb = FMA(v, v, sb);
+        }
+        const REAL n1 = (REAL)sqrt((double)sa), n2 = (REAL)sqrt((double)sb);
+        cs += (double)(dot / (geom_max(n1, eps) * geom_max(n2, eps)));
+        cnt += 1;
+    }
+    out3[0] = (REAL)(l1 / cnt);
+    out3[1] = (REAL)0.5 * (REAL)(mse / (3.0 * cnt)) + (REAL)0.5 * ((REAL)1 - (REAL)(cs / cnt));
+    out3[2] = (REAL)cnt;
+}
+/* v_depth (P,), v_normal (P, 3) dense; zero outside the mask */
+void NAME(geom_loss_bwd)(int64_t P, const REAL *depth, int d_stride, const REAL *gt_depth, int gd_stride,
+                         const REAL *normal, int n_pstride, int n_cstride, const REAL *gt_normal, int g_pstride,
+                         int g_cstride, const uint8_t *mask, REAL v_depth_loss, REAL v_normal_loss, REAL *v_depth,
+                         REAL *v_normal) {
+    const REAL eps = (REAL)1e-12;
+    double cnt = 0;
+    for (int64_t p = 0; p < P; ++p)
+        if (!mask || mask[p]) cnt += 1;
+    const REAL M = (REAL)cnt;
+    const REAL kd = v_depth_loss / M;
+    const REAL km = (REAL)0.5 * v_normal_loss * 2 / (3 * M);       /* d 0.5 mse */
+    const REAL kc = -((REAL)0.5 * v_normal_loss) / M;              /* d 0.5 (1 - mean sim) */
+    for (int64_t p = 0; p < P; ++p) {
+        if (mask && !mask[p]) {
+            v_depth[p] = 0;
+            for (int c = 0; c < 3; ++c) v_normal[3 * p + c] = 0;
+            continue;
+        }
+        const REAL d = depth[p * d_stride] - gt_depth[p * gd_stride];
+        v_depth[p] = kd * (d > 0 ? (REAL)1 : (d < 0 ? (REAL)-1 : (REAL)0));
+        REAL dot = 0, sa = 0, sb = 0, u3[3], v3[3];
+        for (int c = 0; c < 3; ++c) {
+            u3[c] = normal[p * n_pstride + c * n_cstride];
+            v3[c] = gt_normal[p * g_pstride + c * g_cstride];
+            dot = FMA(u3[c], v3[c], dot); sa = FMA(u3[c], u3[c], sa); sb = FMA(v3[c], v3[c], sb);
+        }
+        const REAL n1 = (REAL)sqrt((double)sa), n2 = (REAL)sqrt((double)sb);
+        const REAL ca = geom_max(n1, eps), cb = geom_max(n2, eps);
+        const REAL sim = dot / (ca * cb);
+        for (int c = 0; c < 3; ++c) {
+            const REAL ua = u3[c] / ca, vb = v3[c] / cb;
+            const REAL dsim = (vb - (n1 > eps ? sim * ua : 0)) / ca;      /* as cosine_loss_bwd */
+            v_normal[3 * p + c] = km * (u3[c] - v3[c]) + kc * dsim;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * Binning — gsplat rasterize.py compute_cumulative_intersects + bin_and_sort_gaussians (†),
  * forward.cu map_gaussian_to_intersects / get_tile_bin_edges, torch.sort on the int64 keys;
  * run inside every Rasterize*.forward (gaussian_splatting.py:735,747,759,773).

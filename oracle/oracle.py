@@ -184,6 +184,34 @@ def image_loss_bwd(rgb, gt, valid, ssim_lambda=0.2, v_main=1.0, dtype=np.float32
     return out
 
 
+def _geom_args(depth, gt_depth, normal, gt_normal_chw, mask, dtype):
+    depth, gt_depth = _c(depth, dtype).reshape(-1), _c(gt_depth, dtype).reshape(-1)
+    normal, gtn = _c(normal, dtype), _c(gt_normal_chw, dtype)          # (H, W, 3) and (3, H, W)
+    p = depth.shape[0]
+    m = None if mask is None else _c(np.asarray(mask).astype(np.uint8).reshape(-1), np.uint8)
+    args = [C.c_int64(p), _p(depth), C.c_int(1), _p(gt_depth), C.c_int(1), _p(normal), C.c_int(3), C.c_int(1),
+            _p(gtn), C.c_int(1), C.c_int(p), _p(m) if m is not None else None]
+    return p, args, (depth, gt_depth, normal, gtn, m)
+
+
+def geom_loss_fwd(depth, gt_depth, normal, gt_normal_chw, mask, dtype=np.float32):
+    """depth (H, W[, 1]), gt_depth (H, W), normal (H, W, 3), gt_normal (3, H, W), mask (H, W) -> (depth_loss,
+    normal_loss, count) of get_loss_dict :879-880"""
+    lib, pre, _ = _lib(dtype)
+    p, args, keep = _geom_args(depth, gt_depth, normal, gt_normal_chw, mask, dtype)
+    out = np.zeros(3, dtype)
+    getattr(lib, pre + "geom_loss_fwd")(*args, _p(out))
+    return out
+
+
+def geom_loss_bwd(depth, gt_depth, normal, gt_normal_chw, mask, v_depth_loss=1.0, v_normal_loss=1.0, dtype=np.float32):
+    lib, pre, RT = _lib(dtype)
+    p, args, keep = _geom_args(depth, gt_depth, normal, gt_normal_chw, mask, dtype)
+    vd, vn = np.zeros(p, dtype), np.zeros((p, 3), dtype)
+    getattr(lib, pre + "geom_loss_bwd")(*args, RT(v_depth_loss), RT(v_normal_loss), _p(vd), _p(vn))
+    return vd, vn
+
+
 def bin_and_sort(xys, depths, radii, num_tiles_hit, tile_bounds, dtype=np.float32):
     """compute_cumulative_intersects + bin_and_sort_gaussians.
     -> dict(num_intersects, cum_tiles_hit, isect_ids, gaussian_ids, isect_ids_sorted,

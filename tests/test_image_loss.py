@@ -133,3 +133,77 @@ def test_main_loss_error_behaviour():
     with pytest.raises(ValueError):
         losses.main_loss(torch.zeros(20, 20, 3, device=dev), torch.zeros(20, 20, 3, device=dev),
                          torch.ones(20, 19, dtype=torch.bool, device=dev))
+
+
+# ---- depth and normal losses (reference :879-880) -------------------------------------------------------------
+def _geom_inputs(h, w, seed, dtype=np.float32):
+    rng = np.random.default_rng(seed)
+    depth = rng.uniform(0.5, 5, (h, w, 1)).astype(dtype)
+    gt_depth = rng.uniform(0.5, 5, (h, w)).astype(dtype)
+    normal = rng.normal(size=(h, w, 3)).astype(dtype)
+    gt_normal = rng.normal(size=(3, h, w)).astype(dtype)
+    gt_normal /= np.linalg.norm(gt_normal, axis=0, keepdims=True)
+    mask = rng.uniform(size=(h, w)) > 0.3
+    normal[0, 0] = 0.0            # a zero vector: F.normalize's eps branch
+    mask[0, 0] = True
+    return depth, gt_depth, normal, gt_normal, mask
+
+
+def _reference_geom_losses(depth, gt_depth, normal, gt_normal, mask):
+    """the two lines of get_loss_dict; depth (H, W, 1), normal (H, W, 3) model outputs; gt_normal (3, H, W)"""
+    def cosine_similarity_loss(e1, e2):
+        return 1 - (F.normalize(e1, dim=0) * F.normalize(e2, dim=0)).sum(dim=0).mean()
+    n, d = normal.permute(2, 0, 1), depth.permute(2, 0, 1)
+    m = mask[None]
+    normal_loss = 0.5 * F.mse_loss(n[:, m[0]], gt_normal[:, m[0]], reduction="mean") + \
+        0.5 * cosine_similarity_loss(n[:, m[0]], gt_normal[:, m[0]])
+    depth_loss = F.l1_loss(d[m], gt_depth[None][m], reduction="mean")
+    return depth_loss, normal_loss
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_oracle_depth_normal_losses_match_torch_autograd_of_the_reference_lines(oracle, dtype):
+    h, w = 23, 31
+    depth, gt_depth, normal, gt_normal, mask = _geom_inputs(h, w, 1, dtype)
+    out = oracle.geom_loss_fwd(depth, gt_depth, normal, gt_normal, mask, dtype=dtype)
+    d, n = torch.from_numpy(depth).requires_grad_(True), torch.from_numpy(normal).requires_grad_(True)
+    dl, nl = _reference_geom_losses(d, torch.from_numpy(gt_depth), n, torch.from_numpy(gt_normal), torch.from_numpy(mask))
+    tol = 1e-12 if dtype == np.float64 else 2e-6
+    np.testing.assert_allclose(out[:2], [dl.item(), nl.item()], rtol=tol, atol=tol)
+    assert out[2] == mask.sum()
+    (1.3 * dl + 0.7 * nl).backward()
+    vd, vn = oracle.geom_loss_bwd(depth, gt_depth, normal, gt_normal, mask, 1.3, 0.7, dtype=dtype)
+    atol = 1e-15 if dtype == np.float64 else 1e-9
+    np.testing.assert_allclose(vd.reshape(h, w, 1), d.grad.numpy(), rtol=tol * 10, atol=atol)
+    np.testing.assert_allclose(vn.reshape(h, w, 3), n.grad.numpy(), rtol=tol * 10, atol=atol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,sliced", [(23, 31, False), (96, 128, True), (1200, 1600, True)])
+def test_hip_depth_normal_losses_vs_oracle(oracle, h, w, sliced):
+    from gaussiangrasper_amd import losses
+    dev = torch.device("cuda:0")
+    depth, gt_depth, normal, gt_normal, mask = _geom_inputs(h, w, 4)
+    ref = oracle.geom_loss_fwd(depth, gt_depth, normal, gt_normal, mask)
+    if sliced:      # the plugin route's outputs: channel slices of one (H, W, 7) image
+        tail = torch.zeros(h, w, 7, device=dev)
+        tail[..., 3:4] = torch.from_numpy(depth).to(dev)
+        tail[..., 4:7] = torch.from_numpy(normal).to(dev)
+        tail.requires_grad_(True)
+        d, n = tail[..., 3:4], tail[..., 4:7]
+    else:
+        d = torch.from_numpy(depth).to(dev).requires_grad_(True)
+        n = torch.from_numpy(normal).to(dev).requires_grad_(True)
+    dl, nl = losses.depth_normal_loss(d, torch.from_numpy(gt_depth).to(dev), n, torch.from_numpy(gt_normal).to(dev),
+                                      torch.from_numpy(mask).to(dev))
+    np.testing.assert_allclose([dl.item(), nl.item()], ref[:2], rtol=2e-6, atol=1e-7)
+    (1.3 * dl + 0.7 * nl).backward()
+    vd, vn = oracle.geom_loss_bwd(depth, gt_depth, normal, gt_normal, mask, 1.3, 0.7)
+    if sliced:
+        g = tail.grad.cpu().numpy()
+        got_d, got_n = g[..., 3], g[..., 4:7]
+        assert (g[..., :3] == 0).all()
+    else:
+        got_d, got_n = d.grad.cpu().numpy()[..., 0], n.grad.cpu().numpy()
+    np.testing.assert_array_equal(got_d.reshape(-1), vd)                  # bit for bit
+    np.testing.assert_array_equal(got_n.reshape(-1, 3), vn)

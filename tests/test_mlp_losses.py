@@ -106,8 +106,9 @@ def test_gpu_mlp_backward_large_row_count_uses_the_library_and_agrees():
 
 
 @gpu
-@pytest.mark.parametrize("m,c", [(1, 3), (800, 32), (1000, 512), (5000, 7)])
+@pytest.mark.parametrize("m,c", [(1, 3), (800, 32), (1000, 512), (5000, 7), (70000, 17), (1_500_000, 3)])
 def test_gpu_cosine_loss_vs_oracle_and_autograd(oracle, m, c):
+    # (1.5 M x 3: the reference's normal loss runs it on every masked pixel of the normal image, :879)
     from gaussiangrasper_amd.losses import cosine_similarity_loss
     g = torch.Generator().manual_seed(m * c)
     a, b = torch.randn(m, c, generator=g), torch.randn(m, c, generator=g)
@@ -121,7 +122,7 @@ def test_gpu_cosine_loss_vs_oracle_and_autograd(oracle, m, c):
     (ref * 1.7).backward()
     assert abs(loss.item() - ref.item()) < 3e-6
     l, sim, na, nb = oracle.cosine_loss_fwd(a.numpy(), b.numpy())
-    assert abs(loss.item() - l) < 3e-6
+    assert abs(loss.item() - l) < (3e-6 if m < 100000 else 3e-5)     # fp32 sum of m terms on both sides
     va, vb = oracle.cosine_loss_bwd(a.numpy(), b.numpy(), sim, na, nb, 1.7)
     for got, r, o in ((da.grad, ta.grad, va), (db.grad, tb.grad, vb)):
         gg = got.cpu().numpy()

@@ -530,15 +530,16 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
 // The previous generation (round 1 .. mid round 2: colour row of every Gaussian in SGPRs through scalar loads,
 // 32 fma for D on the VALU, fac parked per contributing Gaussian, one MFMA flush per 32 of them) spent 39 % of
 // its wave-cycles in s_waitcnt — every Gaussian waited for its colour row — and issued 37 % of the VALU peak
-// (profiles/r02_pmc.csv as of commit 22193a5).  Here the survivors of the quadrant cull are QUEUED in LDS (processing order =
-// descending list order) until 32 are there; for a batch
+// (profiles/r02_pmc.csv as of commit 22193a5).  Here the survivors of the quadrant cull are QUEUED in LDS
+// (processing order = descending list order) until 28..32 are there; for a batch
 //     D[64 pixels x 32 Gaussians] = V_OUT[64 x CH] * COLOUR^T[CH x 32]
 // runs as 2 x CH/2 v_mfma_f32_32x32x2_f32 (B operand: every lane loads half a colour row of ITS Gaussian with
 // vector loads, no scalar loads, nothing waited for inside the walk) and lands in the fac slab [slot][pixel];
 // the walk reads D with one ds_read per Gaussian, writes fac over it, and the batch ends with the same
 // FAC * V_OUT flush as before.  Per Gaussian the VALU loses the 32 fma and the colour-row bookkeeping; the
 // matrix pipe (idle otherwise) takes 2 x 64 cycles per Gaussian.
-// 27 left over + 64 staged (last index 90); the null records sit behind <= 27 left over.  Every byte counts:
+//
+// Queue capacity: 27 left over + 64 staged (last index 90); the null records sit behind <= 27 left over.  Every byte counts:
 // with the second array's v_out tile the workgroup needs 53 248 B of LDS, and three workgroups per CU fit only
 // up to there (the allocation granule; 54 272 B measured 2 per CU, whatever the occupancy API says)
 #define BQ_CAP 92
@@ -666,12 +667,12 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
     // vector loads of the colour half-rows need 16-byte aligned rows
     const bool vec = FULL && (C % 4 == 0) && (ch_off % 4 == 0) && ((reinterpret_cast<uintptr_t>(colors) & 15) == 0);
 
-    // one batch: queue entries [base, base + n), n <= 32 (n < 32 only for the last batch of the walk, which
-    // is followed by null records up to a multiple of GRP)
     // records of the NEXT chunk, requested between a batch's walk and its flush: the vector memory counter is
     // in order, so loads issued behind the flush's 24-32 atomic instructions wait for every one of them
     float4 ra_p = make_float4(0.f, 0.f, 0.f, 0.f), rb_p = ra_p;
-    int g_nxt = 0;
+    int g_nxt = 0;   // ids of the next chunk (loaded one chunk ahead)
+    // one batch: queue entries [base, base + n), n = 28 or 32 (fewer only for the last batch of the walk, which
+    // is followed by null records up to a multiple of GRP)
     auto run_batch = [&](const int base, const int n, const bool fetch_next) {
         // (no old value of the prefetch registers to carry through the walk)
         ra_p.x = __builtin_nondeterministic_value(ra_p.x); ra_p.y = __builtin_nondeterministic_value(ra_p.y);

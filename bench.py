@@ -314,7 +314,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
         # every parameter that enters an operator as a leaf: SH and feature rows always; means through the projection;
         # scales / quats / opacities through the plugin route's ActivateGaussians (the shim route's torch
         # activations leave those three to autograd)
-        bucket.enable_direct(ops)
+        bucket.enable_direct(ops, defer_sh=True)   # + the SH gradients of a step's views expanded once (ShadeTail)
     # cotangents resident in HBM, one set reused for every view (dense N(0,1), seeded)
     probe = render_view(scene, views[my_views[0]], ops)
     cot = seeded_cotangents(probe, seed=1234)

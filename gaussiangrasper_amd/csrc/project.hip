@@ -576,6 +576,127 @@ extern "C" int gg_sh_bwd_accumulate(int N, int K, int deg, const float *viewdirs
     return sh_dispatch(false, true, N, K, deg, viewdirs, v_colors, v_coeffs, stream);
 }
 
+// ---- deferred SH gradient: expansion of several views' colour cotangents in one pass --------------------------
+// Over the views of an optimizer step the SH gradient is sum_v Y(dir_v) (x) v_rgb_v: added view by view it is a
+// read-modify-write of 600 B per Gaussian per view (0.157 ms each at 1 M Gaussians); kept as its factors — 12 B
+// of masked colour cotangent per Gaussian and view, the view directions are there anyway — it is expanded ONCE per
+// step: 24 B read per view + 300 B written (+ 300 B read when the buffer already holds something).  Sums run over
+// the views in order, in registers, starting from the buffer's value: the bits of adding view after view.
+#define GG_SH_MULTI_VIEWS 16
+struct ShMultiArgs {
+    const float *viewdirs[GG_SH_MULTI_VIEWS];   // (N, 3) each
+    const float *v_colors[GG_SH_MULTI_VIEWS];   // (N, 3) each, already masked by the clamp
+    int num_views;
+};
+template <int K, bool ACC>
+__global__ __launch_bounds__(256) void sh_bwd_multi_kernel(int N, int deg, ShMultiArgs a,
+                                                           float *__restrict__ v_coeffs) {
+    constexpr int ROW = 3 * K;
+    __shared__ float stage[4][64 * ROW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int base = (blockIdx.x * 4 + wave) * 64;
+    if (base >= N) return;
+    const int nrows = min(64, N - base);
+    float *st = stage[wave];
+    const int i = base + lane;
+    float *dst = v_coeffs + (size_t)base * ROW;
+    if (ACC) {   // the sums continue from what the buffer holds: exactly the bits of adding view after view
+        for (int e = lane; e < nrows * ROW; e += 64) st[e] = dst[e];
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane < nrows) {
+        float acc[ROW];
+        float *row0 = st + lane * ROW;
+#pragma unroll
+        for (int e = 0; e < ROW; ++e) acc[e] = ACC ? row0[e] : 0.0f;
+        const int nb = min(sh_nbases(deg), K);
+        for (int v = 0; v < a.num_views; ++v) {
+            const float *vd = a.viewdirs[v] + 3 * (size_t)i;
+            const float *vc = a.v_colors[v] + 3 * (size_t)i;
+            float Y[GG_SH_MAX_BASES];
+            sh_basis(deg, vd[0], vd[1], vd[2], Y);
+            const float c0 = vc[0], c1 = vc[1], c2 = vc[2];
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (k < nb) {
+                    acc[3 * k + 0] = acc[3 * k + 0] + Y[k] * c0;
+                    acc[3 * k + 1] = acc[3 * k + 1] + Y[k] * c1;
+                    acc[3 * k + 2] = acc[3 * k + 2] + Y[k] * c2;
+                }
+        }
+        float *row = st + lane * ROW;
+#pragma unroll
+        for (int e = 0; e < ROW; ++e) row[e] = acc[e];
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < nrows * ROW; e += 64) dst[e] = st[e];
+}
+// the part of the tail backward that cannot wait: masked colour cotangent (kept for the expansion), depth and
+// normal cotangents (needed by the projection / activation backward of this view)
+__global__ __launch_bounds__(256) void tail_split_kernel(int N, const float *__restrict__ v_tail, int vstride,
+                                                         const uint8_t *__restrict__ mask,
+                                                         float *__restrict__ v_rgb, float *__restrict__ v_depths,
+                                                         float *__restrict__ v_normals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float *vt = v_tail + (size_t)i * vstride;
+    const unsigned m = mask[i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v_rgb[3 * (size_t)i + c] = ((m >> c) & 1u) ? vt[c] : 0.0f;
+    v_depths[i] = vt[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v_normals[3 * (size_t)i + c] = vt[4 + c];
+}
+extern "C" int gg_shade_tail_bwd_split(int N, const float *v_tail, int v_tail_stride, const uint8_t *clamp_mask,
+                                       float *v_rgb, float *v_depths, float *v_normals, gg_stream_t stream) {
+    GG_REQUIRE(N >= 0, "num_points < 0");
+    GG_REQUIRE(v_tail_stride >= 7, "v_tail rows hold 7 values");
+    if (N == 0) return GG_OK;
+    GG_REQUIRE(v_tail && clamp_mask && v_rgb && v_depths && v_normals, "null pointer");
+    hipLaunchKernelGGL(tail_split_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, v_tail,
+                       v_tail_stride, clamp_mask, v_rgb, v_depths, v_normals);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+template <int K>
+static void launch_sh_multi(bool acc, int N, int deg, const ShMultiArgs &a, float *out, hipStream_t s) {
+    dim3 grid((N + 255) / 256), block(256);
+    if (acc) hipLaunchKernelGGL((sh_bwd_multi_kernel<K, true>), grid, block, 0, s, N, deg, a, out);
+    else hipLaunchKernelGGL((sh_bwd_multi_kernel<K, false>), grid, block, 0, s, N, deg, a, out);
+}
+extern "C" int gg_sh_bwd_multi(int N, int K, int deg, int num_views, const float *const *viewdirs,
+                               const float *const *v_colors, float *v_coeffs, int accumulate, gg_stream_t stream) {
+    GG_REQUIRE(N >= 0, "num_points < 0");
+    GG_REQUIRE(K == 1 || K == 4 || K == 9 || K == 16 || K == 25, "num_bases must be 1,4,9,16,25");
+    GG_REQUIRE(deg >= 0 && sh_nbases(deg) <= K, "degrees_to_use exceeds stored bases");
+    GG_REQUIRE(num_views >= 1, "num_views < 1");
+    if (N == 0) return GG_OK;
+    GG_REQUIRE(viewdirs && v_colors && v_coeffs, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    gg_prof_begin(GG_K_SH_BWD, s);
+    for (int first = 0; first < num_views; first += GG_SH_MULTI_VIEWS) {
+        ShMultiArgs a;
+        a.num_views = min(GG_SH_MULTI_VIEWS, num_views - first);
+        for (int v = 0; v < GG_SH_MULTI_VIEWS; ++v) {
+            const int src = first + (v < a.num_views ? v : 0);
+            GG_REQUIRE(viewdirs[src] && v_colors[src], "null view pointer");
+            a.viewdirs[v] = viewdirs[src];
+            a.v_colors[v] = v_colors[src];
+        }
+        const bool acc = accumulate != 0 || first > 0;
+        switch (K) {
+            case 1: launch_sh_multi<1>(acc, N, deg, a, v_coeffs, s); break;
+            case 4: launch_sh_multi<4>(acc, N, deg, a, v_coeffs, s); break;
+            case 9: launch_sh_multi<9>(acc, N, deg, a, v_coeffs, s); break;
+            case 16: launch_sh_multi<16>(acc, N, deg, a, v_coeffs, s); break;
+            default: launch_sh_multi<25>(acc, N, deg, a, v_coeffs, s); break;
+        }
+    }
+    gg_prof_end(GG_K_SH_BWD, s);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
 template <int K>
 static void launch_tail(bool fwd, bool acc, int N, int deg, const float *viewdirs, const float *in, float *out,
                         const float *depths, const float *normals, uint8_t *mask, int vstride, float *v_depths,

@@ -80,7 +80,7 @@ class GradBucket:
         if direct is not None:
             self.enable_direct(direct)
 
-    def enable_direct(self, ops, params: Optional[Sequence[torch.Tensor]] = None) -> None:
+    def enable_direct(self, ops, params: Optional[Sequence[torch.Tensor]] = None, defer_sh: bool = False) -> None:
         """Let the operators' backward kernels add into this bucket directly (ops.register_grad_sink)
         for the given parameters (default: all) — no per-view gradient tensor and no separate add for
         the parameters that enter an operator as leaves (SH coefficients, features).  The overlapped
@@ -88,7 +88,13 @@ class GradBucket:
         index = {id(p): i for i, p in enumerate(self.params)}
         for p in (self.params if params is None else params):
             i = index[id(p)]
-            ops.register_grad_sink(p, self.slices[i].view_as(p), self._make_direct_done(i))
+            if defer_sh:
+                # the SH gradient of a view may stay in factored form until the step's last view (arm()) or until
+                # finish() / all_reduce() flush it; other operators ignore the hint
+                ops.register_grad_sink(p, self.slices[i].view_as(p), self._make_direct_done(i),
+                                       defer=lambda: not self._armed)
+            else:
+                ops.register_grad_sink(p, self.slices[i].view_as(p), self._make_direct_done(i))
         self._direct_ops = ops
 
     def _make_direct_done(self, i: int):
@@ -123,7 +129,15 @@ class GradBucket:
             self._work.append(dist.all_reduce(self.slices[i], op=dist.ReduceOp.SUM, async_op=True))
             self._next += 1
 
+    def _flush_deferred(self) -> None:
+        ops = getattr(self, "_direct_ops", None)
+        if ops is not None and hasattr(ops, "flush_grad_sinks"):
+            ops.flush_grad_sinks()
+
     def zero_(self) -> None:
+        ops = getattr(self, "_direct_ops", None)
+        if ops is not None and hasattr(ops, "discard_deferred_grads"):
+            ops.discard_deferred_grads()     # kept-but-not-expanded contributions belong to what is zeroed here
         self.flat.zero_()
 
     def arm(self) -> None:
@@ -141,6 +155,7 @@ class GradBucket:
         autograd completed the parameters, the ranks compare it, and from then on it is fixed."""
         if not self._armed:      # a rank without views this step still takes part in every collective
             self.arm()
+        self._flush_deferred()   # nothing to do when the last view's backward already expanded the kept views
         self._armed = False
         if not _dist_on():
             return
@@ -163,6 +178,7 @@ class GradBucket:
 
     def all_reduce(self) -> None:
         """Unoverlapped form: one collective over the whole bucket."""
+        self._flush_deferred()
         if _dist_on():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
 

@@ -71,21 +71,53 @@ def _workspace(nbytes: int, dev: torch.device) -> Tensor:
 # (`colors_all` into SphericalHarmonics, `feature` into NDRasterizeGaussians, as at reference
 # :730,:747-753), the backward kernel adds into that buffer itself and returns no gradient for the
 # input.  Off unless a sink is registered: plain autograd semantics otherwise.
-_grad_sinks = {}        # id(param) -> (param, buffer, notify)
+_grad_sinks = {}        # id(param) -> (param, buffer, notify, defer)
+_deferred_sh = {}       # id(param) -> [(degrees_to_use, num_bases, viewdirs, v_rgb), ...] waiting for expansion
 
 
-def register_grad_sink(param: Tensor, buffer: Tensor, notify=None) -> None:
+def register_grad_sink(param: Tensor, buffer: Tensor, notify=None, defer=None) -> None:
     """Let the backward kernels accumulate the gradient of leaf `param` straight into `buffer`
-    (same shape, fp32, contiguous); `notify(param)` is called after each accumulation is enqueued."""
+    (same shape, fp32, contiguous); `notify(param)` is called after each accumulation is enqueued.
+    `defer` (SH coefficients through ShadeTail only): a callable telling whether MORE contributions to this buffer
+    will follow before it is read (the caller is in the middle of the views of an optimizer step).  While it
+    returns True the operator keeps a view's SH gradient as its factors (12 B per Gaussian) instead of adding
+    300 B per Gaussian into the buffer, and expands all kept views in one pass when it returns False — or when
+    `flush_grad_sinks()` is called.  `notify` then fires once, after the expansion."""
     if not (param.is_leaf and param.requires_grad):
         raise ValueError("a gradient sink needs a leaf tensor that requires grad")
     if buffer.shape != param.shape or buffer.dtype != torch.float32 or not buffer.is_contiguous():
         raise ValueError("sink buffer must be a contiguous fp32 tensor of the parameter's shape")
-    _grad_sinks[id(param)] = (param, buffer, notify)
+    _grad_sinks[id(param)] = (param, buffer, notify, defer)
 
 
 def clear_grad_sinks() -> None:
     _grad_sinks.clear()
+    _deferred_sh.clear()
+
+
+def discard_deferred_grads() -> None:
+    """Forget kept-but-not-expanded contributions (the caller zeroes the gradients they belong to)."""
+    _deferred_sh.clear()
+
+
+def flush_grad_sinks() -> None:
+    """Expand every kept SH contribution into its buffer now (gg_sh_bwd_multi) and fire the sinks' `notify`."""
+    for key in list(_deferred_sh):
+        pending = _deferred_sh.pop(key)
+        sink = _grad_sinks.get(key)
+        if sink is None or not pending:
+            continue
+        param, buf, notify = sink[0], sink[1], sink[2]
+        dev = buf.device
+        lib = _lib.load()
+        deg, k = pending[0][0], pending[0][1]
+        n = buf.shape[0]
+        nv = len(pending)
+        vd = (C.c_void_p * nv)(*[_ptr(p[2]) for p in pending])
+        vc = (C.c_void_p * nv)(*[_ptr(p[3]) for p in pending])
+        _lib.check(lib.gg_sh_bwd_multi(n, k, deg, nv, vd, vc, _ptr(buf), 1, _stream(dev)), "gg_sh_bwd_multi")
+        if notify is not None:
+            notify(param)
 
 
 def _sink_for(t: Tensor):
@@ -251,7 +283,7 @@ class SphericalHarmonics(Function):
         v_colors = _f32(v_colors)
         lib = _lib.load()
         if ctx.sink is not None:      # add into the registered gradient buffer, hand autograd nothing
-            param, buf, notify = ctx.sink
+            param, buf, notify = ctx.sink[:3]
             _lib.check(lib.gg_sh_bwd_accumulate(n, ctx.num_bases, ctx.degrees_to_use, _ptr(viewdirs),
                                                 _ptr(v_colors), _ptr(buf), _stream(dev)),
                        "gg_sh_bwd_accumulate")
@@ -314,7 +346,21 @@ class ShadeTail(Function):
         v_normals = torch.empty(n, 3, dtype=torch.float32, device=dev)
         lib = _lib.load()
         if ctx.sink is not None:
-            param, buf, notify = ctx.sink
+            param, buf, notify, defer = ctx.sink
+            pending = _deferred_sh.get(id(param))
+            if defer is not None and (defer() or pending):
+                # keep this view's SH gradient as its factors; expand all kept views once (the last view of the
+                # step, or flush_grad_sinks()).  Same degree / basis count as what is already kept, or flush first
+                if pending and (pending[0][0], pending[0][1]) != (ctx.degrees_to_use, ctx.num_bases):
+                    flush_grad_sinks()
+                v_rgb = torch.empty(n, 3, dtype=torch.float32, device=dev)
+                _lib.check(lib.gg_shade_tail_bwd_split(n, _ptr(v_tail), stride, _ptr(mask), _ptr(v_rgb),
+                                                       _ptr(v_depths), _ptr(v_normals), _stream(dev)),
+                           "gg_shade_tail_bwd_split")
+                _deferred_sh.setdefault(id(param), []).append((ctx.degrees_to_use, ctx.num_bases, viewdirs, v_rgb))
+                if not defer():
+                    flush_grad_sinks()
+                return None, None, None, v_depths, v_normals
             _lib.check(lib.gg_shade_tail_bwd(n, ctx.num_bases, ctx.degrees_to_use, _ptr(viewdirs), _ptr(v_tail),
                                              stride, _ptr(mask), _ptr(buf), 1, _ptr(v_depths), _ptr(v_normals),
                                              _stream(dev)), "gg_shade_tail_bwd")
@@ -682,7 +728,7 @@ class ActivateGaussians(Function):
             opac_stride, _ptr(v_normals), _ptr(v_ls), _ptr(v_q), _ptr(v_o), 1 if ctx.sinks is not None else 0,
             _stream(dev)), "gg_activate_bwd_ex")
         if ctx.sinks is not None:
-            for param, _buf, notify in ctx.sinks:
+            for param, _buf, notify, _defer in ctx.sinks:
                 if notify is not None:
                     notify(param)
             return None, None, None, None, None

@@ -105,6 +105,18 @@ int gg_shade_tail_bwd(int num_points, int num_bases, int degrees_to_use, const f
                       const float *v_tail, int v_tail_stride, const uint8_t *clamp_mask, float *v_coeffs,
                       int accumulate, float *v_depths, float *v_normals, gg_stream_t stream);
 
+/* Deferred SH gradient over the views of an optimizer step (the views of a step accumulate into one
+ * gradient).  gg_shade_tail_bwd_split is the part of gg_shade_tail_bwd that cannot wait — v_depths, v_normals and
+ * the clamp-masked colour cotangent v_rgb (N, 3), which is KEPT instead of being expanded; gg_sh_bwd_multi expands
+ * the kept cotangents of num_views views in one pass: v_coeffs (N, num_bases, 3) = [v_coeffs +] sum_v Y(viewdirs_v)
+ * (x) v_rgb_v, the views summed in order starting from the buffer's value (the bits of adding view after view).  viewdirs /
+ * v_colors: host arrays of num_views device pointers to (N, 3) arrays.  One 300-byte write per Gaussian and step
+ * instead of a 600-byte read-modify-write per Gaussian and view. */
+int gg_shade_tail_bwd_split(int num_points, const float *v_tail, int v_tail_stride, const uint8_t *clamp_mask,
+                            float *v_rgb, float *v_depths, float *v_normals, gg_stream_t stream);
+int gg_sh_bwd_multi(int num_points, int num_bases, int degrees_to_use, int num_views, const float *const *viewdirs,
+                    const float *const *v_colors, float *v_coeffs, int accumulate, gg_stream_t stream);
+
 /* ---- quat_to_rotmat ------------------------------------------------------------------------
  * Replace gsplat `_torch_impl.quat_to_rotmat` (differentiable torch code there: ~35 elementwise
  * launches forward, ~70 backward; reference call sites gaussian_splatting.py:516,614 — the

@@ -97,3 +97,58 @@ def test_hip_shade_tail_bitexact_vs_oracle(oracle, n, k, deg):
         P.clear_grad_sinks()
     assert sh2.grad is None
     np.testing.assert_array_equal(buf.cpu().numpy(), prior + v_sh)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k,deg,views", [(5000, 25, 4, 3), (3000, 16, 3, 2), (70, 25, 4, 20)])
+def test_deferred_sh_gradient_equals_view_by_view_accumulation(oracle, n, k, deg, views):
+    """register_grad_sink(..., defer=...): ShadeTail keeps each view's SH gradient as its factors and expands all
+    kept views in one pass (gg_sh_bwd_multi) at the step's last view or at flush_grad_sinks() — bit-identical to
+    adding view after view (gg_shade_tail_bwd accumulate), also into a buffer that already holds something; the
+    depth / normal cotangents are the same either way; 20 views exercise the 16-view chunks."""
+    from gaussiangrasper_amd import ops as P
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(n + views)
+    _, coeffs, depths, normals = _inputs(n, k, seed=2)
+    dirs = []
+    for _ in range(views):
+        v = rng.standard_normal((n, 3)).astype(np.float32)
+        dirs.append(v / np.linalg.norm(v, axis=1, keepdims=True))
+    recs = [torch.from_numpy(rng.standard_normal((n, 13)).astype(np.float32)).to(dev) for _ in range(views)]
+    t = lambda a: torch.from_numpy(a).to(dev)
+
+    def run(mode):
+        sh = t(coeffs).requires_grad_(True)
+        buf = torch.full((n, k, 3), 0.375, device=dev) if n == 3000 else torch.zeros(n, k, 3, device=dev)
+        prior = buf.clone()
+        fired = []
+        state = {"more": True}
+        P.clear_grad_sinks()
+        if mode == "immediate":
+            P.register_grad_sink(sh, buf, lambda p: fired.append(1))
+        else:
+            P.register_grad_sink(sh, buf, lambda p: fired.append(1), defer=lambda: state["more"])
+        side = []
+        try:
+            for v in range(views):
+                d, nr = t(depths).requires_grad_(True), t(normals).requires_grad_(True)
+                if mode == "last-view":
+                    state["more"] = v < views - 1
+                P.ShadeTail.apply(deg, t(dirs[v]), sh, d, nr).backward(recs[v][:, 6:])
+                side.append((d.grad.clone(), nr.grad.clone()))
+            if mode == "flush":
+                assert len(fired) == 0 and torch.equal(buf, prior)            # nothing expanded yet
+                P.flush_grad_sinks()
+        finally:
+            P.clear_grad_sinks()
+        assert sh.grad is None
+        return buf.cpu().numpy(), fired, side
+
+    ref, fired_ref, side_ref = run("immediate")
+    assert len(fired_ref) == views
+    for mode in ("last-view", "flush"):
+        got, fired, side = run(mode)
+        np.testing.assert_array_equal(got, ref)
+        assert len(fired) == 1
+        for (d0, n0), (d1, n1) in zip(side_ref, side):
+            assert torch.equal(d0, d1) and torch.equal(n0, n1)

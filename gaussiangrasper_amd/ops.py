@@ -283,7 +283,17 @@ class SphericalHarmonics(Function):
         v_colors = _f32(v_colors)
         lib = _lib.load()
         if ctx.sink is not None:      # add into the registered gradient buffer, hand autograd nothing
-            param, buf, notify = ctx.sink[:3]
+            param, buf, notify, defer = ctx.sink
+            pending = _deferred_sh.get(id(param))
+            if defer is not None and (defer() or pending):
+                # keep (view directions, colour cotangent) and expand the step's views in one pass (see ShadeTail)
+                if pending and (pending[0][0], pending[0][1]) != (ctx.degrees_to_use, ctx.num_bases):
+                    flush_grad_sinks()
+                _deferred_sh.setdefault(id(param), []).append((ctx.degrees_to_use, ctx.num_bases, viewdirs,
+                                                               v_colors))
+                if not defer():
+                    flush_grad_sinks()
+                return None, None, None
             _lib.check(lib.gg_sh_bwd_accumulate(n, ctx.num_bases, ctx.degrees_to_use, _ptr(viewdirs),
                                                 _ptr(v_colors), _ptr(buf), _stream(dev)),
                        "gg_sh_bwd_accumulate")

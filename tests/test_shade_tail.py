@@ -152,3 +152,34 @@ def test_deferred_sh_gradient_equals_view_by_view_accumulation(oracle, n, k, deg
         assert len(fired) == 1
         for (d0, n0), (d1, n1) in zip(side_ref, side):
             assert torch.equal(d0, d1) and torch.equal(n0, n1)
+
+
+@pytest.mark.gpu
+def test_deferred_sh_gradient_through_the_shim_routes_operator(oracle):
+    """the same deferral in ops.SphericalHarmonics (the shim route: the caller's clamp sits behind the operator, its
+    backward hands over the already masked colour cotangent)"""
+    from gaussiangrasper_amd import ops as P
+    dev = torch.device("cuda:0")
+    n, k, deg, views = 4000, 25, 4, 4
+    rng = np.random.default_rng(1)
+    _, coeffs, _, _ = _inputs(n, k, seed=6)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    dirs = [rng.standard_normal((n, 3)).astype(np.float32) for _ in range(views)]
+    cots = [t(rng.standard_normal((n, 3)).astype(np.float32)) for _ in range(views)]
+
+    def run(deferred):
+        sh = t(coeffs).requires_grad_(True)
+        buf = torch.zeros(n, k, 3, device=dev)
+        state = {"more": True}
+        P.clear_grad_sinks()
+        P.register_grad_sink(sh, buf, None, defer=(lambda: state["more"]) if deferred else None)
+        try:
+            for v in range(views):
+                state["more"] = v < views - 1
+                rgb = torch.clamp(P.SphericalHarmonics.apply(deg, t(dirs[v]), sh) + 0.5, 0.0, 1.0)
+                rgb.backward(cots[v])
+        finally:
+            P.clear_grad_sinks()
+        return buf.cpu().numpy()
+
+    np.testing.assert_array_equal(run(True), run(False))

@@ -1094,3 +1094,65 @@ def test_split_segment_returns_channel_slices_and_takes_separate_cotangents(orac
             assert_bitexact(_np(img), _np(whole[1])[..., b:e], f"tail image channels {b}:{e}")
         for name, a, b in zip(("v_xy", "v_conic", "v_opacity", "v_feature", "v_tail"), g_parts, g_whole):
             assert_close(a, b, f"split cotangents vs concatenated: {name}", rtol=5e-5, atol_frac=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c,c2", [(32, 1), (32, 8), (35, 4), (64, 7), (33, 2)])
+def test_pair_kernels_channel_counts(oracle, c, c2):
+    """gg_blend_fwd_pair / gg_blend_bwd_pair for 1..8 rider channels and first arrays of 32, 33, 35 and 64 channels
+    (the channels past 32 take their own walks) on an image that is not a multiple of the tile: images bit-exact,
+    gradients within the blend tolerance of the oracle's separate calls"""
+    n, h, w = 6000, 77, 101
+    xys, depths, radii, conics, nth, colors, opac, bg = _blend_inputs(oracle, n, h, w, c + c2, seed=31)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    rng = np.random.default_rng(c * 10 + c2)
+    segs = [(colors[:, :c], bg[:c]), (colors[:, c:], bg[c:])]
+    ref_imgs, v_outs, ref_g = [], [], None
+    for col, b in segs:
+        out, saved = oracle.rasterize_fwd(xys, depths, radii, conics, nth, col, opac, h, w, b)
+        v = rng.standard_normal(out.shape).astype(np.float32)
+        bb = saved["bins"]
+        g = oracle.blend_bwd(bb["gaussian_ids_sorted"], bb["tile_bins"], xys, conics, col, opac, h, w, b,
+                             saved["final_Ts"], saved["final_idx"], v)
+        ref_imgs.append(out)
+        v_outs.append(v)
+        ref_g = [g[0].astype(np.float64), g[1].astype(np.float64), [g[2]], g[3].astype(np.float64)] if ref_g is None \
+            else [ref_g[0] + g[0], ref_g[1] + g[1], ref_g[2] + [g[2]], ref_g[3] + g[3]]
+    xt, ct, ot = t(xys).requires_grad_(True), t(conics).requires_grad_(True), t(opac).requires_grad_(True)
+    cts = [t(col).requires_grad_(True) for col, _ in segs]
+    P.clear_bin_cache()
+    imgs = P.rasterize_segments(xt, t(depths), t(radii), ct, t(nth), ot, h, w,
+                                [(cts[i], t(segs[i][1])) for i in range(2)])
+    for i in range(2):
+        assert_bitexact(_np(imgs[i]), ref_imgs[i], f"pair image {i} (C={c}, C2={c2})")
+    torch.autograd.backward(imgs, [t(v) for v in v_outs])
+    assert_close(_np(xt.grad), ref_g[0], "pair.v_xy", rtol=5e-5, atol_frac=1e-6)
+    assert_close(_np(ct.grad), ref_g[1], "pair.v_conic", rtol=5e-5, atol_frac=1e-6)
+    assert_close(_np(ot.grad), ref_g[3].reshape(_np(ot.grad).shape), "pair.v_opacity", rtol=5e-5, atol_frac=1e-6)
+    for i in range(2):
+        assert_close(_np(cts[i].grad), ref_g[2][i], f"pair.v_colors[{i}]", rtol=5e-5, atol_frac=1e-6)
+
+
+@pytest.mark.gpu
+def test_shade_tail_and_split_segments_edge_cases():
+    """an empty scene through ShadeTail; a split rider segment with nothing visible returns the background slices
+    and zero gradients for separate cotangents"""
+    empty = P.ShadeTail.apply(4, torch.zeros(0, 3, device=DEV), torch.zeros(0, 25, 3, device=DEV, requires_grad=True),
+                              torch.zeros(0, device=DEV), torch.zeros(0, 3, device=DEV))
+    assert tuple(empty.shape) == (0, 7)
+    n, h, w = 64, 32, 48
+    sc = make_scene(n, feature_dim=32, config_index=13).to(DEV)
+    v = ring_cameras(2, h, w, device=DEV)[0]
+    means = (sc.means - 100.0 * (v.viewmat[2, :3])).requires_grad_(True)
+    xys, depths, radii, conics, nth, _ = P.ProjectGaussians.apply(
+        means, sc.scales.exp(), 1, sc.quats, v.viewmat[:3], v.projmat, v.fx, v.fy, v.cx, v.cy, h, w, v.tile_bounds)
+    feat = sc.feature.clone().requires_grad_(True)
+    tail = torch.rand(n, 7, device=DEV, requires_grad=True)
+    bg = torch.arange(7, device=DEV, dtype=torch.float32)
+    P.clear_bin_cache()
+    f_im, rgb, depth, normal = P.rasterize_segments(xys, depths, radii, conics, nth, torch.sigmoid(sc.opacities), h, w,
+                                                    [(feat, torch.zeros(32, device=DEV)), (tail, bg, (3, 1, 3))])
+    assert torch.equal(rgb, bg[:3].expand(h, w, 3)) and torch.equal(depth, bg[3:4].expand(h, w, 1))
+    assert torch.equal(normal, bg[4:].expand(h, w, 3)) and not f_im.any()
+    (rgb.sum() + normal.sum()).backward()
+    assert not feat.grad.any() and not tail.grad.any()

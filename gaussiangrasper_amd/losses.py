@@ -184,3 +184,16 @@ def depth_normal_loss(depth: Tensor, gt_depth: Tensor, normal: Tensor, gt_normal
     depth3 = depth if depth.dim() == 3 else depth.reshape(h, w, 1)
     gd = gt_depth.reshape(h, w) if gt_depth.is_contiguous() else gt_depth.contiguous().reshape(h, w)
     return _DepthNormalLoss.apply(depth3, gd, normal, gt_normal, depth_mask, h, w)
+
+
+def gather_pixels(image: Tensor, *pixel_sets: Tensor):
+    """Rows of a (H, W, C) image at several sets of (row, col) pixel coordinates — the reference's
+    `feature[selected_pairs[i][0][:, 0], selected_pairs[i][0][:, 1]]` / `feature[selected_points[:, 0], ...]`
+    (gaussian_splatting.py:912-917), one advanced-indexing gather per set there, each of whose backward allocates
+    and zero-fills a whole (H, W, C) gradient image (61 MB at 1600x1200x32), scatters into it and is then added to
+    the others.  Here ALL sets go through ONE gather (one index_select over the concatenated flat indices), so the
+    backward is one zero-fill and one scatter.  Returns one (M_k, C) tensor per set.  Plain torch: no kernel."""
+    h, w, c = image.shape
+    flat = [(p[:, 0].long() * w + p[:, 1].long()) for p in pixel_sets]
+    rows = image.reshape(h * w, c).index_select(0, torch.cat(flat))
+    return torch.split(rows, [f.numel() for f in flat], dim=0)

@@ -128,3 +128,22 @@ def test_gpu_cosine_loss_vs_oracle_and_autograd(oracle, m, c):
         gg = got.cpu().numpy()
         assert np.allclose(gg, r.numpy(), rtol=2e-5, atol=1e-9)
         assert np.allclose(gg, o, rtol=2e-5, atol=1e-9)
+
+
+def test_gather_pixels_equals_the_references_advanced_indexing():
+    """losses.gather_pixels: values and gradients of the reference's per-set gathers (:912-917), through one
+    index_select (pure torch; runs on the CPU)"""
+    from gaussiangrasper_amd.losses import gather_pixels
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(20, 30, 5, generator=g).requires_grad_(True)
+    sets = [torch.stack([torch.randint(0, 20, (m,), generator=g), torch.randint(0, 30, (m,), generator=g)], 1)
+            for m in (7, 4, 9)]
+    rows = gather_pixels(img, *sets)
+    ref = [img[s[:, 0], s[:, 1]] for s in sets]
+    for a, b in zip(rows, ref):
+        assert torch.equal(a, b)
+    w = [2.0, 1.0, -0.5]
+    sum(wi * r.sum() for wi, r in zip(w, rows)).backward()
+    got, img.grad = img.grad.clone(), None
+    sum(wi * r.sum() for wi, r in zip(w, ref)).backward()
+    assert torch.allclose(got, img.grad)

@@ -74,7 +74,7 @@ def main():
     fea_up_torch.load_state_dict({k.replace("layers.", ""): v for k, v in fea_up.state_dict().items()})
 
     bucket = GradBucket(scene.params())
-    bucket.enable_direct(ops)
+    bucket.enable_direct(ops, defer_sh=True)     # as bench.py: the SH gradient of the step's views expanded once
     names = ("means", "scales", "quats", "opacities", "colors_all", "feature")
 
     def optimizers(cls):
@@ -84,7 +84,9 @@ def main():
     def iteration(fused: bool, opts):
         bucket.zero_()
         opts[-1].zero_grad(set_to_none=True)        # fea_up's parameters (the Gaussians' gradients live in the bucket)
-        for v in views:
+        for k, v in enumerate(views):
+            if k == len(views) - 1:
+                bucket.arm()                          # the step's last backward
             out = render_view(scene, v, ops, fused=True)
             rgb, depth, normal, feature = out["rgb"], out["depth"], out["normal"], out["feature"]
             if fused:
@@ -98,12 +100,17 @@ def main():
                 depth_l = F.l1_loss(depth[depth_mask], gt_depth[depth_mask])
                 nrm, gtn = normal.permute(2, 0, 1)[:, depth_mask], gt_normal_chw[:, depth_mask]
                 normal_l = 0.5 * F.mse_loss(nrm, gtn) + 0.5 * cos(nrm, gtn)
-            f1 = feature[pairs[0][:, 0], pairs[0][:, 1]]
-            f2 = feature[pairs[1][:, 0], pairs[1][:, 1]]
+            if fused:       # one gather (one zero-filled gradient image in the backward) for all sampled sets
+                f1, f2, fp = losses.gather_pixels(feature, pairs[0], pairs[1], pts)
+            else:           # the reference's three advanced-indexing gathers (:912-917)
+                f1 = feature[pairs[0][:, 0], pairs[0][:, 1]]
+                f2 = feature[pairs[1][:, 0], pairs[1][:, 1]]
+                fp = feature[pts[:, 0], pts[:, 1], :]
             fea_l = cos(f1.permute(1, 0), f2.permute(1, 0))
-            up = (fea_up if fused else fea_up_torch)(feature[pts[:, 0], pts[:, 1], :]).permute(1, 0)
+            up = (fea_up if fused else fea_up_torch)(fp).permute(1, 0)
             up_l = cos(up, gt_fea)
             (main_l + depth_l + normal_l + fea_l + up_l).backward()
+        bucket.finish()
         if fused:
             fused_step(opts)
         else:

@@ -65,8 +65,8 @@ SIGNATURES = {
     "gg_shade_tail_bwd_split": (_I, [_I, _P, _I, _P, _P, _P, _P, _P]),
     "gg_sh_bwd_multi": (_I, [_I, _I, _I, _I, C.POINTER(_P), C.POINTER(_P), _P, _I, _P]),
     "gg_image_loss_workspace": (_SZ, [_I, _I]),
-    "gg_image_loss_fwd": (_I, [_I, _I, _P, _P, _P, _F, _P, _P, _SZ, _P]),
-    "gg_image_loss_bwd": (_I, [_I, _I, _P, _P, _P, _F, _P, _P, _SZ, _P, _P]),
+    "gg_image_loss_fwd": (_I, [_I, _I, _P, _I, _P, _P, _F, _P, _P, _SZ, _P]),
+    "gg_image_loss_bwd": (_I, [_I, _I, _P, _I, _P, _P, _F, _P, _P, _SZ, _P, _P]),
     "gg_geom_loss_workspace": (_SZ, []),
     "gg_geom_loss_fwd": (_I, [_I64, _P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _SZ, _P]),
     "gg_geom_loss_bwd": (_I, [_I64, _P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _SZ, _P, _P, _P]),

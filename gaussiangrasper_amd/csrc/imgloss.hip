@@ -45,7 +45,7 @@ __device__ __forceinline__ float il_ssim_point(const float *m, float &g_b, float
     return L * CS;
 }
 
-__global__ __launch_bounds__(256) void image_loss_fwd_kernel(int H, int W, const float *__restrict__ rgb,
+__global__ __launch_bounds__(256) void image_loss_fwd_kernel(int H, int W, const float *__restrict__ rgb, int rs,
                                                              const float *__restrict__ gt,
                                                              const uint8_t *__restrict__ valid, IlWindow win,
                                                              double *__restrict__ partials,
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void image_loss_fwd_kernel(int H, int W, const
             const size_t p = (size_t)y * W + x;
             if (!valid || valid[p]) {
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) { vx[ch] = gt[3 * p + ch]; vy[ch] = rgb[3 * p + ch]; }
+                for (int ch = 0; ch < 3; ++ch) { vx[ch] = gt[3 * p + ch]; vy[ch] = rgb[(size_t)rs * p + ch]; }
             }
         }
 #pragma unroll
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void image_loss_fwd_kernel(int H, int W, const
             const size_t p = (size_t)y * W + x;
             if (!valid || valid[p]) {
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) l1 += (double)fabsf(gt[3 * p + ch] - rgb[3 * p + ch]);
+                for (int ch = 0; ch < 3; ++ch) l1 += (double)fabsf(gt[3 * p + ch] - rgb[(size_t)rs * p + ch]);
                 cnt = 3.0;
             }
         }
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void image_loss_finish_kernel(int nblocks, int
     }
 }
 
-__global__ __launch_bounds__(256) void image_loss_bwd_kernel(int H, int W, const float *__restrict__ rgb,
+__global__ __launch_bounds__(256) void image_loss_bwd_kernel(int H, int W, const float *__restrict__ rgb, int rs,
                                                              const float *__restrict__ gt,
                                                              const uint8_t *__restrict__ valid, IlWindow win,
                                                              float ssim_lambda, const float *__restrict__ v_main,
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void image_loss_bwd_kernel(int H, int W, const
 #pragma unroll
             for (int k = 0; k < 3; ++k) G[k] += w * hb[3 * ch + k][ty + (IL_WIN - 1) - a][tx];
         }
-        const float Y = rgb[3 * p + ch], X = gt[3 * p + ch];
+        const float Y = rgb[(size_t)rs * p + ch], X = gt[3 * p + ch];
         const float d = Y - X;
         const float sgn = d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.0f);
         v_rgb[3 * p + ch] = ks * (G[0] + 2 * Y * G[1] + X * G[2]) + kl * sgn;
@@ -251,9 +251,11 @@ extern "C" size_t gg_image_loss_workspace(int img_height, int img_width) {
            gg_align_up(sizeof(float) * 9 * Ho * Wo, 256);
 }
 
-extern "C" int gg_image_loss_fwd(int H, int W, const float *rgb, const float *gt, const uint8_t *valid,
-                                 float ssim_lambda, float *out3, void *ws, size_t ws_bytes, gg_stream_t stream) {
+extern "C" int gg_image_loss_fwd(int H, int W, const float *rgb, int rgb_pixel_stride, const float *gt,
+                                 const uint8_t *valid, float ssim_lambda, float *out3, void *ws, size_t ws_bytes,
+                                 gg_stream_t stream) {
     GG_REQUIRE(H >= IL_WIN && W >= IL_WIN, "image smaller than the 11 x 11 SSIM window");
+    GG_REQUIRE(rgb_pixel_stride >= 3, "rgb pixels hold 3 values");
     GG_REQUIRE(rgb && gt && out3, "null pointer");
     if (ws == nullptr || ws_bytes < gg_image_loss_workspace(H, W)) {
         gg_set_error("gg_image_loss_fwd: workspace too small");
@@ -265,18 +267,19 @@ extern "C" int gg_image_loss_fwd(int H, int W, const float *rgb, const float *gt
     const size_t nblk = il_blocks(H, W);
     float *maps = (float *)((char *)ws + gg_align_up(sizeof(double) * (IL_HEADER + 3 * nblk), 256));
     const dim3 grid((W + IL_T - 1) / IL_T, (H + IL_T - 1) / IL_T);
-    hipLaunchKernelGGL(image_loss_fwd_kernel, grid, dim3(256), 0, s, H, W, rgb, gt, valid, il_window(), partials,
-                       maps);
+    hipLaunchKernelGGL(image_loss_fwd_kernel, grid, dim3(256), 0, s, H, W, rgb, rgb_pixel_stride, gt, valid,
+                       il_window(), partials, maps);
     hipLaunchKernelGGL(image_loss_finish_kernel, dim3(1), dim3(256), 0, s, (int)nblk, H - IL_WIN + 1,
                        W - IL_WIN + 1, ssim_lambda, partials, header, out3);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
 
-extern "C" int gg_image_loss_bwd(int H, int W, const float *rgb, const float *gt, const uint8_t *valid,
-                                 float ssim_lambda, const float *v_main, const void *ws, size_t ws_bytes,
-                                 float *v_rgb, gg_stream_t stream) {
+extern "C" int gg_image_loss_bwd(int H, int W, const float *rgb, int rgb_pixel_stride, const float *gt,
+                                 const uint8_t *valid, float ssim_lambda, const float *v_main, const void *ws,
+                                 size_t ws_bytes, float *v_rgb, gg_stream_t stream) {
     GG_REQUIRE(H >= IL_WIN && W >= IL_WIN, "image smaller than the 11 x 11 SSIM window");
+    GG_REQUIRE(rgb_pixel_stride >= 3, "rgb pixels hold 3 values");
     GG_REQUIRE(rgb && gt && v_main && v_rgb, "null pointer");
     if (ws == nullptr || ws_bytes < gg_image_loss_workspace(H, W)) {
         gg_set_error("gg_image_loss_bwd: workspace too small (it must be the forward's)");
@@ -286,8 +289,8 @@ extern "C" int gg_image_loss_bwd(int H, int W, const float *rgb, const float *gt
     const size_t nblk = il_blocks(H, W);
     const float *maps = (const float *)((const char *)ws + gg_align_up(sizeof(double) * (IL_HEADER + 3 * nblk), 256));
     const dim3 grid((W + IL_T - 1) / IL_T, (H + IL_T - 1) / IL_T);
-    hipLaunchKernelGGL(image_loss_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, rgb, gt, valid,
-                       il_window(), ssim_lambda, v_main, header, maps, v_rgb);
+    hipLaunchKernelGGL(image_loss_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, rgb, rgb_pixel_stride,
+                       gt, valid, il_window(), ssim_lambda, v_main, header, maps, v_rgb);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }

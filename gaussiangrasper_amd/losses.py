@@ -67,7 +67,13 @@ class _MainLoss(Function):
         h, w = rgb.shape[:2]
         if h < 11 or w < 11:
             raise ValueError("image smaller than the 11 x 11 SSIM window")
-        r, g = _f32(rgb), _f32(gt)
+        # the plugin route's rgb image is a channel slice of the (H, W, 7) image: read in place
+        if rgb.dtype == torch.float32 and rgb.stride(2) == 1 and rgb.stride(1) >= 3 and rgb.stride(0) == w * rgb.stride(1):
+            r = rgb
+        else:
+            r = _f32(rgb)
+        rs = r.stride(1)
+        g = _f32(gt)
         if valid is not None:
             if tuple(valid.shape) != (h, w):
                 raise ValueError("valid_mask must be (H, W)")
@@ -75,7 +81,7 @@ class _MainLoss(Function):
         lib = _lib.load()
         ws = torch.empty(lib.gg_image_loss_workspace(h, w), dtype=torch.uint8, device=dev)
         out3 = torch.empty(3, dtype=torch.float32, device=dev)
-        _lib.check(lib.gg_image_loss_fwd(h, w, _ptr(r), _ptr(g), _ptr(valid) if valid is not None else None,
+        _lib.check(lib.gg_image_loss_fwd(h, w, _ptr(r), rs, _ptr(g), _ptr(valid) if valid is not None else None,
                                          float(ssim_lambda), _ptr(out3), _ptr(ws), ws.numel(), _stream(dev)),
                    "gg_image_loss_fwd")
         ctx.save_for_backward(r, g, ws) if valid is None else ctx.save_for_backward(r, g, ws, valid)
@@ -91,9 +97,10 @@ class _MainLoss(Function):
         valid = saved[3] if len(saved) > 3 else None
         dev = r.device
         h, w = r.shape[:2]
-        v_rgb = torch.empty_like(r)
+        v_rgb = torch.empty(h, w, 3, dtype=torch.float32, device=dev)
         vm = _f32(v_main).reshape(1)
-        _lib.check(_lib.load().gg_image_loss_bwd(h, w, _ptr(r), _ptr(g), _ptr(valid) if valid is not None else None,
+        _lib.check(_lib.load().gg_image_loss_bwd(h, w, _ptr(r), r.stride(1), _ptr(g),
+                                                 _ptr(valid) if valid is not None else None,
                                                  ctx.ssim_lambda, _ptr(vm), _ptr(ws), ws.numel(), _ptr(v_rgb),
                                                  _stream(dev)), "gg_image_loss_bwd")
         return v_rgb, None, None, None

@@ -305,16 +305,18 @@ int gg_cosine_loss_bwd(int64_t num_points, int channels, const float *a, const f
  * pytorch_msssim.SSIM(data_range=1.0, size_average=True, channel=3), requirements.txt:199):
  *     Ll1 = abs(gt[valid] - rgb[valid]).mean();  gt[~valid] = 0;  rgb[~valid] = 0;
  *     main_loss = (1 - ssim_lambda) * Ll1 + ssim_lambda * (1 - ssim(gt, rgb))
- * rgb, gt (H, W, 3) fp32; valid (H, W) bytes or NULL (all valid).  out3 = {main_loss, Ll1, ssim} (device).
+ * rgb, gt (H, W, 3) fp32, rgb with rgb_pixel_stride >= 3 floats between pixels (a channel slice of a wider image
+ * is read in place); valid (H, W) bytes or NULL (all valid).  out3 = {main_loss, Ll1, ssim} (device).
  * The forward leaves what the backward needs (three derivative maps per channel, the valid count) in `ws`
  * (gg_image_loss_workspace bytes); the backward takes the SAME workspace, untouched, and v_main (1 float, device)
  * and writes v_rgb (H, W, 3) = v_main * d main_loss / d rgb, zero at invalid pixels.  H, W >= 11. */
 size_t gg_image_loss_workspace(int img_height, int img_width);
-int gg_image_loss_fwd(int img_height, int img_width, const float *rgb, const float *gt, const uint8_t *valid,
-                      float ssim_lambda, float *out3, void *ws, size_t ws_bytes, gg_stream_t stream);
-int gg_image_loss_bwd(int img_height, int img_width, const float *rgb, const float *gt, const uint8_t *valid,
-                      float ssim_lambda, const float *v_main, const void *ws, size_t ws_bytes, float *v_rgb,
+int gg_image_loss_fwd(int img_height, int img_width, const float *rgb, int rgb_pixel_stride, const float *gt,
+                      const uint8_t *valid, float ssim_lambda, float *out3, void *ws, size_t ws_bytes,
                       gg_stream_t stream);
+int gg_image_loss_bwd(int img_height, int img_width, const float *rgb, int rgb_pixel_stride, const float *gt,
+                      const uint8_t *valid, float ssim_lambda, const float *v_main, const void *ws, size_t ws_bytes,
+                      float *v_rgb, gg_stream_t stream);
 
 /* Depth and normal losses of get_loss_dict (gaussian_splatting.py:879-880) over the pixels where mask != 0:
  *     depth_loss  = F.l1_loss(depth[m], gt_depth[m])

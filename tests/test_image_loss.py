@@ -82,12 +82,22 @@ def test_hip_main_loss_vs_oracle(oracle, h, w, masked):
     g = torch.from_numpy(gt).to(dev)
     vm = None if valid is None else torch.from_numpy(valid).to(dev)
     g_before = g.clone()
+    if masked:      # the plugin route's rgb: channels 0..2 of an (H, W, 7) image, read in place
+        wide = torch.zeros(h, w, 7, device=dev)
+        wide[..., :3] = r.detach()
+        wide.requires_grad_(True)
+        m2 = losses.main_loss(wide[..., :3], g, vm, lam)[0]
+        (m2 * 1.7).backward()
+        sliced_grad = wide.grad[..., :3].clone()
+        assert not wide.grad[..., 3:].any()
     main, l1, ssim = losses.main_loss(r, g, vm, lam)
     np.testing.assert_allclose([main.item(), l1.item(), ssim.item()], ref, rtol=2e-6, atol=1e-7)
     assert not l1.requires_grad and not ssim.requires_grad
     (main * 1.7).backward()
     v_ref = oracle.image_loss_bwd(rgb, gt, valid, lam, 1.7)
     np.testing.assert_array_equal(r.grad.cpu().numpy(), v_ref)          # bit for bit
+    if masked:
+        assert m2.item() == main.item() and torch.equal(sliced_grad, r.grad)
     assert torch.equal(g, g_before) and torch.equal(r.detach().cpu(), torch.from_numpy(rgb))   # no side effects
     # and the caller's torch ops on the same device agree
     r2 = torch.from_numpy(rgb).to(dev).requires_grad_(True)

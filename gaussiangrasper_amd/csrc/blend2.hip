@@ -564,8 +564,13 @@ struct Seg2B {
 // the second array's v_out tile (64 pixels x 8) sits in LDS, and its colour gradients are a second, small flush
 // (FAC[32 x 64] * V_OUT2[64 x 8] as v_mfma_f32_16x16x4_f32).  What the plugin route's feature | rgb+depth+normal
 // operator uses: one backward walk per view instead of two.
-template <bool FULL, int ABL = 0, int CHD = 32, bool DET = false, bool EX = false>
-__global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
+// LEAN (measured, not launched: kept as the starting point for a 2-Gaussians-per-iteration walk): the build for
+// FOUR resident workgroups per CU instead of three.  Needs <= 128 VGPRs — the quadrant's cotangents are not held in
+// registers (64 of them) but re-read from the cache-resident image at every batch — and <= 40 960 B of LDS:
+// batches of 28 slots (slab 7 280 B).  It gets its four workgroups (40 896 B, 128 VGPRs), but the walk of four
+// Gaussians at a time alone wants more than 128 registers: 81 spilled, 1.50 ms against 1.00.
+template <bool FULL, int ABL = 0, int CHD = 32, bool DET = false, bool EX = false, bool LEAN = false>
+__global__ __launch_bounds__(256, LEAN ? 4 : 3) void blend2_bwd_wide_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
     const float *__restrict__ colors, const float *__restrict__ background,
@@ -574,13 +579,15 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
     float *__restrict__ v_colors, float *__restrict__ v_opacity, int gstride, int cstride,
     DetSlab det = DetSlab(), Seg2B seg2 = Seg2B()) {
     static_assert(!EX || (FULL && CHD == 32 && !DET), "the second array rides on the full 32-channel build");
+    static_assert(!LEAN || (!EX && !DET), "LEAN: plain builds only (so far)");
+    constexpr int NSLOT = LEAN ? 28 : B2_SLOTS;
     constexpr int CH = CHD;
     constexpr int KS = CHD / 2;     // k-steps of the D product; lane half h supplies channels [KS h, KS h + KS)
     constexpr int KG = 6;
     constexpr int KB = GRP * KG;
     using R = Red6<KB>;
     __shared__ WaveQueue queues[4];
-    __shared__ float s_fac[4][B2_SLOTS * 65];
+    __shared__ float s_fac[4][NSLOT * 65];
     __shared__ int s_slote[4][DET ? B2_SLOTS : 1];
     __shared__ __attribute__((aligned(16))) float s_vt[4][EX ? 64 * 8 : 4];   // EX: V_OUT2[pixel][8]
 
@@ -630,26 +637,39 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
     }
     const int wch = lane & 31, half = lane >> 5;
     const bool wch_ok = FULL || wch < nch;
-    // D product, A operands: V_OUT[pixel (lane & 31) + 32 c][channel KS half + s]
-    float voa[2][KS];
+    // D product, A operands: V_OUT[pixel (lane & 31) + 32 c][channel KS half + s];
+    // flush, B operands:     V_OUT[pixel 2s + half][channel wch]
+    auto load_voa = [&](const float *vo, float (&dst)[2][KS]) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int pm = (lane & 31) + 32 * c;
-        const int pj = qx0 + (pm & 7), pi = qy0 + (pm >> 3);
-        const bool pin = (pi < img_h) && (pj < img_w);
+        for (int c = 0; c < 2; ++c) {
+            const int pm = (lane & 31) + 32 * c;
+            const int pj = qx0 + (pm & 7), pi = qy0 + (pm >> 3);
+            const bool pin = (pi < img_h) && (pj < img_w);
+            const float *row = vo + ((size_t)(pin ? pi : 0) * img_w + (pin ? pj : 0)) * C + ch_off + KS * half;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int ch = KS * half + s;
-            voa[c][s] = (pin && (FULL || ch < nch)) ? v_out[((size_t)pi * img_w + pj) * C + ch_off + ch] : 0.0f;
+            for (int s = 0; s < KS; ++s) dst[c][s] = (pin && (FULL || KS * half + s < nch)) ? row[s] : 0.0f;
         }
-    }
-    float vob[32];  // flush, B operands: V_OUT[pixel 2s + half][channel wch]
+    };
+    auto load_vob = [&](const float *vo, float (&dst)[32]) {
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-        const int pq = 2 * s + half;
-        const int pj = qx0 + (pq & 7), pi = qy0 + (pq >> 3);
-        const bool ok = (pi < img_h) && (pj < img_w) && wch_ok;
-        vob[s] = ok ? v_out[((size_t)pi * img_w + pj) * C + ch_off + wch] : 0.0f;
+        for (int s = 0; s < 32; ++s) {
+            const int pq = 2 * s + half;
+            const int pj = qx0 + (pq & 7), pi = qy0 + (pq >> 3);
+            const bool ok = (pi < img_h) && (pj < img_w) && wch_ok;
+            dst[s] = ok ? vo[((size_t)pi * img_w + pj) * C + ch_off + wch] : 0.0f;
+        }
+    };
+    float voa_keep[2][LEAN ? 1 : KS], vob_keep[LEAN ? 1 : 32];
+    if (!LEAN) {
+        float ta[2][KS], tb[32];
+        load_voa(v_out, ta);
+        load_vob(v_out, tb);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) voa_keep[c][LEAN ? 0 : s] = ta[c][s];
+#pragma unroll
+        for (int s = 0; s < 32; ++s) vob_keep[LEAN ? 0 : s] = tb[s];
     }
     int hi = fin;
     for (int off = 32; off > 0; off >>= 1) hi = max(hi, __shfl_xor(hi, off, 64));
@@ -707,6 +727,17 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
                 va0 = *reinterpret_cast<const float4 *>(vt + (lane & 31) * 8 + 4 * half);
                 va1 = *reinterpret_cast<const float4 *>(vt + ((lane & 31) + 32) * 8 + 4 * half);
             }
+            float voa[2][KS];
+            if (LEAN) {
+                const float *vo = v_out;
+                asm volatile("" : "+s"(vo));     // a fresh read per batch: not to be hoisted back into registers
+                load_voa(vo, voa);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) voa[c][s] = voa_keep[c][LEAN ? 0 : s];
+            }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const float bv = cgid < 0 ? 0.0f : colb[s];
@@ -728,8 +759,10 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int pix = (r & 3) + 8 * (r >> 2) + 4 * half;
-            fac_w[FIDX(jl, pix)] = d0[r];
-            fac_w[FIDX(jl, 32 + pix)] = d1[r];
+            if (NSLOT == 32 || jl < NSLOT) {
+                fac_w[FIDX(jl, pix)] = d0[r];
+                fac_w[FIDX(jl, 32 + pix)] = d1[r];
+            }
         }
         __builtin_amdgcn_wave_barrier();
         unsigned slotmask = 0u;   // wave-uniform: slots with at least one blending pixel
@@ -814,9 +847,19 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        float vob[32];
+        if (LEAN) {
+            const float *vo = v_out;
+            asm volatile("" : "+s"(vo));
+            load_vob(vo, vob);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 32; ++s) vob[s] = vob_keep[LEAN ? 0 : s];
+        }
+        const int arow = NSLOT == 32 ? (lane & 31) : min(lane & 31, NSLOT - 1);   // rows >= NSLOT: never written out
 #pragma unroll
         for (int s = 0; s < 32; ++s)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fac_w[FIDX(lane & 31, 2 * s + half)], vob[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fac_w[FIDX(arow, 2 * s + half)], vob[s], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int slot = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -901,7 +944,7 @@ __global__ __launch_bounds__(256, 3) void blend2_bwd_wide_kernel(
         __builtin_amdgcn_wave_barrier();
         int done = 0;
         while (qn - done >= 28) {   // 28 or 32 (a multiple of GRP): at most 27 stay behind, BQ_CAP
-            const int nb = min(32, (qn - done) & ~3);
+            const int nb = LEAN ? NSLOT : min(32, (qn - done) & ~3);
             // (not in the pair build: 8 more registers across its two flushes spill 30 more, 1.30 -> 1.33 ms)
             const bool last = !EX && (qn - done - nb < 28) && (top - 64 > range.x);   // staging comes next
             run_batch(done, nb, last);

@@ -155,7 +155,7 @@ __device__ __forceinline__ int stage_chunk(LIST &L, int lane, int e, bool valid,
 // EX: a second colour array of <= 8 channels (Seg2) is blended in the same walk as this 32-channel chunk
 // (gg_blend_fwd_pair: the plugin's feature | rgb+depth+normal forward in one walk instead of two)
 template <int CH, bool WIDE, bool FULL, bool EX = false, int FABL = 0>
-__global__ __launch_bounds__(256) void blend2_fwd_kernel(
+__global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_fwd_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
     const float *__restrict__ colors, const float *__restrict__ background,
@@ -164,12 +164,13 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
     constexpr bool N8 = !WIDE && CH > 3;          // 8-channel narrow record layout
     static_assert(!EX || WIDE, "the second array rides on the wide kernel");
     typedef WaveListT<EX ? 3 : (N8 ? 2 : 1)> LIST;
-    __shared__ LIST lists[4];
-    const int tile = xcd_tile(blockIdx.x, ntiles);
+    __shared__ LIST lists[GG_WPB_OTHER];
+    int wave;
+    const int tile = blend_tile_wave<GG_WPB_OTHER>(blockIdx.x, threadIdx.x, ntiles, wave);
     if (tile < 0) return;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    LIST &L = lists[wave];
+    const int wslot = GG_WPB_OTHER == 4 ? wave : 0;   // this wave's LDS
+    LIST &L = lists[wslot];
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int qx0 = tx * GG_BLOCK + (wave & 1) * 8, qy0 = ty * GG_BLOCK + (wave >> 1) * 8;
     const int j = qx0 + (lane & 7), i = qy0 + (lane >> 3);
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256) void blend2_fwd_kernel(
 //   1 = no global atomics, 2 = also no butterfly, 3 = also no recurrence/partials (geometry only),
 //   4 = staging + cull only (no group loop)
 template <int CH, int ABL = 0, bool DET = false>
-__global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
+__global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_bwd_narrow_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
     const float *__restrict__ colors, const float *__restrict__ background,
@@ -362,13 +363,14 @@ __global__ __launch_bounds__(256) void blend2_bwd_narrow_kernel(
     using R = Red6<KB>;
     constexpr bool N8 = CH > 3;
     typedef WaveListT<N8 ? 2 : 1> LIST;
-    __shared__ LIST lists[4];
+    __shared__ LIST lists[GG_WPB_OTHER];
 
-    const int tile = xcd_tile(blockIdx.x, ntiles);
+    int wave;
+    const int tile = blend_tile_wave<GG_WPB_OTHER>(blockIdx.x, threadIdx.x, ntiles, wave);
     if (tile < 0) return;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    LIST &L = lists[wave];
+    const int wslot = GG_WPB_OTHER == 4 ? wave : 0;   // this wave's LDS
+    LIST &L = lists[wslot];
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int qx0 = tx * GG_BLOCK + (wave & 1) * 8, qy0 = ty * GG_BLOCK + (wave >> 1) * 8;
     const int j = qx0 + (lane & 7), i = qy0 + (lane >> 3);
@@ -570,7 +572,7 @@ struct Seg2B {
 // batches of 28 slots (slab 7 280 B).  It gets its four workgroups (40 896 B, 128 VGPRs), but the walk of four
 // Gaussians at a time alone wants more than 128 registers: 81 spilled, 1.50 ms against 1.00.
 template <bool FULL, int ABL = 0, int CHD = 32, bool DET = false, bool EX = false, bool LEAN = false>
-__global__ __launch_bounds__(256, LEAN ? 4 : 3) void blend2_bwd_wide_kernel(
+__global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_per_eu(LEAN ? 4 : 3))) void blend2_bwd_wide_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
     const float *__restrict__ colors, const float *__restrict__ background,
@@ -586,19 +588,20 @@ __global__ __launch_bounds__(256, LEAN ? 4 : 3) void blend2_bwd_wide_kernel(
     constexpr int KG = 6;
     constexpr int KB = GRP * KG;
     using R = Red6<KB>;
-    __shared__ WaveQueue queues[4];
-    __shared__ float s_fac[4][NSLOT * 65];
-    __shared__ int s_slote[4][DET ? B2_SLOTS : 1];
-    __shared__ __attribute__((aligned(16))) float s_vt[4][EX ? 64 * 8 : 4];   // EX: V_OUT2[pixel][8]
+    __shared__ WaveQueue queues[GG_WPB_WIDE_BWD];
+    __shared__ float s_fac[GG_WPB_WIDE_BWD][NSLOT * 65];
+    __shared__ int s_slote[GG_WPB_WIDE_BWD][DET ? B2_SLOTS : 1];
+    __shared__ __attribute__((aligned(16))) float s_vt[GG_WPB_WIDE_BWD][EX ? 64 * 8 : 4];   // EX: V_OUT2[pixel][8]
 
-    const int tile = xcd_tile(blockIdx.x, ntiles);
+    int wave;
+    const int tile = blend_tile_wave<GG_WPB_WIDE_BWD>(blockIdx.x, threadIdx.x, ntiles, wave);
     if (tile < 0) return;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float *vt = s_vt[wave];
-    WaveQueue &Q = queues[wave];
-    float *fac_w = s_fac[wave];
-    int *slote = s_slote[wave];
+    const int wslot = GG_WPB_WIDE_BWD == 4 ? wave : 0;   // this wave's LDS
+    float *vt = s_vt[wslot];
+    WaveQueue &Q = queues[wslot];
+    float *fac_w = s_fac[wslot];
+    int *slote = s_slote[wslot];
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int qx0 = tx * GG_BLOCK + (wave & 1) * 8, qy0 = ty * GG_BLOCK + (wave >> 1) * 8;
     const int j = qx0 + (lane & 7), i = qy0 + (lane >> 3);
@@ -980,7 +983,7 @@ void gg_launch_blend2_fwd(int width, int C, int off, int n, int img_h, int img_w
                           int ntiles, const int32_t *ids, const int2 *bins, const GRec *rec,
                           const float *colors, const float *background, float *out_img,
                           float *final_Ts, int32_t *final_idx, int write_final, hipStream_t s) {
-    dim3 grid(gg_tile_grid(ntiles)), block(256);
+    dim3 grid(gg_blend_grid(ntiles, GG_WPB_OTHER)), block(64 * GG_WPB_OTHER);
     if (width == 1)
         hipLaunchKernelGGL((blend2_fwd_kernel<1, false, true>), grid, block, 0, s, B2_FWD_ARGS);
     else if (width == 2)
@@ -999,7 +1002,7 @@ void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
                                const int2 *bins, const GRec *rec, const float *colors, const float *background,
                                float *out_img, float *final_Ts, int32_t *final_idx, const float *colors2, int C2,
                                const float *background2, float *out_img2, hipStream_t s) {
-    dim3 grid(gg_tile_grid(ntiles)), block(256);
+    dim3 grid(gg_blend_grid(ntiles, GG_WPB_OTHER)), block(64 * GG_WPB_OTHER);
     Seg2 seg2;
     seg2.colors = colors2;
     seg2.background = background2;
@@ -1030,7 +1033,8 @@ void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w
                           const int32_t *final_idx, const float *v_out, float *v_xy, float *v_conic,
                           float *v_colors, float *v_opacity, int gstride, int cstride, hipStream_t s,
                           DetSlab det) {
-    dim3 grid(gg_tile_grid(ntiles)), block(256);
+    dim3 grid(gg_blend_grid(ntiles, GG_WPB_OTHER)), block(64 * GG_WPB_OTHER);
+    dim3 gridw(gg_blend_grid(ntiles, GG_WPB_WIDE_BWD)), blockw(64 * GG_WPB_WIDE_BWD);   // the wide kernels
     if (det.p) {   // deterministic mode: same kernels with the atomics replaced by slab stores
         if (width == 1)
             hipLaunchKernelGGL((blend2_bwd_narrow_kernel<1, 0, true>), grid, block, 0, s, B2_BWDN_ARGS);
@@ -1041,9 +1045,9 @@ void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w
         else if (width == 8)
             hipLaunchKernelGGL((blend2_bwd_narrow_kernel<8, 0, true>), grid, block, 0, s, B2_BWDN_ARGS);
         else if (n == 32)
-            hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, 0, 32, true>), grid, block, 0, s, B2_BWDW_ARGS);
+            hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, 0, 32, true>), gridw, blockw, 0, s, B2_BWDW_ARGS);
         else   // partial 32-channel chunk: one masked variant is enough for this mode
-            hipLaunchKernelGGL((blend2_bwd_wide_kernel<false, 0, 32, true>), grid, block, 0, s, B2_BWDW_ARGS);
+            hipLaunchKernelGGL((blend2_bwd_wide_kernel<false, 0, 32, true>), gridw, blockw, 0, s, B2_BWDW_ARGS);
         return;
     }
     if (width == 1)
@@ -1055,17 +1059,21 @@ void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w
     else if (width == 8)
         hipLaunchKernelGGL((blend2_bwd_narrow_kernel<8>), grid, block, 0, s, B2_BWDN_ARGS);
     else if (n == 32)
-        hipLaunchKernelGGL((blend2_bwd_wide_kernel<true>), grid, block, 0, s, B2_BWDW_ARGS);
+        hipLaunchKernelGGL((blend2_bwd_wide_kernel<true>), gridw, blockw, 0, s, B2_BWDW_ARGS);
     else if (n <= 8)
-        hipLaunchKernelGGL((blend2_bwd_wide_kernel<false, 0, 8>), grid, block, 0, s, B2_BWDW_ARGS);
+        hipLaunchKernelGGL((blend2_bwd_wide_kernel<false, 0, 8>), gridw, blockw, 0, s, B2_BWDW_ARGS);
     else if (n <= 16)
-        hipLaunchKernelGGL((blend2_bwd_wide_kernel<false, 0, 16>), grid, block, 0, s, B2_BWDW_ARGS);
+        hipLaunchKernelGGL((blend2_bwd_wide_kernel<false, 0, 16>), gridw, blockw, 0, s, B2_BWDW_ARGS);
     else
-        hipLaunchKernelGGL((blend2_bwd_wide_kernel<false, 0, 32>), grid, block, 0, s, B2_BWDW_ARGS);
+        hipLaunchKernelGGL((blend2_bwd_wide_kernel<false, 0, 32>), gridw, blockw, 0, s, B2_BWDW_ARGS);
 }
 
 #ifdef GG_ABLATION
 static int g_pair_ablate = 0;
+// explicit workgroup -> tile order of the blend2 kernels (device array of ntiles ints, or null: default mapping)
+extern "C" int gg_debug_set_tile_order(const int *order) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tile_order), &order, sizeof(order)) == hipSuccess ? 0 : -1;
+}
 extern "C" int gg_debug_set_pair_ablation(int level) {
     const int prev = g_pair_ablate;
     g_pair_ablate = level;
@@ -1080,7 +1088,7 @@ void gg_launch_blend2_bwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
                                const float *colors2, int C2, const float *background2,
                                const float *const *v_out2_parts, const int *v_out2_channels, int num_parts,
                                float *v_colors2, int cstride2, hipStream_t s) {
-    dim3 grid(gg_tile_grid(ntiles)), block(256);
+    dim3 grid(gg_blend_grid(ntiles, GG_WPB_WIDE_BWD)), block(64 * GG_WPB_WIDE_BWD);
     Seg2B seg2;
     seg2.colors = colors2;
     seg2.background = background2;
@@ -1116,11 +1124,12 @@ void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, 
                                  const float *colors, const float *background, const float *final_Ts,
                                  const int32_t *final_idx, const float *v_out, float *v_xy,
                                  float *v_conic, float *v_colors, float *v_opacity, int gstride, int cstride, hipStream_t s) {
-    dim3 grid(gg_tile_grid(ntiles)), block(256);
+    dim3 grid(gg_blend_grid(ntiles, GG_WPB_OTHER)), block(64 * GG_WPB_OTHER);
+    dim3 gridw(gg_blend_grid(ntiles, GG_WPB_WIDE_BWD)), blockw(64 * GG_WPB_WIDE_BWD);   // the wide kernels
     const int n = 3;   // B2_BWDN_ARGS: the ablated narrow builds are the 3-channel ones
     const DetSlab det = DetSlab();
     switch (abl) {
-#define B2_WABL(L) hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, L>), grid, block, 0, s, C, off, 32, \
+#define B2_WABL(L) hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, L>), gridw, blockw, 0, s, C, off, 32, \
         img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, final_Ts, final_idx, v_out, \
         v_xy, v_conic, v_colors, v_opacity, gstride, cstride, det)
         case 11: B2_WABL(1); break;
@@ -1139,14 +1148,14 @@ void gg_launch_blend2_bwd_ablate(int abl, int C, int off, int img_h, int img_w, 
 // resident workgroups per CU of the backward kernels (tools/kbench.py prints them)
 extern "C" int gg_debug_occupancy(int *out4) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blend2_bwd_wide_kernel<true>, 256, 0) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blend2_bwd_wide_kernel<true>, 64 * GG_WPB_WIDE_BWD, 0) != hipSuccess) return -1;
     out4[0] = n;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blend2_bwd_wide_kernel<true, 0, 32, false, true>, 256, 0) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blend2_bwd_wide_kernel<true, 0, 32, false, true>, 64 * GG_WPB_WIDE_BWD, 0) !=
         hipSuccess) return -1;
     out4[1] = n;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blend2_bwd_narrow_kernel<8>, 256, 0) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blend2_bwd_narrow_kernel<8>, 64 * GG_WPB_OTHER, 0) != hipSuccess) return -1;
     out4[2] = n;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blend2_fwd_kernel<32, true, true, true>, 256, 0) != hipSuccess)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blend2_fwd_kernel<32, true, true, true>, 64 * GG_WPB_OTHER, 0) != hipSuccess)
         return -1;
     out4[3] = n;
     return 0;

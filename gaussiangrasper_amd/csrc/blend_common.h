@@ -41,6 +41,41 @@ __device__ __forceinline__ int xcd_tile(int bid, int ntiles) {
     return tile < ntiles ? tile : -1;
 }
 
+// Waves per workgroup of the blend kernels (WPB).  The waves of a tile never synchronise (every wave walks its
+// 8x8 quadrant on its own), so a workgroup need not hold all four.  With WPB == 1 every quadrant is its own
+// 64-thread workgroup: a finished quadrant frees its registers and LDS at once instead of holding them until the
+// slowest quadrant of its tile is done.  Workgroups b, b + 8, b + 16, b + 24 are then the four quadrants of one
+// tile (same XCD: they share the tile's list and records through that XCD's L2).  Measured (r02, bench view):
+// wide backward 0.997 -> 0.906 ms, pair backward 1.243 -> 1.188 with WPB 1; the forward and the narrow kernels
+// (5-8 waves per SIMD, the four quadrants' list reads hitting in the CU's L1) are 3-5 % SLOWER with it.
+#ifndef GG_WPB_WIDE_BWD
+#define GG_WPB_WIDE_BWD 1
+#endif
+#ifndef GG_WPB_OTHER
+#define GG_WPB_OTHER 4
+#endif
+__host__ __device__ __forceinline__ int gg_blend_grid(int ntiles, int wpb) { return gg_tile_grid(ntiles) * (4 / wpb); }
+// tile (or -1) and quadrant of this wave
+#ifdef GG_ABLATION
+// measurement twin only (tools/kbench_order.py): an explicit workgroup -> tile order, e.g. longest list first
+static __device__ const int *g_tile_order = nullptr;
+#endif
+template <int WPB>
+__device__ __forceinline__ int blend_tile_wave(int bid, int tid, int ntiles, int &wave) {
+    static_assert(WPB == 4 || WPB == 1, "four quadrants per workgroup, or one");
+    int k = bid;
+    if (WPB == 4) {
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    } else {
+        wave = (bid >> 3) & 3;
+        k = ((bid >> 5) << 3) | (bid & 7);
+    }
+#ifdef GG_ABLATION
+    if (g_tile_order) return k < ntiles ? g_tile_order[k] : -1;
+#endif
+    return xcd_tile(k, ntiles);
+}
+
 // Does the alpha>=1/255 ellipse of a record reach the pixel rectangle [xlo,xhi]x[ylo,yhi]?
 // Exact in real arithmetic: sigma is a convex quadratic, so its minimum over the rectangle is 0
 // if the centre is inside and otherwise lies on one of the (at most two) edges facing the centre;

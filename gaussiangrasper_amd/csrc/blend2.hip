@@ -58,6 +58,41 @@ extern "C" int gg_debug_set_fwd_ablation(int level) {
 #else
 #define WALK_STAT(i, v) do { } while (0)
 #endif
+// GG_STAMPS (tools/stamps.py; a diagnostic build of its own, never timed as a whole): s_memtime stamps around the
+// phases of the wide backward.  Every wave adds the cycles it spent per phase into g_stamp_sums:
+//   0 prologue  1 staging (list ids, records, cull, queue)  2 batch start: colour-row loads issued and waited for
+//   3 D product (MFMAs + slab stores)  4 walk  5 flush MFMAs  6 32-channel colour atomics  7 second-array flush
+//   8 queue compaction  9 wave lifetime  10 batches  11 waves
+#ifdef GG_STAMPS
+__device__ unsigned long long g_stamp_sums[16];
+extern "C" int gg_debug_stamps(unsigned long long *out16, int reset) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamp_sums), sizeof(g_stamp_sums)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sums), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+__device__ __forceinline__ unsigned long long gg_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define STAMP_DECL unsigned long long st_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned st_batches = 0; \
+                   const unsigned long long st_t0 = gg_stamp(); unsigned long long st_prev = st_t0
+#define STAMP(i) do { const unsigned long long st_now = gg_stamp(); st_sum[i] += st_now - st_prev; st_prev = st_now; } while (0)
+#define STAMP_BATCH() (++st_batches)
+#define STAMP_END() do { st_sum[9] = gg_stamp() - st_t0; if (lane == 0) { \
+        for (int q_ = 0; q_ < 10; ++q_) atomicAdd(&g_stamp_sums[q_], st_sum[q_]); \
+        atomicAdd(&g_stamp_sums[10], (unsigned long long)st_batches); atomicAdd(&g_stamp_sums[11], 1ull); } } while (0)
+#else
+#define STAMP_DECL do { } while (0)
+#define STAMP(i) do { } while (0)
+#define STAMP_BATCH() do { } while (0)
+#define STAMP_END() do { } while (0)
+#endif
 #define LIST_CAP 72    // 4 leading pads + 64 + 4 trailing pads
 
 // NC: colour float4s per record.  <= 3 channels: c = colours 0..2 and .w = list position; 8-channel
@@ -607,39 +642,95 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     const int j = qx0 + (lane & 7), i = qy0 + (lane >> 3);
     const bool inside = (i < img_h) && (j < img_w);
     const float px = (float)j, py = (float)i;
-    const float xlo = (float)qx0, xhi = (float)(qx0 + 7), ylo = (float)qy0, yhi = (float)(qy0 + 7);
     const int2 range = bins[tile];
     const size_t p = inside ? ((size_t)i * img_w + j) : 0;
 
+    STAMP_DECL;
     const float T_final = inside ? final_T[p] : 1.0f;
     const int fin = inside ? final_idx[p] : range.x;
     float T = T_final;
     float W;
-    {
-        float Bsum = 0.0f;
+    const int wch = lane & 31, half = lane >> 5;
+    const bool wch_ok = FULL || wch < nch;
+    // The quadrant's cotangents V_OUT[64 pixels x CH] are needed three ways: <background, v_out> per pixel (lane =
+    // pixel), the D product's A operands (pixel-major, half a row per lane) and the flush's B operands (lane =
+    // channel).  Read straight from the image, each of the three is ~32 load instructions of 32-64 cache lines
+    // each (lanes 128 bytes apart): in-kernel stamps (tools/stamps.py) showed 31-35 % of a wave's lifetime in this
+    // prologue.  TILE: the 8 KB tile is loaded ONCE, 1 KB per instruction (one image row of the quadrant, float4
+    // per lane), parked in the (still unused) fac slab — [pixel][32] with the 16-byte chunks of a row XOR-swizzled
+    // by the pixel — and the three views are read from there.
+    const bool tile_lds = !LEAN && FULL && CH == 32 && (C % 4 == 0) && (ch_off % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(v_out) & 15) == 0);   // wave-uniform
+    float voa_keep[2][LEAN ? 1 : KS], vob_keep[LEAN ? 1 : 32];
+    float Bsum = 0.0f;
+    if (tile_lds) {
+        float4 rowv[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int pi = qy0 + r, pj = qx0 + (lane >> 3);
+            rowv[r] = (pi < img_h && pj < img_w)
+                          ? *reinterpret_cast<const float4 *>(v_out + ((size_t)pi * img_w + pj) * C + ch_off + 4 * (lane & 7))
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)   // pixel 8 r + (lane >> 3), chunk (lane & 7) ^ (pixel & 7)
+            *reinterpret_cast<float4 *>(fac_w + (8 * r + (lane >> 3)) * 32 + 4 * ((lane & 7) ^ (lane >> 3))) = rowv[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {   // lane = pixel, channels in order (the same fma chain as the direct form)
+            const float4 v = *reinterpret_cast<const float4 *>(fac_w + lane * 32 + 4 * (k ^ (lane & 7)));
+            Bsum = __builtin_fmaf(background[ch_off + 4 * k], v.x, Bsum);
+            Bsum = __builtin_fmaf(background[ch_off + 4 * k + 1], v.y, Bsum);
+            Bsum = __builtin_fmaf(background[ch_off + 4 * k + 2], v.z, Bsum);
+            Bsum = __builtin_fmaf(background[ch_off + 4 * k + 3], v.w, Bsum);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {   // A operands: pixel (lane & 31) + 32 c, channels KS half .. + KS
+            const int pm = (lane & 31) + 32 * c;
+#pragma unroll
+            for (int jq = 0; jq < KS / 4; ++jq) {
+                const float4 v = *reinterpret_cast<const float4 *>(fac_w + pm * 32 + 4 * (((KS / 4) * half + jq) ^ (pm & 7)));
+                voa_keep[c][LEAN ? 0 : 4 * jq] = v.x;
+                voa_keep[c][LEAN ? 0 : 4 * jq + 1] = v.y;
+                voa_keep[c][LEAN ? 0 : 4 * jq + 2] = v.z;
+                voa_keep[c][LEAN ? 0 : 4 * jq + 3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {  // B operands: pixel 2 s + half, channel wch
+            const int pq = 2 * s + half;
+            vob_keep[LEAN ? 0 : s] = fac_w[pq * 32 + 4 * ((wch >> 2) ^ (pq & 7)) + (wch & 3)];
+        }
+        __builtin_amdgcn_wave_barrier();   // the slab is free again
+    } else {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const float v = (inside && (FULL || c < nch)) ? v_out[p * C + ch_off + c] : 0.0f;
             if (FULL || c < nch) Bsum = __builtin_fmaf(background[ch_off + c], v, Bsum);
         }
-        if (EX) {
-            float t8[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                // channel c lives in part a at column c - first channel of that part
-                const int w0 = seg2.vo_w[0], w01 = w0 + seg2.vo_w[1];
-                const int a = c < w0 ? 0 : (c < w01 ? 1 : 2);
-                const int col = c - (a == 0 ? 0 : (a == 1 ? w0 : w01));
-                t8[c] = (inside && c < seg2.nch2) ? seg2.v_out[a][p * seg2.vo_w[a] + col] : 0.0f;
-                if (c < seg2.nch2) Bsum = __builtin_fmaf(seg2.background[c], t8[c], Bsum);
-            }
-            reinterpret_cast<float4 *>(vt + lane * 8)[0] = make_float4(t8[0], t8[1], t8[2], t8[3]);
-            reinterpret_cast<float4 *>(vt + lane * 8)[1] = make_float4(t8[4], t8[5], t8[6], t8[7]);
-        }
-        W = T_final * Bsum;
     }
-    const int wch = lane & 31, half = lane >> 5;
-    const bool wch_ok = FULL || wch < nch;
+    if (EX) {
+        float t8[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            // channel c lives in part a at column c - first channel of that part
+            const int w0 = seg2.vo_w[0], w01 = w0 + seg2.vo_w[1];
+            const int a = c < w0 ? 0 : (c < w01 ? 1 : 2);
+            const int col = c - (a == 0 ? 0 : (a == 1 ? w0 : w01));
+            // (loaded unconditionally — pixel 0 / column 0 stand in where there is nothing to read — so that the eight
+            //  loads are in flight together; as a conditional load each one was waited for in its own branch)
+            const bool have = c < seg2.nch2;
+            t8[c] = seg2.v_out[have ? a : 0][p * seg2.vo_w[have ? a : 0] + (have ? col : 0)];
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            t8[c] = (inside && c < seg2.nch2) ? t8[c] : 0.0f;
+            if (c < seg2.nch2) Bsum = __builtin_fmaf(seg2.background[c], t8[c], Bsum);
+        }
+        reinterpret_cast<float4 *>(vt + lane * 8)[0] = make_float4(t8[0], t8[1], t8[2], t8[3]);
+        reinterpret_cast<float4 *>(vt + lane * 8)[1] = make_float4(t8[4], t8[5], t8[6], t8[7]);
+    }
+    W = T_final * Bsum;
     // D product, A operands: V_OUT[pixel (lane & 31) + 32 c][channel KS half + s];
     // flush, B operands:     V_OUT[pixel 2s + half][channel wch]
     auto load_voa = [&](const float *vo, float (&dst)[2][KS]) {
@@ -662,8 +753,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
             dst[s] = ok ? vo[((size_t)pi * img_w + pj) * C + ch_off + wch] : 0.0f;
         }
     };
-    float voa_keep[2][LEAN ? 1 : KS], vob_keep[LEAN ? 1 : 32];
-    if (!LEAN) {
+    if (!LEAN && !tile_lds) {
         float ta[2][KS], tb[32];
         load_voa(v_out, ta);
         load_vob(v_out, tb);
@@ -703,6 +793,8 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         rb_p.x = __builtin_nondeterministic_value(rb_p.x); rb_p.y = __builtin_nondeterministic_value(rb_p.y);
         rb_p.z = __builtin_nondeterministic_value(rb_p.z); rb_p.w = __builtin_nondeterministic_value(rb_p.w);
         if (ABL >= 6) { KEEP(n); return; }   // staging + queue only
+        STAMP(1);
+        STAMP_BATCH();
         const int jl = lane & 31;
         const int cgid = (jl < n) ? __builtin_bit_cast(int, Q.b[base + jl].w) : -1;
         f32x16 d0, d1;
@@ -741,6 +833,16 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
 #pragma unroll
                     for (int s = 0; s < KS; ++s) voa[c][s] = voa_keep[c][LEAN ? 0 : s];
             }
+#ifdef GG_STAMPS
+            {   // make the colour rows arrive inside phase 2
+                float sink_ = 0.0f;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) sink_ += colb[s];
+                if (EX) sink_ += colb2[0] + colb2[1] + colb2[2] + colb2[3];
+                KEEP(sink_);
+            }
+            STAMP(2);
+#endif
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const float bv = cgid < 0 ? 0.0f : colb[s];
@@ -768,23 +870,20 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
             }
         }
         __builtin_amdgcn_wave_barrier();
+        STAMP(3);
         unsigned slotmask = 0u;   // wave-uniform: slots with at least one blending pixel
         for (int g = 0; g < n; g += GRP) {
-            float vis[GRP], alpha[GRP], dxs[GRP], dys[GRP], opac[GRP], Dv[GRP];
-            float ca[GRP], cb[GRP], cc[GRP];
+            // Two passes over the group.  The second one READS THE RECORDS AGAIN (wave-uniform LDS broadcasts) and
+            // takes D from the slab only then: holding dx, dy, opacity, the conic and D of four Gaussians across
+            // the passes is 28 registers at the kernel's register peak (the pair build spilled 16-26 of them, and a
+            // scratch reload sits behind every float atomic in flight: the vector memory counter is in order).
+            float vis[GRP], alpha[GRP];
             bool pass[GRP];
 #pragma unroll
             for (int q = 0; q < GRP; ++q) {
                 const float4 A = Q.a[base + g + q], B = Q.b[base + g + q];
-                Dv[q] = fac_w[FIDX(g + q, lane)];
                 const int pos = __builtin_bit_cast(int, A.w);
                 const float dx = A.x - px, dy = A.y - py;
-                dxs[q] = dx;
-                dys[q] = dy;
-                opac[q] = A.z;
-                ca[q] = B.x;
-                cb[q] = B.y;
-                cc[q] = B.z;
                 const float sigma = __builtin_fmaf(
                     0.5f, __builtin_fmaf(B.x * dx, dx, (B.z * dy) * dy), (B.y * dx) * dy);
                 vis[q] = gg_expf(-sigma);
@@ -797,6 +896,8 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                 for (int q = 0; q < GRP; ++q) { KEEP(vis[q]); KEEP(alpha[q]); KEEP((int)pass[q]); }
                 continue;
             }
+            int gi = base + g;
+            asm volatile("" : "+s"(gi));   // a second read of the records, not values carried over
             float part[KB];
 #pragma unroll
             for (int q = 0; q < GRP; ++q) {
@@ -806,17 +907,18 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                     for (int v = 0; v < KG; ++v) pg[v] = 0.0f;
                     continue;
                 }
-                const float D = Dv[q];
+                const float4 A = Q.a[gi + q], B = Q.b[gi + q];
+                const float D = fac_w[FIDX(g + q, lane)];
                 const float ra_ = __builtin_amdgcn_rcpf(1.0f - alpha[q]);
                 const float Tn = T * ra_;
                 const float fac = pass[q] ? alpha[q] * Tn : 0.0f;
                 const float v_alpha = pass[q] ? (Tn * D - ra_ * W) : 0.0f;
                 W = pass[q] ? __builtin_fmaf(D, fac, W) : W;
                 T = pass[q] ? Tn : T;
-                const float v_sigma = pass[q] ? (-opac[q] * vis[q]) * v_alpha : 0.0f;
-                const float dx = dxs[q], dy = dys[q];
-                pg[0] = v_sigma * (ca[q] * dx + cb[q] * dy);
-                pg[1] = v_sigma * (cb[q] * dx + cc[q] * dy);
+                const float v_sigma = pass[q] ? (-A.z * vis[q]) * v_alpha : 0.0f;
+                const float dx = A.x - px, dy = A.y - py;
+                pg[0] = v_sigma * (B.x * dx + B.y * dy);
+                pg[1] = v_sigma * (B.y * dx + B.z * dy);
                 const float hs = 0.5f * v_sigma;
                 pg[2] = (hs * dx) * dx;
                 pg[3] = (hs * dx) * dy;
@@ -839,6 +941,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
             }
             if (owner && my_gid >= 0 && mine != 0.0f) atomicAdd(my_base + (size_t)my_gid * my_stride, mine);
         }
+        STAMP(4);
         if (fetch_next) {
             ra_p = reinterpret_cast<const float4 *>(rec + g_nxt)[0];
             rb_p = reinterpret_cast<const float4 *>(rec + g_nxt)[1];
@@ -863,6 +966,11 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
 #pragma unroll
         for (int s = 0; s < 32; ++s)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fac_w[FIDX(arow, 2 * s + half)], vob[s], acc, 0, 0, 0);
+#ifdef GG_STAMPS
+#pragma unroll
+        for (int r = 0; r < 16; ++r) KEEP(acc[r]);
+        STAMP(5);
+#endif
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int slot = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -877,6 +985,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                 atomicAdd(v_colors + (size_t)sg * cs + ch_off + wch, acc[r]);
             }
         }
+        STAMP(6);
         if (EX) {
             // second array: FAC[32 slots x 64 pixels] * V_OUT2[64 x 8] as 2 x 16 v_mfma_f32_16x16x4_f32
             // (A: slot 16 mb + (lane & 15), pixel 4 s + (lane >> 4); B: the same pixel, channel lane & 15;
@@ -906,6 +1015,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
             }
         }
         __builtin_amdgcn_wave_barrier();
+        STAMP(7);
     };
 
     int qn = 0;   // queued survivors (wave-uniform)
@@ -915,6 +1025,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         return (top_ > range.x && e_ >= range.x) ? ids[e_] : 0;
     };
     g_nxt = load_id(hi);
+    STAMP(0);
     bool have_p = false;   // wave-uniform: ra_p / rb_p hold this chunk's records
     for (int top = hi; top > range.x; top -= 64) {
         const int e = top - 64 + lane;
@@ -935,7 +1046,12 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         rb_p.x = __builtin_nondeterministic_value(rb_p.x); rb_p.y = __builtin_nondeterministic_value(rb_p.y);
         rb_p.z = __builtin_nondeterministic_value(rb_p.z); rb_p.w = __builtin_nondeterministic_value(rb_p.w);
         g_nxt = load_id(top - 64);
-        const bool hit = valid && rec_hits_rect(ra, rb, xlo, xhi, ylo, yhi);
+        // the quadrant's rectangle is recomputed here (four conversions of wave-uniform integers): hoisted out of
+        // the loop, the allocator spilled the four floats and reloaded them from scratch in every chunk — behind
+        // every float atomic still in flight
+        int qxl = qx0, qyl = qy0;
+        asm volatile("" : "+s"(qxl), "+s"(qyl));
+        const bool hit = valid && rec_hits_rect(ra, rb, (float)qxl, (float)(qxl + 7), (float)qyl, (float)(qyl + 7));
         const uint64_t m = __ballot(hit);
         const int cnt = __builtin_popcountll(m);
         if (hit) {   // processing order: descending list position
@@ -954,15 +1070,17 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
             have_p = last;
             done += nb;
         }
+        STAMP(1);
         if (done > 0) {   // bring the left-over (< 28) to the front; source and destination do not overlap
             const int left = qn - done;
-            float4 ta, tb;
-            if (lane < left) { ta = Q.a[done + lane]; tb = Q.b[done + lane]; }
+            // (one array at a time: with both records in flight the allocator parked them in scratch)
+            if (lane < left) { const float4 ta = Q.a[done + lane]; __builtin_amdgcn_wave_barrier(); Q.a[lane] = ta; }
             __builtin_amdgcn_wave_barrier();
-            if (lane < left) { Q.a[lane] = ta; Q.b[lane] = tb; }
+            if (lane < left) { const float4 tb = Q.b[done + lane]; __builtin_amdgcn_wave_barrier(); Q.b[lane] = tb; }
             qn = left;
             __builtin_amdgcn_wave_barrier();
         }
+        STAMP(8);
     }
     if (qn > 0) {
         if (lane < GRP) {   // null records behind the last survivor: opacity 0 -> alpha 0 -> never pass
@@ -972,6 +1090,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         __builtin_amdgcn_wave_barrier();
         run_batch(0, qn, false);
     }
+    STAMP_END();
 }
 
 // =============================================================================================

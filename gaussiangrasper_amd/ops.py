@@ -15,6 +15,7 @@ calls of one view share ONE binning (tile sort), cached on the identity+version 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -853,7 +854,8 @@ class RasterizeSegments(Function):
         # narrowest small segment (<= 8 channels) ride in the same record (one cache line per Gaussian)
         small = [i for i in range(k) if cols[i].shape[1] <= 8]
         rider = min(small, key=lambda i: cols[i].shape[1]) if small else None
-        gstride = 6 + (cols[rider].shape[1] if rider is not None else 0)
+        gwidth = 6 + (cols[rider].shape[1] if rider is not None else 0)
+        gstride = int(os.environ.get("GG_REC_STRIDE", "0")) or gwidth     # (experiment: padded records)
         rec_g = torch.empty(n, gstride, dtype=torch.float32, device=dev)
         v_xy, v_conic, v_opacity = rec_g[:, 0:2], rec_g[:, 2:5], rec_g[:, 5:6]
         order = ([rider] if rider is not None else []) + [i for i in range(k) if i != rider]
@@ -895,9 +897,9 @@ class RasterizeSegments(Function):
                 cols[wide].shape[1], cols[rider].shape[1], n, img_height, img_width, _ptr(ids_sorted),
                 _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(cols[wide]), _ptr(cols[rider]), _ptr(opacity),
                 _ptr(bgs[wide]), _ptr(bgs[rider]), _ptr(final_Ts), _ptr(final_idx), _ptr(vo_w), part_ptrs,
-                part_chs, len(rp), _ptr(v_xy), _ptr(v_conic), _ptr(v_colors), _ptr(rec_g[:, 6:]), _ptr(v_opacity),
+                part_chs, len(rp), _ptr(v_xy), _ptr(v_conic), _ptr(v_colors), _ptr(rec_g[:, 6:gwidth]), _ptr(v_opacity),
                 gstride, 0, gstride, _ptr(ws), ws.numel(), flags, _stream(dev)), "gg_blend_bwd_pair")
-            grads[rider] = rec_g[:, 6:]
+            grads[rider] = rec_g[:, 6:gwidth]
             if flags & 2:
                 if sink[2] is not None:
                     sink[2](sink[0])
@@ -911,7 +913,7 @@ class RasterizeSegments(Function):
             flags = 1 | (0 if first else 4)
             sink = ctx.sinks[i]
             if i == rider:
-                v_colors, cstride = rec_g[:, 6:], gstride
+                v_colors, cstride = rec_g[:, 6:gwidth], gstride
             elif sink is not None:
                 v_colors, cstride = sink[1], 0
                 flags |= 2

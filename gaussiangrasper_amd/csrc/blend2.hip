@@ -622,6 +622,29 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     constexpr int KS = CHD / 2;     // k-steps of the D product; lane half h supplies channels [KS h, KS h + KS)
     constexpr int KG = 6;
     constexpr int KB = GRP * KG;
+#ifndef GG_WALK_REREAD
+#define GG_WALK_REREAD 0
+#endif
+    constexpr bool REREAD = GG_WALK_REREAD != 0;
+    // DEFER: the colour gradients of a batch are not added right after its flush.  The vector memory counter is in
+    // order, so every load issued behind the flush's 16-24 float-atomic instructions (the next chunk's records, the
+    // next batch's colour rows) waited for all of them (in-kernel stamps: staging 22-35 %, colour-row wait 12 % of a
+    // wave's lifetime).  The flush results are parked in the fac slab (dead by then) and their atomics are issued
+    // when the NEXT batch has its D product in registers, right in front of its walk — 25 k cycles without a single
+    // vector load, in which they retire.  The geometry sums go the same way (out of the butterfly into the dead
+    // x, y, opacity / conic fields of their slot's queue record, from there to the slab beside the colour rows):
+    // no atomic is issued during a walk, a flush or the staging, so no load ever waits behind one.
+    // Slab while parked: [0, 1024) colour rows (register r of lane l at 64 r + l), [1024, 1536) the second array's,
+    // [1536, 1728) the geometry sums (6 slot + k).
+    // MEASURED (r02, -DGG_BWD_DEFER=1 against 0 on the bench view): pair backward 1.064 against 1.051 ms, 32-channel
+    // 0.836 against 0.827 — no gain, and the stamps still show the same staging and colour-row waits with no atomic
+    // in flight at those points: the waits are plain load latency (several microseconds under this kernel's traffic),
+    // not the counter's ordering.  Kept behind the switch, off.
+#ifndef GG_BWD_DEFER
+#define GG_BWD_DEFER 0
+#endif
+    constexpr bool DEFER = (GG_BWD_DEFER != 0) && !DET && !LEAN && ABL == 0;
+    __shared__ int s_hid[GG_WPB_WIDE_BWD][DEFER ? 32 : 1];   // DEFER: Gaussian of every slot of the parked batch
     using R = Red6<KB>;
     __shared__ WaveQueue queues[GG_WPB_WIDE_BWD];
     __shared__ float s_fac[GG_WPB_WIDE_BWD][NSLOT * 65];
@@ -637,6 +660,8 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     WaveQueue &Q = queues[wslot];
     float *fac_w = s_fac[wslot];
     int *slote = s_slote[wslot];
+    int *hid = s_hid[wslot];
+    unsigned h_mask = 0u;   // DEFER, wave-uniform: slots of the parked batch whose rows are still to be added
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int qx0 = tx * GG_BLOCK + (wave & 1) * 8, qy0 = ty * GG_BLOCK + (wave >> 1) * 8;
     const int j = qx0 + (lane & 7), i = qy0 + (lane >> 3);
@@ -776,6 +801,8 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     if (my_k < 2) { my_base = v_xy + my_k; my_stride = gstride ? gstride : 2; }
     else if (my_k < 5) { my_base = v_conic + (my_k - 2); my_stride = gstride ? gstride : 3; }
     else { my_base = v_opacity; my_stride = gstride ? gstride : 1; }
+    // DEFER: float offset of my value's parking field from &Q.a[first slot of the group] (Q.b follows Q.a)
+    const int my_park = 4 * my_q + (my_k < 3 ? my_k : 4 * BQ_CAP + (my_k - 3));
     const int cs = cstride ? cstride : C;
     // vector loads of the colour half-rows need 16-byte aligned rows
     const bool vec = FULL && (C % 4 == 0) && (ch_off % 4 == 0) && ((reinterpret_cast<uintptr_t>(colors) & 15) == 0);
@@ -784,6 +811,58 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     // in order, so loads issued behind the flush's 24-32 atomic instructions wait for every one of them
     float4 ra_p = make_float4(0.f, 0.f, 0.f, 0.f), rb_p = ra_p;
     int g_nxt = 0;   // ids of the next chunk (loaded one chunk ahead)
+    // DEFER: the parked batch's colour gradients: acc register r of lane l at slab[64 r + l], the second array's
+    // at slab[1024 + 64 (4 mb + r) + l]
+    auto issue_pending = [&]() {
+        if (h_mask == 0u) return;
+        // (lane-derived slot numbers, mask bits and table addresses are computed HERE: as loop invariants the
+        //  allocator spilled them and reloaded each one between two atomics, behind a wait for the first)
+        int half_l = half, k4_l = lane >> 4;
+        asm volatile("" : "+v"(half_l), "+v"(k4_l));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int slot = (r & 3) + 8 * (r >> 2) + 4 * half_l;
+            const float v = fac_w[64 * r + lane];
+            const bool on = ((h_mask >> slot) & 1u) != 0u && wch_ok;
+            if (on && v != 0.0f) atomicAdd(v_colors + (size_t)hid[slot] * cs + ch_off + wch, v);
+            // (four at a time: scheduled freely, the 24 values and 24 addresses of all the atomics are live at once,
+            //  on top of the D accumulators)
+            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (EX) {
+            const int n16 = lane & 15, k4 = k4_l;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                if (((h_mask >> (16 * mb)) & 0xffffu) == 0u) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int slot = 16 * mb + 4 * k4 + r;
+                    const float v = fac_w[1024 + 64 * (4 * mb + r) + lane];
+                    const bool on = ((h_mask >> slot) & 1u) != 0u && n16 < seg2.nch2;
+                    if (on && v != 0.0f) atomicAdd(seg2.v_colors + (size_t)hid[slot] * seg2.cs2 + n16, v);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        {   // geometry sums: three instructions for the 32 x 6 values
+            int lane_l = lane;
+            asm volatile("" : "+v"(lane_l));
+            const int sxy = gstride ? gstride : 2, scn = gstride ? gstride : 3, sop = gstride ? gstride : 1;
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const int i6 = 64 * v + lane_l, slot = i6 / 6, k = i6 - 6 * slot;
+                const float val = fac_w[1536 + i6];
+                const bool on = ((h_mask >> slot) & 1u) != 0u;
+                if (on && val != 0.0f) {
+                    const size_t gid = (size_t)hid[slot];
+                    float *dst = k < 2 ? v_xy + gid * sxy + k : (k < 5 ? v_conic + gid * scn + (k - 2) : v_opacity + gid * sop);
+                    atomicAdd(dst, val);
+                }
+            }
+        }
+        h_mask = 0u;
+        __builtin_amdgcn_wave_barrier();
+    };
     // one batch: queue entries [base, base + n), n = 28 or 32 (fewer only for the last batch of the walk, which
     // is followed by null records up to a multiple of GRP)
     auto run_batch = [&](const int base, const int n, const bool fetch_next) {
@@ -860,6 +939,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
             }
         }
         if (DET && lane < 32) slote[jl] = __builtin_bit_cast(int, Q.a[base + min(jl, n - 1)].w);
+        if (DEFER) issue_pending();   // the parked batch leaves the slab before D goes in
         // D[pixel m][slot n]: lane holds n = lane & 31, m = (r & 3) + 8 (r >> 2) + 4 half (+ 32 for d1)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -879,9 +959,11 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
             // scratch reload sits behind every float atomic in flight: the vector memory counter is in order).
             float vis[GRP], alpha[GRP];
             bool pass[GRP];
+            float4 Ah[REREAD ? 1 : GRP], Bh[REREAD ? 1 : GRP];
 #pragma unroll
             for (int q = 0; q < GRP; ++q) {
                 const float4 A = Q.a[base + g + q], B = Q.b[base + g + q];
+                if (!REREAD) { Ah[REREAD ? 0 : q] = A; Bh[REREAD ? 0 : q] = B; }
                 const int pos = __builtin_bit_cast(int, A.w);
                 const float dx = A.x - px, dy = A.y - py;
                 const float sigma = __builtin_fmaf(
@@ -897,7 +979,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                 continue;
             }
             int gi = base + g;
-            asm volatile("" : "+s"(gi));   // a second read of the records, not values carried over
+            if (REREAD) asm volatile("" : "+s"(gi));   // a second read of the records, not values carried over
             float part[KB];
 #pragma unroll
             for (int q = 0; q < GRP; ++q) {
@@ -907,7 +989,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                     for (int v = 0; v < KG; ++v) pg[v] = 0.0f;
                     continue;
                 }
-                const float4 A = Q.a[gi + q], B = Q.b[gi + q];
+                const float4 A = REREAD ? Q.a[gi + q] : Ah[REREAD ? 0 : q], B = REREAD ? Q.b[gi + q] : Bh[REREAD ? 0 : q];
                 const float D = fac_w[FIDX(g + q, lane)];
                 const float ra_ = __builtin_amdgcn_rcpf(1.0f - alpha[q]);
                 const float Tn = T * ra_;
@@ -937,6 +1019,10 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
             if (DET) {
                 const size_t e = (size_t)__builtin_bit_cast(int, Q.a[base + g + my_q].w);
                 if (owner && my_gid >= 0) det.p[(e * 4 + wave) * det.ks + det.goff + my_k] = mine;
+                continue;
+            }
+            if (DEFER) {   // k-th sum of slot base + g + my_q: field k of the slot's (dead) record
+                if (owner) reinterpret_cast<float *>(&Q.a[base + g])[my_park] = mine;
                 continue;
             }
             if (owner && my_gid >= 0 && mine != 0.0f) atomicAdd(my_base + (size_t)my_gid * my_stride, mine);
@@ -971,9 +1057,14 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         for (int r = 0; r < 16; ++r) KEEP(acc[r]);
         STAMP(5);
 #endif
+        // (lane-derived slot numbers and mask bits are computed HERE, from laundered values: as loop invariants they
+        //  took 6-16 registers for the whole kernel)
+        int half_f = half, k4_f = lane >> 4;
+        asm volatile("" : "+v"(half_f), "+v"(k4_f));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int slot = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (DEFER) continue;   // parked below, after the second array's flush has read fac
+            const int slot = (r & 3) + 8 * (r >> 2) + 4 * half_f;
             if (ABL >= 1) { KEEP(acc[r]); continue; }
             const bool on = ((slotmask >> slot) & 1u) != 0u && wch_ok;
             if (DET) {
@@ -990,11 +1081,13 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
             // second array: FAC[32 slots x 64 pixels] * V_OUT2[64 x 8] as 2 x 16 v_mfma_f32_16x16x4_f32
             // (A: slot 16 mb + (lane & 15), pixel 4 s + (lane >> 4); B: the same pixel, channel lane & 15;
             //  D: lane holds channel lane & 15 of slots 16 mb + 4 (lane >> 4) + r)
-            const int n16 = lane & 15, k4 = lane >> 4;
+            const int n16 = lane & 15, k4 = k4_f;
             const float *vbp = vt + k4 * 8 + (n16 & 7);
             const float vmask = n16 < 8 ? 1.0f : 0.0f;   // lanes of channels 8..15 supply zeros
+            f32x4 a4h[2];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
+                a4h[mb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                 if (((slotmask >> (16 * mb)) & 0xffffu) == 0u) continue;
                 f32x4 a4 = {0.0f, 0.0f, 0.0f, 0.0f};
                 const int m = 16 * mb + n16;
@@ -1002,8 +1095,10 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                 for (int s = 0; s < 16; ++s)
                     a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fac_w[FIDX(m, 4 * s + k4)], vbp[32 * s] * vmask, a4,
                                                               0, 0, 0);
+                a4h[mb] = a4;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    if (DEFER) continue;
                     const int slot = 16 * mb + 4 * k4 + r;
                     if (ABL >= 1) { KEEP(a4[r]); continue; }
                     const bool on = ((slotmask >> slot) & 1u) != 0u && n16 < seg2.nch2;
@@ -1013,6 +1108,25 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                     }
                 }
             }
+            if (DEFER) {   // every MFMA above has read its fac operands: the slab is free for the parked results
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) fac_w[1024 + 64 * (4 * mb + r) + lane] = a4h[mb][r];
+            }
+        }
+        if (DEFER) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) fac_w[64 * r + lane] = acc[r];
+            if (lane < 32) hid[lane] = __builtin_bit_cast(int, Q.b[base + lane].w);   // (slots >= n: never used)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {   // geometry sums: queue record fields -> slab[1536 + 6 slot + k]
+                const int i6 = 64 * v + lane, slot = i6 / 6, k = i6 - 6 * slot;
+                fac_w[1536 + i6] = reinterpret_cast<const float *>(&Q.a[base])[4 * slot + (k < 3 ? k : 4 * BQ_CAP + (k - 3))];
+            }
+            h_mask = slotmask;
         }
         __builtin_amdgcn_wave_barrier();
         STAMP(7);
@@ -1027,7 +1141,11 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     g_nxt = load_id(hi);
     STAMP(0);
     bool have_p = false;   // wave-uniform: ra_p / rb_p hold this chunk's records
-    for (int top = hi; top > range.x; top -= 64) {
+    // ONE call site of run_batch (the tail batch runs through the same loop): inlined twice, the allocator kept two
+    // sets of loop invariants and spilled one
+    for (int top = hi;; top -= 64) {
+      const bool more = top > range.x;   // wave-uniform: another chunk to stage
+      if (more) {
         const int e = top - 64 + lane;
         const bool valid = e >= range.x;
         const int g = g_nxt;
@@ -1061,15 +1179,25 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         }
         qn += cnt;
         __builtin_amdgcn_wave_barrier();
+      } else {
+        if (qn == 0) break;
+        if (lane < GRP) {   // null records behind the last survivor: opacity 0 -> alpha 0 -> never pass
+            Q.a[qn + lane] = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, 0x7fffffff));
+            Q.b[qn + lane] = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, -1));
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
         int done = 0;
-        while (qn - done >= 28) {   // 28 or 32 (a multiple of GRP): at most 27 stay behind, BQ_CAP
-            const int nb = LEAN ? NSLOT : min(32, (qn - done) & ~3);
+        // 28 or 32 (a multiple of GRP): at most 27 stay behind, BQ_CAP; after the last chunk: what is left (<= 27)
+        while (more ? (qn - done >= 28) : (done == 0)) {
+            const int nb = !more ? qn : (LEAN ? NSLOT : min(32, (qn - done) & ~3));
             // (not in the pair build: 8 more registers across its two flushes spill 30 more, 1.30 -> 1.33 ms)
-            const bool last = !EX && (qn - done - nb < 28) && (top - 64 > range.x);   // staging comes next
+            const bool last = more && (!EX || DEFER) && (qn - done - nb < 28) && (top - 64 > range.x);   // staging comes next
             run_batch(done, nb, last);
             have_p = last;
             done += nb;
         }
+        if (!more) break;
         STAMP(1);
         if (done > 0) {   // bring the left-over (< 28) to the front; source and destination do not overlap
             const int left = qn - done;
@@ -1082,14 +1210,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         }
         STAMP(8);
     }
-    if (qn > 0) {
-        if (lane < GRP) {   // null records behind the last survivor: opacity 0 -> alpha 0 -> never pass
-            Q.a[qn + lane] = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, 0x7fffffff));
-            Q.b[qn + lane] = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, -1));
-        }
-        __builtin_amdgcn_wave_barrier();
-        run_batch(0, qn, false);
-    }
+    if (DEFER) issue_pending();   // the last batch's colour gradients
     STAMP_END();
 }
 

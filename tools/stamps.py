@@ -11,7 +11,10 @@ from gaussiangrasper_amd.camera import ring_cameras
 from gaussiangrasper_amd.scene import make_scene
 
 out = os.path.join(os.path.dirname(gg_build.OUT), "libgg_raster_stamps.so")
-gg_build.build(force=True, extra_flags=("-DGG_STAMPS",), out=out)
+if os.environ.get("STAMPS_LIB"):      # a prebuilt diagnostic variant (e.g. -DGG_EPI_SKIP=1)
+    out = os.path.abspath(os.environ["STAMPS_LIB"])
+else:
+    gg_build.build(force=True, extra_flags=("-DGG_STAMPS",), out=out)
 _lib.LIB_PATH = out
 lib = _lib.load()
 dev = "cuda:0"
@@ -42,16 +45,24 @@ feat = sc.feature.detach().requires_grad_(True)
 x = xys.detach().requires_grad_(True)
 vo = torch.randn(h, w, 32, device=dev)
 for rep in range(2):
+    torch.cuda.synchronize()
+    lib.gg_debug_stamps(None, 1)
     out_ = ops.NDRasterizeGaussians.apply(x, depths, radii, conics.detach(), nth, feat, opac.detach(), h, w,
                                           torch.zeros(32, device=dev))
+    if rep == 1:
+        report("32-channel FORWARD (phases: 0 prologue, 1 staging, 4 walk, 7 epilogue; a batch = a chunk of 64 list entries)")
     lib.gg_debug_stamps(None, 1)
     out_.backward(vo)
 report("32-channel backward")
 tail = torch.rand(n, 7, device=dev).requires_grad_(True)
 vos = [torch.randn(h, w, 32, device=dev), torch.randn(h, w, 7, device=dev)]
 for rep in range(2):
+    torch.cuda.synchronize()
+    lib.gg_debug_stamps(None, 1)
     imgs = ops.rasterize_segments(x, depths, radii, conics.detach(), nth, opac.detach(), h, w,
                                   [(feat, torch.zeros(32, device=dev)), (tail, torch.zeros(7, device=dev))])
+    if rep == 1:
+        report("pair FORWARD (32 + 7)")
     lib.gg_debug_stamps(None, 1)
     torch.autograd.backward(imgs, vos)
 report("pair backward (32 + 7)")

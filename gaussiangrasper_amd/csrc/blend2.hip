@@ -128,9 +128,11 @@ __device__ __forceinline__ int stage_chunk(LIST &L, int lane, int e, bool valid,
                                            const GRec *__restrict__ rec,
                                            const float *__restrict__ colors, int C, int ch_off, int nch,
                                            float xlo, float xhi, float ylo, float yhi,
-                                           const Seg2 *seg2 = nullptr) {
-    const float4 ra = reinterpret_cast<const float4 *>(rec + g)[0];
-    const float4 rb = reinterpret_cast<const float4 *>(rec + g)[1];
+                                           const Seg2 *seg2 = nullptr,
+                                           const float4 *pre = nullptr /* the record, loaded by the caller */,
+                                           const float *pre2 = nullptr /* 8 colours of the second array, ditto */) {
+    const float4 ra = pre ? pre[0] : reinterpret_cast<const float4 *>(rec + g)[0];
+    const float4 rb = pre ? pre[1] : reinterpret_cast<const float4 *>(rec + g)[1];
     const bool hit = valid && rec_hits_rect(ra, rb, xlo, xhi, ylo, yhi);
     const uint64_t m = __ballot(hit);
     const int cnt = __builtin_popcountll(m);
@@ -142,7 +144,10 @@ __device__ __forceinline__ int stage_chunk(LIST &L, int lane, int e, bool valid,
         float4 ra2 = ra;
         if (WIDE) {
             cc.x = __builtin_bit_cast(float, g);
-            if (seg2) {   // the second array's colours ride in the record (d, e)
+            if (seg2 && pre2) {
+                L.d[pos] = make_float4(pre2[0], pre2[1], pre2[2], pre2[3]);
+                L.e[pos] = make_float4(pre2[4], pre2[5], pre2[6], pre2[7]);
+            } else if (seg2) {   // the second array's colours ride in the record (d, e)
                 const float *c2 = seg2->colors + (size_t)g * seg2->C2;
                 const int n2 = seg2->nch2;
                 L.d[pos] = make_float4(c2[0], n2 > 1 ? c2[1] : 0.f, n2 > 2 ? c2[2] : 0.f, n2 > 3 ? c2[3] : 0.f);
@@ -231,12 +236,51 @@ __global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_fwd_kernel(
     const bool wch_ok = FULL || wch < nch;
 
     STAMP(0);
+    // The two dependent loads of the staging (list id, then the 32-byte record) run ahead of the walk: the id two
+    // chunks, the record one chunk (in-kernel stamps: staging, i.e. waiting for them, was 23-33 % of a forward
+    // wave's lifetime).  PIPE: only the wide builds have the registers for it (9 more).
+    // (measured: pair forward 0.490 -> 0.480 ms; the plain 32-channel build loses its fifth wave per SIMD to the 9
+    //  registers, 0.372 -> 0.394: EX only.  Requesting the second array's colour row of every list entry a chunk
+    //  ahead as well — 8 more registers, 3x the rows the survivors of the cull need — measured slower: 0.498.)
+    constexpr bool PIPE = WIDE && EX;
+    constexpr bool PIPE2 = false;
+    auto id_at = [&](int b) { return (b + lane < range.y) ? ids[b + lane] : 0; };
+    int g_n1 = PIPE ? id_at(range.x) : 0, g_n2 = PIPE ? id_at(range.x + 64) : 0;
+    float4 rec_n[2];
+    float c2_n[8];
+    auto load_c2 = [&](int g, float (&dst)[8]) {
+        const float *c2 = seg2.colors + (size_t)g * seg2.C2;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) dst[c] = c < seg2.nch2 ? c2[c] : 0.0f;
+    };
+    if (PIPE) {
+        rec_n[0] = reinterpret_cast<const float4 *>(rec + g_n1)[0];
+        rec_n[1] = reinterpret_cast<const float4 *>(rec + g_n1)[1];
+        if (PIPE2) load_c2(g_n1, c2_n);
+    }
     for (int base = range.x; base < range.y; base += 64) {
         if (__ballot(!done) == 0ull) break;
         const int e = base + lane;
-        const int g_cur = e < range.y ? ids[e] : 0;   // (loading it a chunk ahead measures the same here)
+        int g_cur;
+        float4 rec_c[2];
+        float c2_c[8];
+        if (PIPE) {
+            g_cur = g_n1;
+            rec_c[0] = rec_n[0];
+            rec_c[1] = rec_n[1];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) c2_c[c] = PIPE2 ? c2_n[c] : 0.0f;
+            g_n1 = g_n2;                                  // ids of chunk + 1 (requested an iteration ago)
+            rec_n[0] = reinterpret_cast<const float4 *>(rec + g_n1)[0];
+            rec_n[1] = reinterpret_cast<const float4 *>(rec + g_n1)[1];
+            if (PIPE2) load_c2(g_n1, c2_n);
+            g_n2 = id_at(base + 128);
+        } else {
+            g_cur = e < range.y ? ids[e] : 0;
+        }
         const int cnt = stage_chunk<CH, WIDE, false, LIST>(L, lane, e, e < range.y, g_cur, rec, colors, C,
-                                                           ch_off, nch, xlo, xhi, ylo, yhi, EX ? &seg2 : nullptr);
+                                                           ch_off, nch, xlo, xhi, ylo, yhi, EX ? &seg2 : nullptr,
+                                                           PIPE ? rec_c : nullptr, PIPE2 ? c2_c : nullptr);
         WALK_STAT(0, min(64, range.y - base));
         STAMP(1);
         STAMP_BATCH();

@@ -780,6 +780,22 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                       ((reinterpret_cast<uintptr_t>(v_out) & 15) == 0);   // wave-uniform
     float voa_keep[2][LEAN ? 1 : KS], vob_keep[LEAN ? 1 : 32];
     float Bsum = 0.0f;
+    // A wave starts with a chain of dependent loads: tile range -> final_idx -> (wave maximum) -> list ids -> records.
+    // The ids of the first chunk are requested as soon as final_idx is there, i.e. BEFORE the cotangent tile is waited
+    // for and re-laid, and the first records right after that: two of the chain's latencies run beside the tile's.
+    auto wave_hi = [&]() {
+        int h = fin;
+        for (int off = 32; off > 0; off >>= 1) h = max(h, __shfl_xor(h, off, 64));
+        return __builtin_amdgcn_readfirstlane(h);
+    };
+    auto load_id = [&](int top_) {
+        const int e_ = top_ - 64 + lane;
+        return (top_ > range.x && e_ >= range.x) ? ids[e_] : 0;
+    };
+    int hi, g_first;
+    // records of the NEXT chunk, requested between a batch's walk and its flush: the vector memory counter is
+    // in order, so loads issued behind the flush's 24-32 atomic instructions wait for every one of them
+    float4 ra_p = make_float4(0.f, 0.f, 0.f, 0.f), rb_p = ra_p;
     if (tile_lds) {
         float4 rowv[8];
 #pragma unroll
@@ -789,6 +805,8 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                           ? *reinterpret_cast<const float4 *>(v_out + ((size_t)pi * img_w + pj) * C + ch_off + 4 * (lane & 7))
                           : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        hi = wave_hi();
+        g_first = load_id(hi);
 #pragma unroll
         for (int r = 0; r < 8; ++r)   // pixel 8 r + (lane >> 3), chunk (lane & 7) ^ (pixel & 7)
             *reinterpret_cast<float4 *>(fac_w + (8 * r + (lane >> 3)) * 32 + 4 * ((lane & 7) ^ (lane >> 3))) = rowv[r];
@@ -820,12 +838,18 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         }
         __builtin_amdgcn_wave_barrier();   // the slab is free again
     } else {
+        hi = wave_hi();
+        g_first = load_id(hi);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const float v = (inside && (FULL || c < nch)) ? v_out[p * C + ch_off + c] : 0.0f;
             if (FULL || c < nch) Bsum = __builtin_fmaf(background[ch_off + c], v, Bsum);
         }
     }
+    // the first chunk's records: requested here (the ids have arrived beside the tile), consumed after the rest of
+    // the prologue
+    ra_p = reinterpret_cast<const float4 *>(rec + g_first)[0];
+    rb_p = reinterpret_cast<const float4 *>(rec + g_first)[1];
     if (EX) {
         float t8[8];
 #pragma unroll
@@ -881,10 +905,6 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
 #pragma unroll
         for (int s = 0; s < 32; ++s) vob_keep[LEAN ? 0 : s] = tb[s];
     }
-    int hi = fin;
-    for (int off = 32; off > 0; off >>= 1) hi = max(hi, __shfl_xor(hi, off, 64));
-    hi = __builtin_amdgcn_readfirstlane(hi);
-
     bool owner;
     const int myvar = R::var(lane, owner);
     const int my_q = myvar / KG, my_k = myvar - my_q * KG;
@@ -899,9 +919,6 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     // vector loads of the colour half-rows need 16-byte aligned rows
     const bool vec = FULL && (C % 4 == 0) && (ch_off % 4 == 0) && ((reinterpret_cast<uintptr_t>(colors) & 15) == 0);
 
-    // records of the NEXT chunk, requested between a batch's walk and its flush: the vector memory counter is
-    // in order, so loads issued behind the flush's 24-32 atomic instructions wait for every one of them
-    float4 ra_p = make_float4(0.f, 0.f, 0.f, 0.f), rb_p = ra_p;
     int g_nxt = 0;   // ids of the next chunk (loaded one chunk ahead)
     // DEFER: the parked batch's colour gradients: acc register r of lane l at slab[64 r + l], the second array's
     // at slab[1024 + 64 (4 mb + r) + l]
@@ -1226,13 +1243,9 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
 
     int qn = 0;   // queued survivors (wave-uniform)
     // the first of the two dependent loads of the staging (id, then record) runs one chunk ahead of the walk
-    auto load_id = [&](int top_) {
-        const int e_ = top_ - 64 + lane;
-        return (top_ > range.x && e_ >= range.x) ? ids[e_] : 0;
-    };
-    g_nxt = load_id(hi);
+    g_nxt = g_first;
     STAMP(0);
-    bool have_p = false;   // wave-uniform: ra_p / rb_p hold this chunk's records
+    bool have_p = true;   // wave-uniform: ra_p / rb_p hold this chunk's records
     // ONE call site of run_batch (the tail batch runs through the same loop): inlined twice, the allocator kept two
     // sets of loop invariants and spilled one
     for (int top = hi;; top -= 64) {

@@ -13,5 +13,6 @@ run sq2 --pmc SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_V
 run fetch --pmc FETCH_SIZE
 run write --pmc WRITE_SIZE
 run occ --pmc VALUBusy OccupancyPercent MemUnitStalled
+run atom --pmc TCC_EA0_ATOMIC_sum TCP_UTCL1_TRANSLATION_MISS_sum
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $out/stats.log 2>&1
 find $out -name "*.csv" | head -40

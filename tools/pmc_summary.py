@@ -10,8 +10,8 @@ src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 NAMES = {"blend2_fwd_kernel<32, true, true, true": "blend_fwd_pair_kernel<40>",
          "blend2_fwd_kernel<3,": "blend_fwd_kernel<3>", "blend2_fwd_kernel<8,": "blend_fwd_kernel<8>",
          "blend2_fwd_kernel<32,": "blend_fwd_kernel<32>", "blend2_bwd_narrow_kernel<3,": "blend_bwd_kernel<3>",
-         "blend2_bwd_narrow_kernel<8,": "blend_bwd_kernel<8>", "blend2_bwd_wide_kernel<true, 0, 32, false, false>": "blend_bwd_kernel<32>",
-         "blend2_bwd_wide_kernel<true, 0, 32, false, true>": "blend_bwd_pair_kernel<40>"}
+         "blend2_bwd_narrow_kernel<8,": "blend_bwd_kernel<8>", "blend2_bwd_wide_kernel<true, 0, 32, false, false": "blend_bwd_kernel<32>",
+         "blend2_bwd_wide_kernel<true, 0, 32, false, true": "blend_bwd_pair_kernel<40>"}
 
 
 def short(kernel):
@@ -62,7 +62,8 @@ for name in sorted({r[0] for r in rows}):
     for ctr, key in (("SQ_INSTS_VALU", "insts_valu"), ("SQ_INSTS_SALU", "insts_salu"), ("SQ_INSTS_SMEM", "insts_smem"),
                      ("SQ_WAVE_CYCLES", "wave_cycles"), ("SQ_WAIT_ANY", "wait_any"), ("SQ_WAIT_INST_ANY", "wait_inst_any"),
                      ("SQ_ACTIVE_INST_ANY", "active_inst_any"), ("VALUBusy", "valu_busy_pct"),
-                     ("OccupancyPercent", "occupancy_pct")):
+                     ("OccupancyPercent", "occupancy_pct"), ("TCC_EA0_ATOMIC_sum", "atomic_requests_64B"),
+                     ("TCP_UTCL1_TRANSLATION_MISS_sum", "utcl1_misses")):
         if (name, ctr) in mean:
             rec[key] = mean[(name, ctr)]
     if name in mix:

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_fwd_kernel(
     const int tile = blend_tile_wave<GG_WPB_OTHER>(blockIdx.x, threadIdx.x, ntiles, wave);
     if (tile < 0) return;
     const int lane = threadIdx.x & 63;
-    const int wslot = GG_WPB_OTHER == 4 ? wave : 0;   // this wave's LDS
+    const int wslot = wave & (GG_WPB_OTHER - 1);   // this wave's LDS
     LIST &L = lists[wslot];
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int qx0 = tx * GG_BLOCK + (wave & 1) * 8, qy0 = ty * GG_BLOCK + (wave >> 1) * 8;
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_bwd_narrow_kernel(
     const int tile = blend_tile_wave<GG_WPB_OTHER>(blockIdx.x, threadIdx.x, ntiles, wave);
     if (tile < 0) return;
     const int lane = threadIdx.x & 63;
-    const int wslot = GG_WPB_OTHER == 4 ? wave : 0;   // this wave's LDS
+    const int wslot = wave & (GG_WPB_OTHER - 1);   // this wave's LDS
     LIST &L = lists[wslot];
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int qx0 = tx * GG_BLOCK + (wave & 1) * 8, qy0 = ty * GG_BLOCK + (wave >> 1) * 8;
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     const int tile = blend_tile_wave<GG_WPB_WIDE_BWD>(blockIdx.x, threadIdx.x, ntiles, wave);
     if (tile < 0) return;
     const int lane = threadIdx.x & 63;
-    const int wslot = GG_WPB_WIDE_BWD == 4 ? wave : 0;   // this wave's LDS
+    const int wslot = wave & (GG_WPB_WIDE_BWD - 1);   // this wave's LDS
     float *vt = s_vt[wslot];
     WaveQueue &Q = queues[wslot];
     float *fac_w = s_fac[wslot];

@@ -62,10 +62,13 @@ static __device__ const int *g_tile_order = nullptr;
 #endif
 template <int WPB>
 __device__ __forceinline__ int blend_tile_wave(int bid, int tid, int ntiles, int &wave) {
-    static_assert(WPB == 4 || WPB == 1, "four quadrants per workgroup, or one");
+    static_assert(WPB == 4 || WPB == 2 || WPB == 1, "four, two or one quadrant per workgroup");
     int k = bid;
     if (WPB == 4) {
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    } else if (WPB == 2) {   // workgroups b and b + 8: the upper and the lower pair of quadrants of one tile
+        wave = 2 * ((bid >> 3) & 1) + __builtin_amdgcn_readfirstlane(tid >> 6);
+        k = ((bid >> 4) << 3) | (bid & 7);
     } else {
         wave = (bid >> 3) & 3;
         k = ((bid >> 5) << 3) | (bid & 7);

@@ -196,7 +196,8 @@ def _blend_inputs(oracle, n, h, w, ch, seed=0, cfg=1):
                                       (50000, 300, 400, 32), (20000, 150, 200, 39),
                                       (5000, 100, 120, 128), (300000, 600, 800, 32),
                                       (3000, 64, 80, 2), (3000, 64, 80, 8), (3000, 64, 80, 12),
-                                      (3000, 64, 80, 17), (3000, 64, 80, 35)])
+                                      (3000, 64, 80, 17), (3000, 64, 80, 35),
+                                      (4000, 90, 100, 32), (4000, 83, 101, 64)])   # ragged quadrants, float4 image rows
 def test_blend_fwd_bitexact(oracle, n, h, w, ch):
     xys, depths, radii, conics, nth, colors, opac, bg = _blend_inputs(oracle, n, h, w, ch)
     ref_out, saved = oracle.rasterize_fwd(xys, depths, radii, conics, nth, colors, opac, h, w, bg)
@@ -222,7 +223,8 @@ def test_blend_fwd_bitexact(oracle, n, h, w, ch):
                                       (2000, 48, 64, 5), (50000, 300, 400, 3),
                                       (50000, 300, 400, 32), (20000, 150, 200, 39),
                                       (3000, 64, 80, 2), (3000, 64, 80, 8), (3000, 64, 80, 12),
-                                      (3000, 64, 80, 17), (3000, 64, 80, 35)])
+                                      (3000, 64, 80, 17), (3000, 64, 80, 35),
+                                      (4000, 90, 100, 32), (4000, 83, 101, 64)])   # ragged quadrants, tile through LDS
 def test_blend_bwd(oracle, n, h, w, ch):
     """tolerance: |gpu-oracle| <= 1e-6*max|grad| + 5e-5*|grad| (fp32 atomics vs fp64-summed oracle; the
     kernel uses the algebraically-equal scalar-W form of v_alpha, see blend.hip header).  Set from the
@@ -803,11 +805,11 @@ def test_direct_gradient_accumulation_equals_autograd_accumulation():
         assert_close(_np(b), _np(a), name, rtol=1e-4, atol_frac=2e-6)
 
 
-def test_rasterize_segments_equals_separate_calls(oracle):
+@pytest.mark.parametrize("n,h,w", [(20000, 150, 200), (6000, 91, 101)])   # the second: ragged quadrants both ways
+def test_rasterize_segments_equals_separate_calls(oracle, n, h, w):
     """RasterizeSegments (feature 32 | rgb+depth+normal 7 | a 3-channel array): images bit-identical to
     NDRasterize on each array; geometry gradients = the sum over the separate calls; colour gradients per
     array — against the oracle with the tolerance of test_blend_bwd"""
-    n, h, w = 20000, 150, 200
     xys, depths, radii, conics, nth, colors, opac, bg = _blend_inputs(oracle, n, h, w, 42, seed=8)
     segs = [(colors[:, :32].copy(), bg[:32].copy()), (colors[:, 32:39].copy(), bg[32:39].copy()),
             (colors[:, 39:42].copy(), bg[39:42].copy())]

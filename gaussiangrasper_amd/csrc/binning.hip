@@ -64,7 +64,7 @@ extern "C" int gg_count_intersects(int N, const int32_t *num_tiles_hit, int64_t 
     GG_REQUIRE(N >= 0, "num_points < 0");
     GG_REQUIRE(out != nullptr, "null output");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(out, 0, sizeof(int64_t), s) != hipSuccess) {
+    if (gg_fill_async(out, 0, sizeof(int64_t), s) != hipSuccess) {
         gg_set_error("gg_count_intersects: memset failed");
         return GG_ERR_LAUNCH;
     }
@@ -447,7 +447,7 @@ static int bin_sort_impl(int N, int64_t I, const int64_t *I_dev, const float *xy
     GG_REQUIRE(tile_bins != nullptr, "null tile_bins");
     hipStream_t s = (hipStream_t)stream;
     const int T = tiles_x * tiles_y;
-    if (hipMemsetAsync(tile_bins, 0, sizeof(int32_t) * 2 * (size_t)T, s) != hipSuccess) {
+    if (gg_fill_async(tile_bins, 0, sizeof(int32_t) * 2 * (size_t)T, s) != hipSuccess) {
         gg_set_error("gg_bin_sort: memset failed");
         return GG_ERR_LAUNCH;
     }
@@ -471,7 +471,7 @@ static int bin_sort_impl(int N, int64_t I, const int64_t *I_dev, const float *xy
     const uint32_t *order = va;
     // 2. offsets in depth order
     int nsb = (N + SC_TILE - 1) / SC_TILE;
-    if (hipMemsetAsync(w.block_sums, 0, gg_scan_state_bytes(nsb), s) != hipSuccess) {
+    if (gg_fill_async(w.block_sums, 0, gg_scan_state_bytes(nsb), s) != hipSuccess) {
         gg_set_error("gg_bin_sort: memset failed");
         return GG_ERR_LAUNCH;
     }
@@ -489,8 +489,8 @@ static int bin_sort_impl(int N, int64_t I, const int64_t *I_dev, const float *xy
     // out-of-range tile id and id 0, so they sort to the end and are never dereferenced
     // (with a device-side count every processed entry is emitted: nothing to pre-fill)
     if (!I_dev) {
-        (void)hipMemsetAsync(kcur, 0xFF, sizeof(uint32_t) * (size_t)I, s);
-        (void)hipMemsetAsync(vcur, 0, sizeof(uint32_t) * (size_t)I, s);
+        (void)gg_fill_async(kcur, 0xFF, sizeof(uint32_t) * (size_t)I, s);
+        (void)gg_fill_async(vcur, 0, sizeof(uint32_t) * (size_t)I, s);
     }
     hipLaunchKernelGGL(emit_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, order, w.offsets,
                        xys, radii, tiles_x, tiles_y, I, I_dev, kcur, vcur);

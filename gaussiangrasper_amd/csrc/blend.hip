@@ -314,26 +314,26 @@ static int blend_bwd_impl(int C, int N, int img_h, int img_w, const int32_t *ids
         fail = false;
         const bool in_record = geom_stride > 0 && color_stride == geom_stride && v_colors == v_xy + 6;
         if (!in_record && !acc_colors)
-            fail = hipMemsetAsync(v_colors, 0, sizeof(float) * (color_stride ? color_stride : C) * n, s) !=
+            fail = gg_fill_async(v_colors, 0, sizeof(float) * (color_stride ? color_stride : C) * n, s) !=
                    hipSuccess;
     } else if (geom_stride > 0) {
         // interleaved records {xy, conic, opacity[, colours]} of geom_stride floats per Gaussian
         GG_REQUIRE(v_conic == v_xy + 2 && v_opacity == v_xy + 5, "interleaved geometry gradients: "
                    "v_conic = v_xy + 2 and v_opacity = v_xy + 5 expected");
-        fail = hipMemsetAsync(v_xy, 0, sizeof(float) * geom_stride * n, s) != hipSuccess;
+        fail = gg_fill_async(v_xy, 0, sizeof(float) * geom_stride * n, s) != hipSuccess;
         if (!(color_stride == geom_stride && v_colors == v_xy + 6) && !acc_colors)   // colours live elsewhere
-            fail |= hipMemsetAsync(v_colors, 0, sizeof(float) * (color_stride ? color_stride : C) * n, s) !=
+            fail |= gg_fill_async(v_colors, 0, sizeof(float) * (color_stride ? color_stride : C) * n, s) !=
                     hipSuccess;
     } else if (!acc_colors && color_stride == 0 && v_conic == v_xy + 2 * n && v_opacity == v_conic + 3 * n &&
                v_colors == v_opacity + n) {
-        fail = hipMemsetAsync(v_xy, 0, sizeof(float) * (6 + (size_t)C) * n, s) != hipSuccess;
+        fail = gg_fill_async(v_xy, 0, sizeof(float) * (6 + (size_t)C) * n, s) != hipSuccess;
     } else {
-        fail = hipMemsetAsync(v_xy, 0, sizeof(float) * 2 * n, s) != hipSuccess;
-        fail |= hipMemsetAsync(v_conic, 0, sizeof(float) * 3 * n, s) != hipSuccess;
+        fail = gg_fill_async(v_xy, 0, sizeof(float) * 2 * n, s) != hipSuccess;
+        fail |= gg_fill_async(v_conic, 0, sizeof(float) * 3 * n, s) != hipSuccess;
         if (!acc_colors)
-            fail |= hipMemsetAsync(v_colors, 0, sizeof(float) * (color_stride ? color_stride : C) * n, s) !=
+            fail |= gg_fill_async(v_colors, 0, sizeof(float) * (color_stride ? color_stride : C) * n, s) !=
                     hipSuccess;
-        fail |= hipMemsetAsync(v_opacity, 0, sizeof(float) * n, s) != hipSuccess;
+        fail |= gg_fill_async(v_opacity, 0, sizeof(float) * n, s) != hipSuccess;
     }
     if (fail) {
         gg_set_error("gg_blend_bwd: memset failed");
@@ -349,8 +349,8 @@ static int blend_bwd_impl(int C, int N, int img_h, int img_w, const int32_t *ids
         dw = det_ws_layout(det_ws, N, C, I);
         det.p = dw.slab;
         det.ks = C + 6 * nchunks;
-        if (hipMemsetAsync(dw.slab, 0, sizeof(float) * 4 * (size_t)det.ks * (size_t)I, s) != hipSuccess ||
-            hipMemsetAsync(dw.seg, 0, 8 * (size_t)N, s) != hipSuccess) {
+        if (gg_fill_async(dw.slab, 0, sizeof(float) * 4 * (size_t)det.ks * (size_t)I, s) != hipSuccess ||
+            gg_fill_async(dw.seg, 0, 8 * (size_t)N, s) != hipSuccess) {
             gg_set_error("gg_blend_bwd_deterministic: memset failed");
             return GG_ERR_LAUNCH;
         }
@@ -458,16 +458,16 @@ extern "C" int gg_blend_bwd_pair(int C, int C2, int N, int img_h, int img_w, con
     GG_REQUIRE(!in_record || geom_stride >= 6 + C2, "the record is too short for the second array's gradients");
     bool fail = false;
     if (geom_stride > 0) {
-        fail |= hipMemsetAsync(v_xy, 0, sizeof(float) * geom_stride * n, s) != hipSuccess;
+        fail |= gg_fill_async(v_xy, 0, sizeof(float) * geom_stride * n, s) != hipSuccess;
     } else {
-        fail |= hipMemsetAsync(v_xy, 0, sizeof(float) * 2 * n, s) != hipSuccess;
-        fail |= hipMemsetAsync(v_conic, 0, sizeof(float) * 3 * n, s) != hipSuccess;
-        fail |= hipMemsetAsync(v_opacity, 0, sizeof(float) * n, s) != hipSuccess;
+        fail |= gg_fill_async(v_xy, 0, sizeof(float) * 2 * n, s) != hipSuccess;
+        fail |= gg_fill_async(v_conic, 0, sizeof(float) * 3 * n, s) != hipSuccess;
+        fail |= gg_fill_async(v_opacity, 0, sizeof(float) * n, s) != hipSuccess;
     }
     if (!in_record)
-        fail |= hipMemsetAsync(v_colors2, 0, sizeof(float) * (color_stride2 ? color_stride2 : C2) * n, s) != hipSuccess;
+        fail |= gg_fill_async(v_colors2, 0, sizeof(float) * (color_stride2 ? color_stride2 : C2) * n, s) != hipSuccess;
     if (!acc_colors)
-        fail |= hipMemsetAsync(v_colors, 0, sizeof(float) * (color_stride ? color_stride : C) * n, s) != hipSuccess;
+        fail |= gg_fill_async(v_colors, 0, sizeof(float) * (color_stride ? color_stride : C) * n, s) != hipSuccess;
     if (fail) {
         gg_set_error("gg_blend_bwd_pair: memset failed");
         return GG_ERR_LAUNCH;

@@ -190,6 +190,9 @@ class ProjectGaussians(Function):
                 viewmat: Tensor, projmat: Tensor, fx: float, fy: float, cx: float, cy: float,
                 img_height: int, img_width: int, tile_bounds: Tuple[int, int, int],
                 clip_thresh: float = CLIP_THRESH_DEFAULT):
+        # cotangents nobody produced (cov3d always, others by route) arrive as None, not as zero-filled tensors:
+        # autograd's default materialisation was a 24 MB fill kernel per view for cov3d alone
+        ctx.set_materialize_grads(False)
         if means3d.ndim != 2 or means3d.shape[1] != 3:
             raise ValueError("means3d must have dimensions (N, 3)")
         n = means3d.shape[0]
@@ -698,6 +701,7 @@ class ActivateGaussians(Function):
 
     @staticmethod
     def forward(ctx, means, log_scales, quats, opacities, cam_pos):
+        ctx.set_materialize_grads(False)   # undefined cotangents arrive as None (handled in backward)
         dev = _require_hip(means, log_scales, quats, opacities, cam_pos)
         n = means.shape[0]
         if tuple(log_scales.shape) != (n, 3) or tuple(quats.shape) != (n, 4) or opacities.numel() != n:

@@ -74,7 +74,7 @@ __device__ __forceinline__ int blend_tile_wave(int bid, int tid, int ntiles, int
         k = ((bid >> 5) << 3) | (bid & 7);
     }
 #ifdef GG_ABLATION
-    if (g_tile_order) return k < ntiles ? g_tile_order[k] : -1;
+    if (g_tile_order) return k < ntiles ? __builtin_amdgcn_readfirstlane(g_tile_order[k]) : -1;   // (wave-uniform)
 #endif
     return xcd_tile(k, ntiles);
 }

@@ -15,7 +15,6 @@ calls of one view share ONE binning (tile sort), cached on the identity+version 
 from __future__ import annotations
 
 import ctypes as C
-import os
 from typing import Optional, Tuple
 
 import torch
@@ -859,7 +858,7 @@ class RasterizeSegments(Function):
         small = [i for i in range(k) if cols[i].shape[1] <= 8]
         rider = min(small, key=lambda i: cols[i].shape[1]) if small else None
         gwidth = 6 + (cols[rider].shape[1] if rider is not None else 0)
-        gstride = int(os.environ.get("GG_REC_STRIDE", "0")) or gwidth     # (experiment: padded records)
+        gstride = gwidth    # (records padded to 16 floats = one 64-byte atomic request each: measured, no change)
         rec_g = torch.empty(n, gstride, dtype=torch.float32, device=dev)
         v_xy, v_conic, v_opacity = rec_g[:, 0:2], rec_g[:, 2:5], rec_g[:, 5:6]
         order = ([rider] if rider is not None else []) + [i for i in range(k) if i != rider]

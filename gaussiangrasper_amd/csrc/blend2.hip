@@ -386,7 +386,8 @@ __global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_fwd_kernel(
     }
     STAMP(8);
 #ifndef GG_EPI_SKIP
-#define GG_EPI_SKIP 0   // diagnostic builds only (with GG_STAMPS): 1 no final_T / final_idx stores, 2 no image stores
+#define GG_EPI_SKIP 0   // diagnostic builds only (with GG_STAMPS): 1 no final_T / final_idx stores, 2 no image stores.
+                        // NEVER run a backward after a GG_EPI_SKIP=1 forward: final_idx is uninitialised (it faulted once)
 #endif
     if (GG_EPI_SKIP == 1) { KEEP(T); KEEP(last); }
     if (GG_EPI_SKIP != 1 && inside && write_final) {

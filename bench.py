@@ -85,6 +85,9 @@ def parse(argv=None):
     ap.add_argument("--no-secondary", "--no-fused", dest="no_secondary", action="store_true",
                     help="skip the measurement of the other route")
     ap.add_argument("--no-overlap", action="store_true", help="one all-reduce after the last view")
+    ap.add_argument("--no-view-pipeline", action="store_true",
+                    help="the views of a step strictly one after the other on one stream (default: backward of "
+                         "view k beside forward of view k + 1 on two streams)")
     ap.add_argument("--no-direct", action="store_true",
                     help="autograd accumulates every parameter gradient (no in-kernel accumulation "
                          "into the gradient bucket for the SH and feature parameters)")
@@ -269,7 +272,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
     ops = importlib.import_module(args.ops)
     from gaussiangrasper_amd.camera import ring_cameras
-    from gaussiangrasper_amd.dist import GradBucket, shard_views, train_step
+    from gaussiangrasper_amd.dist import GradBucket, shard_views, train_step, train_step_pipelined
     from gaussiangrasper_amd.pipeline import backward_view, render_view, seeded_cotangents
     from gaussiangrasper_amd.scene import make_scene
 
@@ -328,15 +331,26 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
         def render_and_backward(v):
             out = render_view(scene, views[v], ops, fused=fused)
             backward_view(out, cot)
+        render_and_backward.render = lambda v: render_view(scene, views[v], ops, fused=fused)
+        render_and_backward.backward = lambda out: backward_view(out, cot)
         return render_and_backward
 
     overlap = not args.no_overlap
+    pipe_streams_box = [None]
+    if torch.device(dev).type == "cuda" and not args.no_view_pipeline and not args.deterministic:
+        pipe_streams_box[0] = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+
+    def one_step(fn):
+        if pipe_streams_box[0] is not None:
+            train_step_pipelined(fn.render, fn.backward, bucket, my_views, pipe_streams_box[0], overlap=overlap)
+        else:
+            train_step(fn, bucket, my_views, overlap=overlap)
 
     def timed(fn, steps):
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            train_step(fn, bucket, my_views, overlap=overlap)
+            one_step(fn)
         barrier()
         return max_over_ranks(time.perf_counter() - t0)
 
@@ -344,14 +358,16 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
         """warm-up, the timed steps with the kernel timers OFF, then one profiled step"""
         fn = make_step(fused)
         for _ in range(warmup):
-            train_step(fn, bucket, my_views, overlap=overlap)
+            one_step(fn)
         t = timed(fn, args.steps)
         grads = bucket.gathered().detach().cpu().clone() if (args.dump_grads and rank == 0) else None
         kern, t_prof = {}, None
         if lib is not None and not args.no_prof:               # all ranks take part (collectives)
             lib.gg_prof_reset()
             lib.gg_prof_enable(1)
+            saved, pipe_streams_box[0] = pipe_streams_box[0], None   # per-kernel times: one stream, no overlap
             t_prof = timed(fn, 1)
+            pipe_streams_box[0] = saved
             lib.gg_prof_enable(0)
             kern = read_kernel_times(lib)
         return t, kern, t_prof, grads
@@ -391,6 +407,8 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
                                   if plugin_first else "shim route: the reference's 4 rasterize calls per view",
                                   args.views_per_step),
                    "route": args.route, "deterministic_backward": bool(args.deterministic),
+                   "view_pipeline": ("backward of view k beside forward of view k + 1 on two streams"
+                                     if pipe_streams_box[0] is not None else "off"),
                    "num_gaussians": args.points, "image": [args.height, args.width],
                    "feature_dim": args.feature_dim, "views_per_step_per_gpu": args.views_per_step,
                    "n_visible": n_vis, "num_intersects": n_isect,

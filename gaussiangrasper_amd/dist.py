@@ -210,6 +210,47 @@ def train_step(render_and_backward: Callable[[int], None], bucket: GradBucket, v
             bucket.all_reduce()
 
 
+def train_step_pipelined(render: Callable[[int], object], backward: Callable[[object], None], bucket: GradBucket,
+                         view_ids: Sequence[int], streams, reduce: bool = True, overlap: bool = True) -> None:
+    """train_step with the views of the step software-pipelined over two (or more) HIP streams: view k runs
+    forward AND backward on stream k mod S (autograd runs a backward node on its forward's stream), the forward
+    chains are ordered among themselves by events and so are the backward chains — so the only overlap is
+    backward(k) beside forward(k + 1).  The views of a step are independent until the optimizer step; what the
+    overlap buys is the second stream's kernels filling the first one's tails and launch gaps (a view is ~45
+    kernels, half of them a few microseconds long, and every blend kernel ends with ~20 % of its wave slots
+    empty).  Forward kernels never write a gradient buffer and the backward chains are serialised, so every
+    accumulation into the bucket happens one view at a time, as in train_step."""
+    cur = torch.cuda.current_stream()
+    bucket.zero_()
+    for s in streams:
+        s.wait_stream(cur)
+    ev_f = ev_b = None
+    view_ids = list(view_ids)
+    for k, v in enumerate(view_ids):
+        s = streams[k % len(streams)]
+        if reduce and overlap and k == len(view_ids) - 1:
+            bucket.arm()
+        with torch.cuda.stream(s):
+            if ev_f is not None:
+                s.wait_event(ev_f)          # one forward chain at a time (they share the binning's scratch order)
+            out = render(v)
+            ev_f = torch.cuda.Event()
+            ev_f.record(s)
+            if ev_b is not None:
+                s.wait_event(ev_b)          # one backward chain at a time: gradient accumulation
+            backward(out)
+            del out
+            ev_b = torch.cuda.Event()
+            ev_b.record(s)
+    for s in streams:
+        cur.wait_stream(s)
+    if reduce:
+        if overlap:
+            bucket.finish()
+        else:
+            bucket.all_reduce()
+
+
 # ------------------------------------------------------------------------------------------------
 # rank launcher: N fresh processes, one per GPU, started BEFORE the parent touches the GPU
 # ------------------------------------------------------------------------------------------------

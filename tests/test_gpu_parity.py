@@ -775,6 +775,46 @@ def test_speculative_binning_matches_the_exact_path_and_recovers_from_a_small_ca
     assert torch.equal(spec.tile_bins, exact.tile_bins)
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_views_pipelined_over_two_streams_give_the_sequential_gradient(fused):
+    """dist.train_step_pipelined (backward of view k beside forward of view k + 1 on two streams, forward chains
+    and backward chains each ordered by events): the same gradient bucket as the views one after the other, up to
+    the order of the float atomics — both routes, gradient sinks and the deferred SH expansion on"""
+    from gaussiangrasper_amd.dist import GradBucket, train_step, train_step_pipelined
+    views = ring_cameras(5, 200, 300, device=DEV)
+    res = []
+    for piped in (False, True):
+        sc = make_scene(30_000, feature_dim=32, config_index=5).to(DEV)
+        sc.scales.data.add_(0.8)
+        for p in sc.params():
+            p.requires_grad_(True)
+        bucket = GradBucket(sc.params())
+        bucket.enable_direct(P, defer_sh=True)
+        cots = {}
+
+        def render(v):
+            return (v, render_view(sc, views[v], P, fused=fused))
+
+        def backward(vo):
+            v, out = vo
+            if v not in cots:
+                cots[v] = seeded_cotangents(out, seed=v)
+            backward_view(out, cots[v])
+        P.clear_bin_cache()
+        for _ in range(2):     # the second step reuses cached cotangents and allocator blocks across streams
+            if piped:
+                streams = [torch.cuda.Stream(device=DEV), torch.cuda.Stream(device=DEV)]
+                train_step_pipelined(render, backward, bucket, range(5), streams, reduce=False)
+            else:
+                train_step(lambda v: backward(render(v)), bucket, range(5), reduce=False)
+            bucket._flush_deferred()
+        torch.cuda.synchronize()
+        res.append(bucket.gathered().detach().cpu().numpy().copy())
+        P.clear_grad_sinks()
+    assert np.abs(res[0]).sum() > 0
+    assert_close(res[1], res[0], f"pipelined vs sequential views (fused={fused})", rtol=1e-4, atol_frac=2e-6)
+
+
 def test_direct_gradient_accumulation_equals_autograd_accumulation():
     """GradBucket.enable_direct: the SH backward adds into the bucket itself and the 32-channel colour
     atomics land in the bucket: the same sums as autograd's accumulation, up to the order of the float

@@ -1,5 +1,10 @@
+#!/usr/bin/env python3
+"""How long the host takes to enqueue a view against how long the GPU takes to run it (bench workload, plugin route),
+for the sequential step and for the two-stream pipelined step (dist.train_step_pipelined).  r02: 2.05 / 2.10 ms
+sequential, 1.97 / 2.04 ms pipelined — the host is held to the GPU's pace by the per-view count check."""
 import sys, time, os
-sys.path[:0] = ['/root/repo', '/root/repo/shim']
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'shim')]
 import torch
 from gaussiangrasper_amd import ops
 from gaussiangrasper_amd.camera import ring_cameras

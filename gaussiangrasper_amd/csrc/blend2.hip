@@ -699,8 +699,13 @@ struct Seg2B {
 // registers (64 of them) but re-read from the cache-resident image at every batch — and <= 40 960 B of LDS:
 // batches of 28 slots (slab 7 280 B).  It gets its four workgroups (40 896 B, 128 VGPRs), but the walk of four
 // Gaussians at a time alone wants more than 128 registers: 81 spilled, 1.50 ms against 1.00.
-template <bool FULL, int ABL = 0, int CHD = 32, bool DET = false, bool EX = false, bool LEAN = false>
-__global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_per_eu(LEAN ? 4 : 3))) void blend2_bwd_wide_kernel(
+// S16 (experiment for FOUR waves per SIMD, -DGG_BWD_S16=1): batches of 16 slots on v_mfma_f32_16x16x4_f32 — D
+// accumulators 16 registers instead of 32, flush accumulators 8 instead of 16, slab 4 160 B instead of 8 320, the walk
+// re-reading its records.  k-step s of lane group q = lane >> 4 is channel 8 q + s, so a lane's B operand is still two
+// float4 loads of its Gaussian's colour row.  Needs 16-byte aligned colour rows and cotangent rows (the launcher
+// checks) and the full 32-channel chunk.
+template <bool FULL, int ABL = 0, int CHD = 32, bool DET = false, bool EX = false, bool LEAN = false, bool S16 = false>
+__global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_per_eu((LEAN || S16) ? 4 : 3))) void blend2_bwd_wide_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
     const float *__restrict__ colors, const float *__restrict__ background,
@@ -710,7 +715,8 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     DetSlab det = DetSlab(), Seg2B seg2 = Seg2B()) {
     static_assert(!EX || (FULL && CHD == 32 && !DET), "the second array rides on the full 32-channel build");
     static_assert(!LEAN || (!EX && !DET), "LEAN: plain builds only (so far)");
-    constexpr int NSLOT = LEAN ? 28 : B2_SLOTS;
+    static_assert(!S16 || (FULL && CHD == 32 && !DET && !LEAN && ABL == 0), "S16: the full 32-channel build");
+    constexpr int NSLOT = S16 ? 16 : (LEAN ? 28 : B2_SLOTS);
     constexpr int CH = CHD;
     constexpr int KS = CHD / 2;     // k-steps of the D product; lane half h supplies channels [KS h, KS h + KS)
     constexpr int KG = 6;
@@ -718,7 +724,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
 #ifndef GG_WALK_REREAD
 #define GG_WALK_REREAD 0
 #endif
-    constexpr bool REREAD = GG_WALK_REREAD != 0;
+    constexpr bool REREAD = GG_WALK_REREAD != 0 || S16;
     // DEFER: the colour gradients of a batch are not added right after its flush.  The vector memory counter is in
     // order, so every load issued behind the flush's 16-24 float-atomic instructions (the next chunk's records, the
     // next batch's colour rows) waited for all of them (in-kernel stamps: staging 22-35 %, colour-row wait 12 % of a
@@ -736,7 +742,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
 #ifndef GG_BWD_DEFER
 #define GG_BWD_DEFER 0
 #endif
-    constexpr bool DEFER = (GG_BWD_DEFER != 0) && !DET && !LEAN && ABL == 0;
+    constexpr bool DEFER = (GG_BWD_DEFER != 0) && !DET && !LEAN && ABL == 0 && !S16;
     __shared__ int s_hid[GG_WPB_WIDE_BWD][DEFER ? 32 : 1];   // DEFER: Gaussian of every slot of the parked batch
     using R = Red6<KB>;
     __shared__ WaveQueue queues[GG_WPB_WIDE_BWD];
@@ -779,7 +785,8 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     // by the pixel — and the three views are read from there.
     const bool tile_lds = !LEAN && FULL && CH == 32 && (C % 4 == 0) && (ch_off % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(v_out) & 15) == 0);   // wave-uniform
-    float voa_keep[2][LEAN ? 1 : KS], vob_keep[LEAN ? 1 : 32];
+    float voa_keep[2][(LEAN || S16) ? 1 : KS], vob_keep[(LEAN || S16) ? 1 : 32];
+    float va16[S16 ? 4 : 1][S16 ? 8 : 1], vb16[S16 ? 16 : 1][S16 ? 2 : 1];   // S16: A operands of D, B operands of the flush
     float Bsum = 0.0f;
     // A wave starts with a chain of dependent loads: tile range -> final_idx -> (wave maximum) -> list ids -> records.
     // The ids of the first chunk are requested as soon as final_idx is there, i.e. BEFORE the cotangent tile is waited
@@ -797,7 +804,62 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     // records of the NEXT chunk, requested between a batch's walk and its flush: the vector memory counter is
     // in order, so loads issued behind the flush's 24-32 atomic instructions wait for every one of them
     float4 ra_p = make_float4(0.f, 0.f, 0.f, 0.f), rb_p = ra_p;
-    if (tile_lds) {
+    if (S16) {   // the tile goes through the (16-slot) slab in two halves of 32 pixels
+        hi = wave_hi();
+        g_first = load_id(hi);
+        const int sl = lane & 15, q4 = lane >> 4;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            float4 rowv[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int pi = qy0 + 4 * hh + rr, pj = qx0 + (lane >> 3);
+                rowv[rr] = (pi < img_h && pj < img_w)
+                               ? *reinterpret_cast<const float4 *>(v_out + ((size_t)pi * img_w + pj) * C + ch_off + 4 * (lane & 7))
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {   // local pixel 8 rr + (lane >> 3), chunk (lane & 7) ^ (pixel & 7)
+                const int pl = 8 * rr + (lane >> 3);
+                *reinterpret_cast<float4 *>(fac_w + pl * 32 + 4 * ((lane & 7) ^ (pl & 7))) = rowv[rr];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if ((lane >> 5) == hh) {   // <background, v_out> of this half's pixels
+                const int pl = lane & 31;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float4 v = *reinterpret_cast<const float4 *>(fac_w + pl * 32 + 4 * (k ^ (pl & 7)));
+                    Bsum = __builtin_fmaf(background[ch_off + 4 * k], v.x, Bsum);
+                    Bsum = __builtin_fmaf(background[ch_off + 4 * k + 1], v.y, Bsum);
+                    Bsum = __builtin_fmaf(background[ch_off + 4 * k + 2], v.z, Bsum);
+                    Bsum = __builtin_fmaf(background[ch_off + 4 * k + 3], v.w, Bsum);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {   // A operands of D: pixel 16 (2 hh + b) + sl, channels 8 q4 .. + 7
+                const int pl = 16 * b + sl;
+#pragma unroll
+                for (int jq = 0; jq < 2; ++jq) {
+                    const float4 v = *reinterpret_cast<const float4 *>(fac_w + pl * 32 + 4 * ((2 * q4 + jq) ^ (pl & 7)));
+                    va16[S16 ? 2 * hh + b : 0][S16 ? 4 * jq : 0] = v.x;
+                    va16[S16 ? 2 * hh + b : 0][S16 ? 4 * jq + 1 : 0] = v.y;
+                    va16[S16 ? 2 * hh + b : 0][S16 ? 4 * jq + 2 : 0] = v.z;
+                    va16[S16 ? 2 * hh + b : 0][S16 ? 4 * jq + 3 : 0] = v.w;
+                }
+            }
+#pragma unroll
+            for (int ss = 0; ss < 8; ++ss) {   // B operands of the flush: pixel 4 (8 hh + ss) + q4, channel 16 nb + sl
+                const int pl = 4 * ss + q4;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const int c = 16 * nb + sl;
+                    vb16[S16 ? 8 * hh + ss : 0][S16 ? nb : 0] = fac_w[pl * 32 + 4 * ((c >> 2) ^ (pl & 7)) + (c & 3)];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // the slab is free again
+    } else if (tile_lds) {
         float4 rowv[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -826,16 +888,16 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
 #pragma unroll
             for (int jq = 0; jq < KS / 4; ++jq) {
                 const float4 v = *reinterpret_cast<const float4 *>(fac_w + pm * 32 + 4 * (((KS / 4) * half + jq) ^ (pm & 7)));
-                voa_keep[c][LEAN ? 0 : 4 * jq] = v.x;
-                voa_keep[c][LEAN ? 0 : 4 * jq + 1] = v.y;
-                voa_keep[c][LEAN ? 0 : 4 * jq + 2] = v.z;
-                voa_keep[c][LEAN ? 0 : 4 * jq + 3] = v.w;
+                voa_keep[c][(LEAN || S16) ? 0 : 4 * jq] = v.x;
+                voa_keep[c][(LEAN || S16) ? 0 : 4 * jq + 1] = v.y;
+                voa_keep[c][(LEAN || S16) ? 0 : 4 * jq + 2] = v.z;
+                voa_keep[c][(LEAN || S16) ? 0 : 4 * jq + 3] = v.w;
             }
         }
 #pragma unroll
         for (int s = 0; s < 32; ++s) {  // B operands: pixel 2 s + half, channel wch
             const int pq = 2 * s + half;
-            vob_keep[LEAN ? 0 : s] = fac_w[pq * 32 + 4 * ((wch >> 2) ^ (pq & 7)) + (wch & 3)];
+            vob_keep[(LEAN || S16) ? 0 : s] = fac_w[pq * 32 + 4 * ((wch >> 2) ^ (pq & 7)) + (wch & 3)];
         }
         __builtin_amdgcn_wave_barrier();   // the slab is free again
     } else {
@@ -895,16 +957,16 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
             dst[s] = ok ? vo[((size_t)pi * img_w + pj) * C + ch_off + wch] : 0.0f;
         }
     };
-    if (!LEAN && !tile_lds) {
+    if (!LEAN && !S16 && !tile_lds) {
         float ta[2][KS], tb[32];
         load_voa(v_out, ta);
         load_vob(v_out, tb);
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int s = 0; s < KS; ++s) voa_keep[c][LEAN ? 0 : s] = ta[c][s];
+            for (int s = 0; s < KS; ++s) voa_keep[c][(LEAN || S16) ? 0 : s] = ta[c][s];
 #pragma unroll
-        for (int s = 0; s < 32; ++s) vob_keep[LEAN ? 0 : s] = tb[s];
+        for (int s = 0; s < 32; ++s) vob_keep[(LEAN || S16) ? 0 : s] = tb[s];
     }
     bool owner;
     const int myvar = R::var(lane, owner);
@@ -984,12 +1046,50 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         if (ABL >= 6) { KEEP(n); return; }   // staging + queue only
         STAMP(1);
         STAMP_BATCH();
-        const int jl = lane & 31;
+        const int jl = S16 ? (lane & 15) : (lane & 31);
         const int cgid = (jl < n) ? __builtin_bit_cast(int, Q.b[base + jl].w) : -1;
+        if (S16) {   // D[64 pixels x 16 slots] as 4 x 10 v_mfma_f32_16x16x4_f32
+            const int q4 = lane >> 4;
+            const float *row = colors + (size_t)(cgid < 0 ? 0 : cgid) * C + ch_off + 8 * q4;
+            const float4 c0 = *reinterpret_cast<const float4 *>(row), c1 = *reinterpret_cast<const float4 *>(row + 4);
+            const float colb[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            float colb2[2] = {0.0f, 0.0f};
+            float va2[4][2];
+            if (EX) {
+                const float *row2 = seg2.colors + (size_t)(cgid < 0 ? 0 : cgid) * seg2.C2 + 2 * q4;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) colb2[t] = (2 * q4 + t < seg2.nch2) ? row2[t] : 0.0f;
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) {
+                    const float2 t2 = *reinterpret_cast<const float2 *>(vt + (16 * blk + jl) * 8 + 2 * q4);
+                    va2[blk][0] = t2.x;
+                    va2[blk][1] = t2.y;
+                }
+            }
+            f32x4 d[4];
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                d[blk] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(va16[S16 ? blk : 0][S16 ? t : 0], cgid < 0 ? 0.0f : colb[t],
+                                                                  d[blk], 0, 0, 0);
+                if (EX) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        d[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(va2[blk][t], cgid < 0 ? 0.0f : colb2[t], d[blk], 0, 0, 0);
+                }
+            }
+            // D[pixel 16 blk + 4 q4 + r][slot jl]
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fac_w[FIDX(jl, 16 * blk + 4 * q4 + r)] = d[blk][r];
+        }
         f32x16 d0, d1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) d0[r] = d1[r] = 0.0f;
-        if (ABL < 4) {
+        if (ABL < 4 && !S16) {
             float colb[KS];
             const float *row = colors + (size_t)(cgid < 0 ? 0 : cgid) * C + ch_off + KS * half;
             if (vec) {
@@ -1020,7 +1120,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) voa[c][s] = voa_keep[c][LEAN ? 0 : s];
+                    for (int s = 0; s < KS; ++s) voa[c][s] = voa_keep[c][(LEAN || S16) ? 0 : s];
             }
 #ifdef GG_STAMPS
             {   // make the colour rows arrive inside phase 2
@@ -1053,6 +1153,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         // D[pixel m][slot n]: lane holds n = lane & 31, m = (r & 3) + 8 (r >> 2) + 4 half (+ 32 for d1)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+            if (S16) continue;
             const int pix = (r & 3) + 8 * (r >> 2) + 4 * half;
             if (NSLOT == 32 || jl < NSLOT) {
                 fac_w[FIDX(jl, pix)] = d0[r];
@@ -1146,6 +1247,29 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         // are not written
         slotmask = __builtin_amdgcn_readfirstlane(slotmask);
         if (ABL >= 2 || slotmask == 0u) return;
+        if (S16) {   // FAC[16 slots x 64 pixels] * V_OUT[64 x 32 channels] as 2 x 16 v_mfma_f32_16x16x4_f32
+            int sl = lane & 15, q4 = lane >> 4;
+            asm volatile("" : "+v"(sl), "+v"(q4));
+            f32x4 acc2[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float a = fac_w[FIDX(sl, 4 * t + q4)];
+                acc2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vb16[S16 ? t : 0][0], acc2[0], 0, 0, 0);
+                acc2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vb16[S16 ? t : 0][S16 ? 1 : 0], acc2[1], 0, 0, 0);
+            }
+            // lane holds channel 16 nb + sl of slots 4 q4 + r
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int slot = 4 * q4 + r;
+                    const bool on = ((slotmask >> slot) & 1u) != 0u;
+                    if (on && acc2[nb][r] != 0.0f) {
+                        const int sg = __builtin_bit_cast(int, Q.b[base + slot].w);
+                        atomicAdd(v_colors + (size_t)sg * cs + ch_off + 16 * nb + sl, acc2[nb][r]);
+                    }
+                }
+        }
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -1156,12 +1280,14 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
             load_vob(vo, vob);
         } else {
 #pragma unroll
-            for (int s = 0; s < 32; ++s) vob[s] = vob_keep[LEAN ? 0 : s];
+            for (int s = 0; s < 32; ++s) vob[s] = vob_keep[(LEAN || S16) ? 0 : s];
         }
         const int arow = NSLOT == 32 ? (lane & 31) : min(lane & 31, NSLOT - 1);   // rows >= NSLOT: never written out
 #pragma unroll
-        for (int s = 0; s < 32; ++s)
+        for (int s = 0; s < 32; ++s) {
+            if (S16) continue;
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fac_w[FIDX(arow, 2 * s + half)], vob[s], acc, 0, 0, 0);
+        }
 #ifdef GG_STAMPS
 #pragma unroll
         for (int r = 0; r < 16; ++r) KEEP(acc[r]);
@@ -1173,7 +1299,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         asm volatile("" : "+v"(half_f), "+v"(k4_f));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            if (DEFER) continue;   // parked below, after the second array's flush has read fac
+            if (DEFER || S16) continue;   // parked below, after the second array's flush has read fac
             const int slot = (r & 3) + 8 * (r >> 2) + 4 * half_f;
             if (ABL >= 1) { KEEP(acc[r]); continue; }
             const bool on = ((slotmask >> slot) & 1u) != 0u && wch_ok;
@@ -1198,6 +1324,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
                 a4h[mb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (S16 && mb > 0) continue;
                 if (((slotmask >> (16 * mb)) & 0xffffu) == 0u) continue;
                 f32x4 a4 = {0.0f, 0.0f, 0.0f, 0.0f};
                 const int m = 16 * mb + n16;
@@ -1295,10 +1422,10 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
       }
         int done = 0;
         // 28 or 32 (a multiple of GRP): at most 27 stay behind, BQ_CAP; after the last chunk: what is left (<= 27)
-        while (more ? (qn - done >= 28) : (done == 0)) {
-            const int nb = !more ? qn : (LEAN ? NSLOT : min(32, (qn - done) & ~3));
+        while (more ? (qn - done >= (S16 ? 16 : 28)) : (done == 0)) {
+            const int nb = !more ? qn : ((LEAN || S16) ? NSLOT : min(32, (qn - done) & ~3));
             // (not in the pair build: 8 more registers across its two flushes spill 30 more, 1.30 -> 1.33 ms)
-            const bool last = more && (!EX || DEFER) && (qn - done - nb < 28) && (top - 64 > range.x);   // staging comes next
+            const bool last = more && (!EX || DEFER) && (qn - done - nb < (S16 ? 16 : 28)) && (top - 64 > range.x);   // staging comes next
             run_batch(done, nb, last);
             have_p = last;
             done += nb;
@@ -1323,6 +1450,9 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
 // =============================================================================================
 // launchers used by the C ABI in blend.hip
 // =============================================================================================
+#ifndef GG_BWD_S16
+#define GG_BWD_S16 1
+#endif
 #define B2_FWD_ARGS C, off, n, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, \
                     out_img, final_Ts, final_idx, write_final
 void gg_launch_blend2_fwd(int width, int C, int off, int n, int img_h, int img_w, int tiles_x,
@@ -1404,6 +1534,10 @@ void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w
         hipLaunchKernelGGL((blend2_bwd_narrow_kernel<3>), grid, block, 0, s, B2_BWDN_ARGS);
     else if (width == 8)
         hipLaunchKernelGGL((blend2_bwd_narrow_kernel<8>), grid, block, 0, s, B2_BWDN_ARGS);
+    else if (n == 32 && GG_BWD_S16 && C % 4 == 0 && off % 4 == 0 && (reinterpret_cast<uintptr_t>(colors) & 15) == 0 &&
+             (reinterpret_cast<uintptr_t>(v_out) & 15) == 0)   // the 16-slot build (four waves per SIMD)
+        hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, 0, 32, false, false, false, GG_BWD_S16 != 0>), gridw, blockw, 0, s,
+                           B2_BWDW_ARGS);
     else if (n == 32)
         hipLaunchKernelGGL((blend2_bwd_wide_kernel<true>), gridw, blockw, 0, s, B2_BWDW_ARGS);
     else if (n <= 8)
@@ -1449,6 +1583,13 @@ void gg_launch_blend2_bwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
 #define B2_PAIR(L) hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, L, 32, false, true>), grid, block, 0, s, C, 0, 32, \
         img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, final_Ts, final_idx, v_out, v_xy, \
         v_conic, v_colors, v_opacity, gstride, cstride, DetSlab(), seg2)
+    if (GG_BWD_S16 && C % 4 == 0 && (reinterpret_cast<uintptr_t>(colors) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(v_out) & 15) == 0) {   // the 16-slot build (four waves per SIMD)
+        hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, 0, 32, false, true, false, GG_BWD_S16 != 0>), grid, block, 0, s, C,
+                           0, 32, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, final_Ts, final_idx,
+                           v_out, v_xy, v_conic, v_colors, v_opacity, gstride, cstride, DetSlab(), seg2);
+        return;
+    }
 #ifdef GG_ABLATION
     switch (g_pair_ablate) {   // measurement twin (tools/kbench.py): wrong results on purpose
         case 1: B2_PAIR(1); return;

@@ -69,8 +69,8 @@ PRODUCT_OPS = "gaussiangrasper_amd.ops"
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=4, choices=(4, 5))
     ap.add_argument("--points", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)

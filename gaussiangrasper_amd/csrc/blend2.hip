@@ -194,8 +194,12 @@ __device__ __forceinline__ int stage_chunk(LIST &L, int lane, int e, bool valid,
 // =============================================================================================
 // EX: a second colour array of <= 8 channels (Seg2) is blended in the same walk as this 32-channel chunk
 // (gg_blend_fwd_pair: the plugin's feature | rgb+depth+normal forward in one walk instead of two)
+#ifndef GG_FWD_LEAN
+#define GG_FWD_LEAN 1
+#endif
 template <int CH, bool WIDE, bool FULL, bool EX = false, int FABL = 0>
-__global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_fwd_kernel(
+__global__ __launch_bounds__(64 * GG_WPB_OTHER) __attribute__((amdgpu_waves_per_eu((GG_FWD_LEAN != 0 && WIDE && EX) ? 5 : 1)))
+void blend2_fwd_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
     const float *__restrict__ colors, const float *__restrict__ background,
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_fwd_kernel(
     // (measured: pair forward 0.490 -> 0.480 ms; the plain 32-channel build loses its fifth wave per SIMD to the 9
     //  registers, 0.372 -> 0.394: EX only.  Requesting the second array's colour row of every list entry a chunk
     //  ahead as well — 8 more registers, 3x the rows the survivors of the cull need — measured slower: 0.498.)
-    constexpr bool PIPE = WIDE && EX;
+    constexpr bool PIPE = WIDE && EX && (GG_FWD_LEAN == 0);
     constexpr bool PIPE2 = false;
     auto id_at = [&](int b) { return (b + lane < range.y) ? ids[b + lane] : 0; };
     int g_n1 = PIPE ? id_at(range.x) : 0, g_n2 = PIPE ? id_at(range.x + 64) : 0;
@@ -289,9 +293,14 @@ __global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_fwd_kernel(
         for (int k = 0; k < cnt; k += GRP) {
             if (k > 0 && __ballot(!done) == 0ull) break;
             WALK_STAT(1, min(GRP, cnt - k));
+            // LEANF (pair build, experiment -DGG_FWD_LEAN=1): the records of a group are not all requested up front
+            // (12 ds_read_b128 = 48 registers in flight) but two Gaussians at a time, and the list position is read
+            // again where it is needed: a fifth wave per SIMD needs <= 96 registers.
+            constexpr bool LEANF = (GG_FWD_LEAN != 0) && WIDE && EX;
             float4 A[GRP], B[GRP], Cc[GRP], Cd[GRP];
 #pragma unroll
             for (int q = 0; q < GRP; ++q) {
+                if (LEANF) continue;
                 A[q] = L.a[GRP + k + q];
                 B[q] = L.b[GRP + k + q];
                 Cc[q] = L.c[GRP + k + q];
@@ -310,11 +319,16 @@ __global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_fwd_kernel(
             bool pass[GRP];
 #pragma unroll
             for (int q = 0; q < GRP; ++q) {
+                if (LEANF) {
+                    A[q] = L.a[GRP + k + q];
+                    B[q] = L.b[GRP + k + q];
+                }
                 const float dx = A[q].x - px, dy = A[q].y - py;
                 const float sigma = __builtin_fmaf(
                     0.5f, __builtin_fmaf(B[q].x * dx, dx, (B[q].z * dy) * dy), (B[q].y * dx) * dy);
                 alpha[q] = fminf(GG_ALPHA_MAX_FWD, A[q].z * gg_expf(-sigma));
                 pass[q] = sigma >= 0.0f && !(alpha[q] < GG_ALPHA_MIN);
+                if (LEANF && q == 1) __builtin_amdgcn_sched_barrier(0);
             }
             float vis[GRP];
 #pragma unroll
@@ -334,7 +348,7 @@ __global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_fwd_kernel(
                 }
 #endif
                 T = blend ? next_T : T;
-                last = blend ? __builtin_bit_cast(int, N8 ? A[q].w : Cc[q].w) : last;
+                last = blend ? __builtin_bit_cast(int, N8 ? A[q].w : (LEANF ? L.c[GRP + k + q].w : Cc[q].w)) : last;
                 done = done || stop;
                 if (EX && fabl < 3) {   // the second array's colours: read from the record right where they are used
                     const float4 xd = L.d[GRP + k + q], xe = L.e[GRP + k + q];

@@ -197,8 +197,11 @@ __device__ __forceinline__ int stage_chunk(LIST &L, int lane, int e, bool valid,
 #ifndef GG_FWD_LEAN
 #define GG_FWD_LEAN 1
 #endif
+#ifndef GG_FWD_WAVES
+#define GG_FWD_WAVES 5
+#endif
 template <int CH, bool WIDE, bool FULL, bool EX = false, int FABL = 0>
-__global__ __launch_bounds__(64 * GG_WPB_OTHER) __attribute__((amdgpu_waves_per_eu((GG_FWD_LEAN != 0 && WIDE && EX) ? 5 : 1)))
+__global__ __launch_bounds__(64 * GG_WPB_OTHER) __attribute__((amdgpu_waves_per_eu((GG_FWD_LEAN != 0 && WIDE && EX) ? GG_FWD_WAVES : 1)))
 void blend2_fwd_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,

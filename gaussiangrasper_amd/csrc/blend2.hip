@@ -1600,7 +1600,12 @@ void gg_launch_blend2_bwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
 #define B2_PAIR(L) hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, L, 32, false, true>), grid, block, 0, s, C, 0, 32, \
         img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, final_Ts, final_idx, v_out, v_xy, \
         v_conic, v_colors, v_opacity, gstride, cstride, DetSlab(), seg2)
-    if (GG_BWD_S16 && C % 4 == 0 && (reinterpret_cast<uintptr_t>(colors) & 15) == 0 &&
+#ifdef GG_ABLATION
+    const bool ablated = g_pair_ablate != 0;   // the ablated builds are the 32-slot ones
+#else
+    const bool ablated = false;
+#endif
+    if (GG_BWD_S16 && !ablated && C % 4 == 0 && (reinterpret_cast<uintptr_t>(colors) & 15) == 0 &&
         (reinterpret_cast<uintptr_t>(v_out) & 15) == 0) {   // the 16-slot build (four waves per SIMD)
         hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, 0, 32, false, true, false, GG_BWD_S16 != 0>), grid, block, 0, s, C,
                            0, 32, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, final_Ts, final_idx,

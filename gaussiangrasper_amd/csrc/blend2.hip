@@ -27,6 +27,12 @@
 #include "blend_common.h"
 
 #define GRP 4          // survivors per loop iteration
+// quad-list backward: 0 = a chunk's 64 records are requested when the queue is free for them (the wave waits for one
+// load per 64 survivors), 1 = requested between the previous chunk's last walk and its flush.  Measured (r03, bench
+// view): 1.000 / 1.014 ms, and a whole chunk ahead (8 registers across four batches: 16 spilled) 1.019.
+#ifndef GG_QR_PREFETCH
+#define GG_QR_PREFETCH 0
+#endif
 #define KEEP(x) asm volatile("" ::"v"(x))   // measurement builds: keep a value alive
 
 #ifdef GG_ABLATION
@@ -93,6 +99,12 @@ __device__ __forceinline__ unsigned long long gg_stamp() {
 #define STAMP_BATCH() do { } while (0)
 #define STAMP_END() do { } while (0)
 #endif
+#ifdef GG_STAMPS
+#ifndef GG_EPI_SKIP
+#define GG_EPI_SKIP 0
+#endif
+extern "C" int gg_debug_epi_skip() { return GG_EPI_SKIP; }
+#endif
 #define LIST_CAP 72    // 4 leading pads + 64 + 4 trailing pads
 
 // NC: colour float4s per record.  <= 3 channels: c = colours 0..2 and .w = list position; 8-channel
@@ -122,7 +134,7 @@ __device__ __forceinline__ int lane_prefix(uint64_t m) {
 
 // Stage one chunk: returns the survivor count; list[OFF + k] = k-th survivor in list order,
 // GRP null records (opacity 0 -> never pass) on both sides.
-template <int CH, bool WIDE, bool REL = false, typename LIST = WaveList>
+template <int CH, bool WIDE, bool REL = false, typename LIST = WaveList, bool QWT = false>
 __device__ __forceinline__ int stage_chunk(LIST &L, int lane, int e, bool valid,
                                            const int g /* ids[e], loaded by the caller one chunk ahead */,
                                            const GRec *__restrict__ rec,
@@ -130,9 +142,27 @@ __device__ __forceinline__ int stage_chunk(LIST &L, int lane, int e, bool valid,
                                            float xlo, float xhi, float ylo, float yhi,
                                            const Seg2 *seg2 = nullptr,
                                            const float4 *pre = nullptr /* the record, loaded by the caller */,
-                                           const float *pre2 = nullptr /* 8 colours of the second array, ditto */) {
+                                           const float *pre2 = nullptr /* 8 colours of the second array, ditto */,
+                                           float4 *qdst = nullptr /* quad list: next free record of this quadrant */,
+                                           int qprev_cnt = 0 /* quad list: survivors of the previous chunk (still in L) */) {
     const float4 ra = pre ? pre[0] : reinterpret_cast<const float4 *>(rec + g)[0];
     const float4 rb = pre ? pre[1] : reinterpret_cast<const float4 *>(rec + g)[1];
+    if (QWT) {
+        // quad list, late form: the PREVIOUS chunk's survivors leave from the list (still intact: compacted, in list
+        // order) behind this chunk's record request.  The vector memory counter is in order: stores issued in front
+        // of a load are waited for with it, stores behind it are not — and the compiler's wait for the records is
+        // vmcnt(2) only if no branch surrounds the stores: they are unconditional.  Lanes past the last survivor
+        // repeat its record (same address, same data); with no survivor at all every lane writes a dead record to
+        // the next free slot, which the next chunk's survivors (or nobody: it lies behind the count) overwrite.
+        __builtin_amdgcn_sched_barrier(0);
+        const int sl = max(min(lane, qprev_cnt - 1), 0);
+        const float4 pa = L.a[GRP + sl], pb = L.b[GRP + sl];
+        const int ppos = __builtin_bit_cast(int, L.c[GRP + sl].w) - 1;
+        float4 *q = qdst - 2 * (size_t)qprev_cnt + 2 * sl;
+        q[0] = make_float4(pa.x, pa.y, pa.z, __builtin_bit_cast(float, ppos));
+        q[1] = pb;
+        __builtin_amdgcn_sched_barrier(0);
+    }
     const bool hit = valid && rec_hits_rect(ra, rb, xlo, xhi, ylo, yhi);
     const uint64_t m = __ballot(hit);
     const int cnt = __builtin_popcountll(m);
@@ -200,16 +230,18 @@ __device__ __forceinline__ int stage_chunk(LIST &L, int lane, int e, bool valid,
 #ifndef GG_FWD_WAVES
 #define GG_FWD_WAVES 5
 #endif
-template <int CH, bool WIDE, bool FULL, bool EX = false, int FABL = 0>
+// QW: the wave persists the survivors of its quadrant cull (quad lists, blend_common.h) for the backward walk
+template <int CH, bool WIDE, bool FULL, bool EX = false, int FABL = 0, bool QW = false>
 __global__ __launch_bounds__(64 * GG_WPB_OTHER) __attribute__((amdgpu_waves_per_eu((GG_FWD_LEAN != 0 && WIDE && EX) ? GG_FWD_WAVES : 1)))
 void blend2_fwd_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
     const float *__restrict__ colors, const float *__restrict__ background,
     float *__restrict__ out_img, float *__restrict__ final_T, int32_t *__restrict__ final_idx,
-    int write_final, Seg2 seg2 = Seg2()) {
+    int write_final, Seg2 seg2 = Seg2(), QList ql = QList()) {
     constexpr bool N8 = !WIDE && CH > 3;          // 8-channel narrow record layout
     static_assert(!EX || WIDE, "the second array rides on the wide kernel");
+    static_assert(!QW || WIDE, "quad lists are written by the wide builds (their list record keeps position + 1 in c.w)");
     typedef WaveListT<EX ? 3 : (N8 ? 2 : 1)> LIST;
     __shared__ LIST lists[GG_WPB_OTHER];
     int wave;
@@ -230,6 +262,9 @@ void blend2_fwd_kernel(
     float T = 1.0f;
     int last = range.x;
     bool done = !inside;
+    // quad list of this quadrant: qn_prev survivors before the chunk staged last, cnt_last in it (wave-uniform)
+    float4 *qseg = QW ? ql.recs + 2 * ((size_t)4 * range.x + (size_t)wave * (range.y - range.x)) : nullptr;
+    int qn_prev = 0, cnt_last = 0;
     float acc[WIDE ? 1 : CH];
     float acc2[EX ? 8 : 1];
 #pragma unroll
@@ -285,9 +320,12 @@ void blend2_fwd_kernel(
         } else {
             g_cur = e < range.y ? ids[e] : 0;
         }
-        const int cnt = stage_chunk<CH, WIDE, false, LIST>(L, lane, e, e < range.y, g_cur, rec, colors, C,
+        if (QW) qn_prev += cnt_last;
+        const int cnt = stage_chunk<CH, WIDE, false, LIST, QW>(L, lane, e, e < range.y, g_cur, rec, colors, C,
                                                            ch_off, nch, xlo, xhi, ylo, yhi, EX ? &seg2 : nullptr,
-                                                           PIPE ? rec_c : nullptr, PIPE2 ? c2_c : nullptr);
+                                                           PIPE ? rec_c : nullptr, PIPE2 ? c2_c : nullptr,
+                                                           QW ? qseg + 2 * (size_t)qn_prev : nullptr, QW ? cnt_last : 0);
+        if (QW) cnt_last = cnt;
         WALK_STAT(0, min(64, range.y - base));
         STAMP(1);
         STAMP_BATCH();
@@ -402,9 +440,29 @@ void blend2_fwd_kernel(
         STAMP(4);
     }
     STAMP(8);
+    if (QW) {
+        // how many of the persisted survivors can still pass the backward's `position < final_idx` test of some pixel:
+        // those of the earlier chunks and, of the chunk staged last (its records are still in the list: c.w =
+        // position + 1), the ones at or below the quadrant's largest final_idx.  (If that maximum lies in an earlier
+        // chunk the count keeps a few entries too many: they fail the per-pixel test, nothing else.)
+        int hi_q = last;
+        for (int off = 32; off > 0; off >>= 1) hi_q = max(hi_q, __shfl_xor(hi_q, off, 64));
+        const bool keep = lane < cnt_last && __builtin_bit_cast(int, L.c[GRP + lane].w) <= hi_q;
+        const int n_eff = qn_prev + __builtin_popcountll(__ballot(keep));
+        if (lane == 0) ql.cnt[tile * 4 + wave] = n_eff;
+        if (keep) {   // the last chunk's survivors (the counted ones: a prefix)
+            const float4 pa = L.a[GRP + lane], pb = L.b[GRP + lane];
+            const int ppos = __builtin_bit_cast(int, L.c[GRP + lane].w) - 1;
+            float4 *q = qseg + 2 * ((size_t)qn_prev + lane);
+            q[0] = make_float4(pa.x, pa.y, pa.z, __builtin_bit_cast(float, ppos));
+            q[1] = pb;
+        }
+    }
 #ifndef GG_EPI_SKIP
 #define GG_EPI_SKIP 0   // diagnostic builds only (with GG_STAMPS): 1 no final_T / final_idx stores, 2 no image stores.
-                        // NEVER run a backward after a GG_EPI_SKIP=1 forward: final_idx is uninitialised (it faulted once)
+                        // A backward after a GG_EPI_SKIP=1 forward reads an uninitialised final_idx image: it faulted
+                        // once (r02).  Since r03 the backward kernels hold final_idx to the tile's list range, and
+                        // tools/stamps.py asks the build (gg_debug_epi_skip) and runs no backward on such a forward.
 #endif
     if (GG_EPI_SKIP == 1) { KEEP(T); KEEP(last); }
     if (GG_EPI_SKIP != 1 && inside && write_final) {
@@ -526,7 +584,8 @@ __global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_bwd_narrow_kernel(
     const size_t p = inside ? ((size_t)i * img_w + j) : 0;
 
     const float T_final = inside ? final_T[p] : 1.0f;
-    const int fin = inside ? final_idx[p] : range.x;
+    // final_idx comes from the caller (public C ABI): a stale or garbage value must not index the list
+    const int fin = inside ? min(max(final_idx[p], range.x), range.y) : range.x;
     float T = T_final;
     float vo[CH];
     float W;
@@ -691,10 +750,13 @@ __global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_bwd_narrow_kernel(
 // up to there (the allocation granule; 54 272 B measured 2 per CU, whatever the occupancy API says)
 #define BQ_CAP 92
 
-struct __attribute__((aligned(16))) WaveQueue {
-    float4 a[BQ_CAP];   // x, y, opacity, list position (int bits)
-    float4 b[BQ_CAP];   // conic a, b, c, Gaussian id (int bits; -1 = null record)
+template <int CAP>
+struct __attribute__((aligned(16))) WaveQueueT {
+    float4 a[CAP];   // x, y, opacity, list position (int bits)
+    float4 b[CAP];   // conic a, b, c, Gaussian id (int bits; -1 = null record)
 };
+typedef WaveQueueT<BQ_CAP> WaveQueue;
+#define BQ_CAP_QR 64   // quad-list builds: the queue is one chunk of the persisted survivors (nulls behind the last one)
 
 // second colour array (<= 8 channels) whose backward rides on the walk of a 32-channel chunk (gg_blend_bwd_pair)
 struct Seg2B {
@@ -721,7 +783,11 @@ struct Seg2B {
 // re-reading its records.  k-step s of lane group q = lane >> 4 is channel 8 q + s, so a lane's B operand is still two
 // float4 loads of its Gaussian's colour row.  Needs 16-byte aligned colour rows and cotangent rows (the launcher
 // checks) and the full 32-channel chunk.
-template <bool FULL, int ABL = 0, int CHD = 32, bool DET = false, bool EX = false, bool LEAN = false, bool S16 = false>
+// QR (round 3): the walk streams the quadrant's survivors from the forward's quad list (blend_common.h) instead of
+// staging the tile list again: no list ids, no record gather, no cull, no queue compaction — the queue is 64
+// consecutive records of a contiguous array, the next 64 requested while the current ones are walked.
+template <bool FULL, int ABL = 0, int CHD = 32, bool DET = false, bool EX = false, bool LEAN = false, bool S16 = false,
+          bool QR = false>
 __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_per_eu((LEAN || S16) ? 4 : 3))) void blend2_bwd_wide_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
@@ -729,7 +795,8 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     const float *__restrict__ final_T, const int32_t *__restrict__ final_idx,
     const float *__restrict__ v_out, float *__restrict__ v_xy, float *__restrict__ v_conic,
     float *__restrict__ v_colors, float *__restrict__ v_opacity, int gstride, int cstride,
-    DetSlab det = DetSlab(), Seg2B seg2 = Seg2B()) {
+    DetSlab det = DetSlab(), Seg2B seg2 = Seg2B(), QList ql = QList()) {
+    static_assert(!QR || S16, "quad lists: the 16-slot builds");
     static_assert(!EX || (FULL && CHD == 32 && !DET), "the second array rides on the full 32-channel build");
     static_assert(!LEAN || (!EX && !DET), "LEAN: plain builds only (so far)");
     static_assert(!S16 || (FULL && CHD == 32 && !DET && !LEAN && ABL == 0), "S16: the full 32-channel build");
@@ -762,7 +829,8 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     constexpr bool DEFER = (GG_BWD_DEFER != 0) && !DET && !LEAN && ABL == 0 && !S16;
     __shared__ int s_hid[GG_WPB_WIDE_BWD][DEFER ? 32 : 1];   // DEFER: Gaussian of every slot of the parked batch
     using R = Red6<KB>;
-    __shared__ WaveQueue queues[GG_WPB_WIDE_BWD];
+    typedef WaveQueueT<QR ? BQ_CAP_QR : BQ_CAP> QUEUE;
+    __shared__ QUEUE queues[GG_WPB_WIDE_BWD];
     __shared__ float s_fac[GG_WPB_WIDE_BWD][NSLOT * 65];
     __shared__ int s_slote[GG_WPB_WIDE_BWD][DET ? B2_SLOTS : 1];
     __shared__ __attribute__((aligned(16))) float s_vt[GG_WPB_WIDE_BWD][EX ? 64 * 8 : 4];   // EX: V_OUT2[pixel][8]
@@ -773,7 +841,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     const int lane = threadIdx.x & 63;
     const int wslot = wave & (GG_WPB_WIDE_BWD - 1);   // this wave's LDS
     float *vt = s_vt[wslot];
-    WaveQueue &Q = queues[wslot];
+    QUEUE &Q = queues[wslot];
     float *fac_w = s_fac[wslot];
     int *slote = s_slote[wslot];
     int *hid = s_hid[wslot];
@@ -788,10 +856,15 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
 
     STAMP_DECL;
     const float T_final = inside ? final_T[p] : 1.0f;
-    const int fin = inside ? final_idx[p] : range.x;
+    // final_idx comes from the caller (public C ABI): a stale or garbage value must not index the list
+    const int fin = inside ? min(max(final_idx[p], range.x), range.y) : range.x;
     float T = T_final;
     float W;
     const int wch = lane & 31, half = lane >> 5;
+    // QR: this quadrant's survivors (the forward's count, held to the segment's capacity: the buffer is the caller's)
+    const float4 *qseg = QR ? ql.recs + 2 * ((size_t)4 * range.x + (size_t)wave * (range.y - range.x)) : nullptr;
+    const int n_q = QR ? __builtin_amdgcn_readfirstlane(min(max(ql.cnt[tile * 4 + wave], 0), range.y - range.x)) : 0;
+    int q_next = 0;   // QR, wave-uniform: run_batch(fetch_next) requests the chunk below this survivor index
     const bool wch_ok = FULL || wch < nch;
     // The quadrant's cotangents V_OUT[64 pixels x CH] are needed three ways: <background, v_out> per pixel (lane =
     // pixel), the D product's A operands (pixel-major, half a row per lane) and the flush's B operands (lane =
@@ -821,9 +894,22 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     // records of the NEXT chunk, requested between a batch's walk and its flush: the vector memory counter is
     // in order, so loads issued behind the flush's 24-32 atomic instructions wait for every one of them
     float4 ra_p = make_float4(0.f, 0.f, 0.f, 0.f), rb_p = ra_p;
+    // QR: records of survivors [top_n - 64, top_n) in processing order (lane l = survivor top_n - 1 - l; lanes past the
+    // first survivor read record 0 and are replaced by null records when the chunk enters the queue)
+    auto qload = [&](int top_n) {
+        const int idx = max(top_n - 1 - lane, 0);
+        ra_p = qseg[2 * idx];
+        rb_p = qseg[2 * idx + 1];
+    };
     if (S16) {   // the tile goes through the (16-slot) slab in two halves of 32 pixels
-        hi = wave_hi();
-        g_first = load_id(hi);
+        if (QR) {
+            hi = range.x;
+            g_first = 0;
+            if (n_q > 0) qload(n_q);   // requested beside the cotangent tile
+        } else {
+            hi = wave_hi();
+            g_first = load_id(hi);
+        }
         const int sl = lane & 15, q4 = lane >> 4;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
@@ -928,8 +1014,10 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     }
     // the first chunk's records: requested here (the ids have arrived beside the tile), consumed after the rest of
     // the prologue
-    ra_p = reinterpret_cast<const float4 *>(rec + g_first)[0];
-    rb_p = reinterpret_cast<const float4 *>(rec + g_first)[1];
+    if (!QR) {
+        ra_p = reinterpret_cast<const float4 *>(rec + g_first)[0];
+        rb_p = reinterpret_cast<const float4 *>(rec + g_first)[1];
+    }
     if (EX) {
         float t8[8];
 #pragma unroll
@@ -1257,8 +1345,12 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         }
         STAMP(4);
         if (fetch_next) {
-            ra_p = reinterpret_cast<const float4 *>(rec + g_nxt)[0];
-            rb_p = reinterpret_cast<const float4 *>(rec + g_nxt)[1];
+            if (QR) {
+                qload(q_next);
+            } else {
+                ra_p = reinterpret_cast<const float4 *>(rec + g_nxt)[0];
+                rb_p = reinterpret_cast<const float4 *>(rec + g_nxt)[1];
+            }
         }
         // flush: FAC[32 slots x 64 pixels] * V_OUT[64 x 32 channels]; rows outside slotmask still hold D and
         // are not written
@@ -1393,6 +1485,33 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     bool have_p = true;   // wave-uniform: ra_p / rb_p hold this chunk's records
     // ONE call site of run_batch (the tail batch runs through the same loop): inlined twice, the allocator kept two
     // sets of loop invariants and spilled one
+    if constexpr (QR) {
+        // chunk by chunk down the quad list: 64 records into the queue (processing order = descending list position),
+        // up to four batches of 16, the next chunk requested between the last batch's walk and its flush (QR_PREFETCH)
+        // or right here (then the wave waits for it: one load per 64 survivors, nothing dependent before it)
+        bool have_q = n_q > 0;   // ra_p / rb_p hold the chunk (requested in the prologue / by the previous chunk's last batch)
+        for (int top_n = n_q; top_n > 0; top_n -= 64) {
+            if (!have_q) qload(top_n);
+            // (a record whose Gaussian id is not one — a stale or foreign buffer — becomes a null record: the id
+            //  indexes the colour and gradient rows)
+            const bool real = top_n - 1 - lane >= 0 && (unsigned)__builtin_bit_cast(int, rb_p.w) < (unsigned)ql.npoints;
+            Q.a[lane] = real ? ra_p : make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, 0x7fffffff));
+            Q.b[lane] = real ? rb_p : make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, -1));
+            __builtin_amdgcn_wave_barrier();
+            const int m = min(64, top_n);
+            const bool more = top_n > 64;
+            q_next = top_n - 64;
+            have_q = false;
+            for (int b0 = 0; b0 < m; b0 += 16) {
+                const bool pre = (GG_QR_PREFETCH == 1) && more && (b0 + 16 >= m);
+                run_batch(b0, min(16, m - b0), pre);
+                have_q = have_q || pre;
+            }
+            __builtin_amdgcn_wave_barrier();   // the queue is rewritten by the next chunk
+        }
+        STAMP_END();
+        return;
+    }
     for (int top = hi;; top -= 64) {
       const bool more = top > range.x;   // wave-uniform: another chunk to stage
       if (more) {
@@ -1494,7 +1613,7 @@ void gg_launch_blend2_fwd(int width, int C, int off, int n, int img_h, int img_w
 void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int ntiles, const int32_t *ids,
                                const int2 *bins, const GRec *rec, const float *colors, const float *background,
                                float *out_img, float *final_Ts, int32_t *final_idx, const float *colors2, int C2,
-                               const float *background2, float *out_img2, hipStream_t s) {
+                               const float *background2, float *out_img2, QList ql, hipStream_t s) {
     dim3 grid(gg_blend_grid(ntiles, GG_WPB_OTHER)), block(64 * GG_WPB_OTHER);
     Seg2 seg2;
     seg2.colors = colors2;
@@ -1513,6 +1632,11 @@ void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
         default: break;
     }
 #endif
+    if (ql.recs) {   // the survivors of the quadrant cull are persisted for the backward walk
+        hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, true, 0, true>), grid, block, 0, s, C, 0, 32, img_h, img_w,
+                           tiles_x, ntiles, ids, bins, rec, colors, background, out_img, final_Ts, final_idx, 1, seg2, ql);
+        return;
+    }
     B2_FPAIR(0);
 }
 
@@ -1584,7 +1708,7 @@ void gg_launch_blend2_bwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
                                float *v_conic, float *v_colors, float *v_opacity, int gstride, int cstride,
                                const float *colors2, int C2, const float *background2,
                                const float *const *v_out2_parts, const int *v_out2_channels, int num_parts,
-                               float *v_colors2, int cstride2, hipStream_t s) {
+                               float *v_colors2, int cstride2, QList ql, hipStream_t s) {
     dim3 grid(gg_blend_grid(ntiles, GG_WPB_WIDE_BWD)), block(64 * GG_WPB_WIDE_BWD);
     Seg2B seg2;
     seg2.colors = colors2;
@@ -1607,6 +1731,13 @@ void gg_launch_blend2_bwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
 #endif
     if (GG_BWD_S16 && !ablated && C % 4 == 0 && (reinterpret_cast<uintptr_t>(colors) & 15) == 0 &&
         (reinterpret_cast<uintptr_t>(v_out) & 15) == 0) {   // the 16-slot build (four waves per SIMD)
+        if (ql.recs) {   // ... streaming the forward's quad lists
+            hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, 0, 32, false, true, false, GG_BWD_S16 != 0, GG_BWD_S16 != 0>), grid,
+                               block, 0, s, C, 0, 32, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background,
+                               final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, gstride, cstride, DetSlab(),
+                               seg2, ql);
+            return;
+        }
         hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, 0, 32, false, true, false, GG_BWD_S16 != 0>), grid, block, 0, s, C,
                            0, 32, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, final_Ts, final_idx,
                            v_out, v_xy, v_conic, v_colors, v_opacity, gstride, cstride, DetSlab(), seg2);

@@ -17,6 +17,9 @@ else:
     gg_build.build(force=True, extra_flags=("-DGG_STAMPS",), out=out)
 _lib.LIB_PATH = out
 lib = _lib.load()
+# a -DGG_EPI_SKIP=1 forward stores no final_T / final_idx: no backward may run on its outputs (the build says so)
+lib.gg_debug_epi_skip.restype = ctypes.c_int
+FWD_ONLY = lib.gg_debug_epi_skip() == 1
 dev = "cuda:0"
 h, w, n = 1200, 1600, 1_000_000
 sc = make_scene(n, config_index=3).to(dev)
@@ -52,8 +55,10 @@ for rep in range(2):
     if rep == 1:
         report("32-channel FORWARD (phases: 0 prologue, 1 staging, 4 walk, 7 epilogue; a batch = a chunk of 64 list entries)")
     lib.gg_debug_stamps(None, 1)
-    out_.backward(vo)
-report("32-channel backward")
+    if not FWD_ONLY:
+        out_.backward(vo)
+if not FWD_ONLY:
+    report("32-channel backward")
 tail = torch.rand(n, 7, device=dev).requires_grad_(True)
 vos = [torch.randn(h, w, 32, device=dev), torch.randn(h, w, 7, device=dev)]
 for rep in range(2):
@@ -64,5 +69,7 @@ for rep in range(2):
     if rep == 1:
         report("pair FORWARD (32 + 7)")
     lib.gg_debug_stamps(None, 1)
-    torch.autograd.backward(imgs, vos)
-report("pair backward (32 + 7)")
+    if not FWD_ONLY:
+        torch.autograd.backward(imgs, vos)
+if not FWD_ONLY:
+    report("pair backward (32 + 7)")

@@ -78,6 +78,8 @@ def parse(argv=None):
     ap.add_argument("--feature-dim", type=int, default=None)
     ap.add_argument("--views-per-step", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="skip the short BASELINE-config-5 (render-only) object of the default one-GPU line")
     ap.add_argument("--no-prof", action="store_true", help="skip the profiled step (no per-kernel times)")
     ap.add_argument("--route", default="plugin", choices=("plugin", "shim"),
                     help="headline route: the nerfstudio plugin's fused operator (default) or the shim's "
@@ -85,6 +87,11 @@ def parse(argv=None):
     ap.add_argument("--no-secondary", "--no-fused", dest="no_secondary", action="store_true",
                     help="skip the measurement of the other route")
     ap.add_argument("--no-overlap", action="store_true", help="one all-reduce after the last view")
+    ap.add_argument("--reduce", default="allreduce", choices=("allreduce", "rs_ag"),
+                    help="gradient-to-Gaussian reduction: all-reduce of the gradient bucket (default; the timed step "
+                         "ends with reduced gradients, as the reference's DDP step would) or rs_ag = reduce-scatter, "
+                         "fused Adam on this rank's shard, all-gather of the parameters (dist.ShardedAdamStep; the "
+                         "timed step then INCLUDES the optimizer step)")
     ap.add_argument("--no-view-pipeline", action="store_true",
                     help="the views of a step strictly one after the other on one stream (default: backward of "
                          "view k beside forward of view k + 1 on two streams)")
@@ -162,14 +169,57 @@ def cpu_baseline(args, scene, view):
                       f"oracle/gg_oracle.c with OpenMP, {dt:.1f} s wall"}
 
 
-def cpu_baseline_render(args, scene, view, mlp_state):
-    """Config 5: forward of a BOUNDED sample — a quarter-size crop-equivalent (the same scene rendered
-    at 1/4 of the pixels) would change the lists, so the sample is one full view's projection, SH and
-    binning plus the four forwards at full size if it fits in ~30 s, otherwise reported as skipped."""
-    return {"value": None, "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "skipped: one 5 M-Gaussian 128-channel 1080p forward on the CPU oracle takes "
-                      "minutes (BASELINE.md §2 allows skipping C5 on CPU); config 4's line carries the "
-                      "CPU baseline"}
+def cpu_baseline_render(args, scene, view, fea_up):
+    """Config 5 on the host cores, BOUNDED: one full-size view forward on the CPU oracle is minutes (30.7 M list
+    entries x 135 channels + a 2 M-pixel 128 -> 128 -> 512 MLP), so the sample is
+      (a) projection + SH of ALL Gaussians for the view (full size), and
+      (b) binning, the four rasterize forwards and fea_up on a WINDOW of the same view — the same camera and
+          intrinsics with the principal point shifted so that a (W / 4) x (H / 4) rectangle around the image centre
+          is the whole image: the same Gaussians per pixel as the full view, 1 / 16 of the pixels;
+    value = 1 / (t_a + 16 t_b).  Both on the oracle (oracle/gg_oracle.c, OpenMP on every host core) through the
+    shim's operator sequence, as cpu_baseline() does for config 4."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import oracle_ops
+    from oracle import oracle as O
+    from gaussiangrasper_amd.camera import view_from_c2w
+    from gaussiangrasper_amd.pipeline import activate, render_view
+    O.build()
+    cores = os.cpu_count() or 1
+    O.set_num_threads(cores)
+    torch.set_num_threads(cores)
+    sc = scene.to("cpu")
+    w4, h4 = max(16, view.width // 4 // 16 * 16), max(16, view.height // 4 // 16 * 16)
+    x0, y0 = (view.width - w4) // 2, (view.height - h4) // 2
+    c2w = torch.eye(4)
+    wv = view.viewmat.detach().cpu()
+    c2w[:3, :3] = wv[:3, :3].T @ torch.diag(torch.tensor([1.0, -1.0, -1.0]))
+    c2w[:3, 3] = view.cam_pos.detach().cpu()
+    window = view_from_c2w(c2w, view.fx, view.fy, view.cx - x0, view.cy - y0, h4, w4)
+    full = view_from_c2w(c2w, view.fx, view.fy, view.cx, view.cy, view.height, view.width)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        act = activate(sc, full, oracle_ops.quat_to_rotmat)
+        oracle_ops.ProjectGaussians.apply(act["means"], act["scales"], 1, act["quats"], full.viewmat[:3, :],
+                                          full.projmat, full.fx, full.fy, full.cx, full.cy, full.height, full.width,
+                                          full.tile_bounds)
+        oracle_ops.SphericalHarmonics.apply(4, act["viewdirs"], act["sh"])
+        t_a = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        out = render_view(sc, window, oracle_ops)
+        feat = out["feature"].reshape(-1, out["feature"].shape[-1]).numpy()
+        l0, l2 = fea_up.layers[0], fea_up.layers[2]
+        O.mlp_fwd(feat, l0.weight.detach().cpu().numpy(), l0.bias.detach().cpu().numpy(),
+                  l2.weight.detach().cpu().numpy(), l2.bias.detach().cpu().numpy())
+        t_b = time.perf_counter() - t0
+        # (the window's own projection + SH are inside t_b as well: counted once too often, 1 / 16 of t_a)
+    scale = (view.width * view.height) / float(w4 * h4)
+    est = t_a + scale * t_b
+    return {"value": 1.0 / est, "unit": "views/s", "cores": O.num_threads(), "kind": "port",
+            "sample": f"bounded: projection + SH of all {args.points} Gaussians at full size ({t_a:.1f} s) + binning, "
+                      f"four rasterize forwards (rgb, {args.feature_dim}-ch feature, depth, normal) and fea_up on a "
+                      f"{w4}x{h4} window of the {view.width}x{view.height} view ({t_b:.1f} s, x{scale:.1f} pixels); "
+                      f"extrapolated view time {est:.1f} s; oracle/gg_oracle.c with OpenMP"}
 
 
 def read_kernel_times(lib):
@@ -304,11 +354,21 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
     if selftest:
         scene_cpu.scales.add_(1.6)      # tiny test images: splats large enough to cover pixels
     scene = scene_cpu.to(dev)
-    for p in scene.params():
-        p.requires_grad_(True)
     total_views = args.views_per_step * world
     views = ring_cameras(total_views, args.height, args.width, device=dev)
     my_views = shard_views(total_views, rank, world)
+    # The plugin route runs the CLASS train.sh loads: plugin.make_fused_model_class(...).get_outputs(camera) — camera
+    # preparation from a `Cameras` object on the device (one host read-back of its scalars), operator sequence,
+    # output dictionary — on gaussiangrasper_amd.stub's stand-ins for the two nerfstudio classes it touches
+    # (nerfstudio is not installable here).  Its six Parameters are the scene's leaves: one bucket for both routes.
+    from gaussiangrasper_amd.plugin import make_fused_model_class
+    from gaussiangrasper_amd.stub import StubCameras, StubGaussianSplattingModel
+    plugin_model = make_fused_model_class(StubGaussianSplattingModel, ops=ops)(scene)
+    for k in ("means", "scales", "quats", "opacities", "colors_all", "feature"):
+        setattr(scene, k, getattr(plugin_model, k))
+    plugin_model.train()
+    # cameras as FullImageDatamanager.next_train hands them out: on the device, stamped with their dataset index
+    cameras = {v: StubCameras.from_view(views[v], device=dev, cam_idx=v) for v in my_views}
     bucket = GradBucket(scene.params())
     if args.deterministic:
         ops.set_deterministic_backward(True)
@@ -328,23 +388,38 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
         ops.clear_bin_cache()
 
     def make_step(fused: bool):
+        if fused:
+            render = lambda v: plugin_model(cameras[v])
+        else:
+            render = lambda v: render_view(scene, views[v], ops, fused=False)
+
         def render_and_backward(v):
-            out = render_view(scene, views[v], ops, fused=fused)
-            backward_view(out, cot)
-        render_and_backward.render = lambda v: render_view(scene, views[v], ops, fused=fused)
+            backward_view(render(v), cot)
+        render_and_backward.render = render
         render_and_backward.backward = lambda out: backward_view(out, cot)
         return render_and_backward
 
     overlap = not args.no_overlap
+    stepper = None
+    if args.reduce == "rs_ag":
+        from gaussiangrasper_amd.dist import ShardedAdamStep, torch_adam_piece
+        # the reference's per-group Adam hyper-parameters (method_configs.py:618-660), in scene.params() order
+        lrs = (1.6e-4, 0.005, 0.001, 0.05, 5e-4, 5e-4)     # means, scales, quats, opacities, colors_all, feature
+        stepper = ShardedAdamStep(bucket, [dict(lr=lr, eps=1e-15) for lr in lrs],
+                                  adam_piece=torch_adam_piece if selftest else None)
     pipe_streams_box = [None]
     if torch.device(dev).type == "cuda" and not args.no_view_pipeline and not args.deterministic:
         pipe_streams_box[0] = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
 
     def one_step(fn):
+        red = stepper is None
         if pipe_streams_box[0] is not None:
-            train_step_pipelined(fn.render, fn.backward, bucket, my_views, pipe_streams_box[0], overlap=overlap)
+            train_step_pipelined(fn.render, fn.backward, bucket, my_views, pipe_streams_box[0], reduce=red,
+                                 overlap=overlap)
         else:
-            train_step(fn, bucket, my_views, overlap=overlap)
+            train_step(fn, bucket, my_views, reduce=red, overlap=overlap)
+        if stepper is not None:
+            stepper.step()
 
     def timed(fn, steps):
         barrier()
@@ -403,7 +478,10 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
                                "%d-ch feature + depth + normal images per view (%s), "
                                "fwd+bwd, %d views/step/GPU, gradient all-reduce each step"
                                % (args.points, args.width, args.height, args.feature_dim,
-                                  "nerfstudio plugin route: one fused rasterize operator per view"
+                                  "nerfstudio plugin route: the timed callable is FusedGaussianSplattingModel."
+                                  "get_outputs(camera) of gaussiangrasper_amd.plugin (the class train.sh loads, on "
+                                  "stub.py's stand-ins for nerfstudio's base model and Cameras) — one fused rasterize "
+                                  "operator per view"
                                   if plugin_first else "shim route: the reference's 4 rasterize calls per view",
                                   args.views_per_step),
                    "route": args.route, "deterministic_backward": bool(args.deterministic),
@@ -417,8 +495,10 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
                    "grad_accumulation": "SH and feature gradients added into the step's gradient bucket by "
                                         "the backward kernels; the other parameters by autograd"
                                         if direct else "autograd",
-                   "grad_allreduce": "per parameter, overlapped with the last view's backward"
-                                     if overlap else "one collective after the last view",
+                   "grad_allreduce": ("reduce-scatter + fused Adam on the shard + all-gather of the parameters "
+                                      "(the step includes the optimizer)") if stepper is not None else
+                                     ("per parameter, overlapped with the last view's backward"
+                                      if overlap else "one collective after the last view"),
                    "backend": args.backend if world > 1 else None},
     }
     if rank == 0:
@@ -437,6 +517,26 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
                     total_views, args.height, args.width)[0])
             except Exception as exc:  # noqa: BLE001
                 result["cpu_baseline"] = {"error": repr(exc)}
+    # BASELINE config 5 (render.sh's body at 5 M Gaussians, 128-dim feature, 1080p) rides along on the default
+    # one-GPU run as a short object, so that the driver's line carries it: 2 steps of 2 views, its own kernel times
+    # and its own bounded CPU sample.  `--config 5` is the full-length form.
+    if world == 1 and not selftest and args.device == "cuda" and not args.no_config5:
+        del plugin_model, bucket, scene, cot, cameras
+        ops.clear_bin_cache()
+        ops.clear_grad_sinks()
+        torch.cuda.empty_cache()
+        a5 = argparse.Namespace(**vars(args))
+        a5.config, a5.points, a5.height, a5.width, a5.feature_dim = 5, 5_000_000, 1080, 1920, 128
+        a5.views_per_step, a5.steps, a5.warmup = 2, 2, 1
+        try:
+            r5 = render_only_result(a5, rank, world, dev, ops, lib, barrier, max_over_ranks)
+            result["config5"] = {k: r5[k] for k in ("metric", "value", "unit", "ms_per_view", "steps", "kernels",
+                                                    "kernel_time_fraction_of_wall", "cpu_baseline") if k in r5}
+            result["config5"]["workload"] = r5["config"]["workload"]
+            result["config5"]["num_intersects"] = r5["config"]["num_intersects"]
+        except Exception as exc:  # noqa: BLE001
+            result["config5"] = {"error": repr(exc)}
+    if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
@@ -444,12 +544,12 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
     return 0
 
 
-def run_render_only(args, rank, world, dev, ops, lib, barrier, max_over_ranks) -> int:
+def render_only_result(args, rank, world, dev, ops, lib, barrier, max_over_ranks, with_cpu_baseline=True):
     """BASELINE config 5: the body of render.sh's loop (base_pipeline.py:401-408) per view —
     model(camera) in eval mode = project, SH, four rasterize forwards, then fea_up on every pixel of
-    the feature image — on this rank's views; no gradient, no collective."""
+    the feature image — on this rank's views; no gradient, no collective.  Returns the result object
+    (rank 0; None on the other ranks)."""
     import torch
-    import torch.distributed as dist
     from gaussiangrasper_amd.camera import ring_cameras
     from gaussiangrasper_amd.dist import shard_views
     from gaussiangrasper_amd.mlp import MLP
@@ -519,12 +619,26 @@ def run_render_only(args, rank, world, dev, ops, lib, barrier, max_over_ranks) -
                    "n_visible": n_vis, "num_intersects": n_isect,
                    "parallelism": f"view-parallel x{world}, replicated Gaussians, no collective"},
     }
+    if rank != 0:
+        return None
+    result["ms_per_view"] = ms_per_view
+    result["roofline"] = build_roofline(args, kernels, n_vis, n_isect, ms_per_view) if kernels else None
+    result["kernels"] = {k: round(v["avg_ms"], 4) for k, v in sorted(kernels.items())}
+    if kernels:
+        result["kernel_time_fraction_of_wall"] = sum(v["total_ms"] for v in kernels.values()) / (1e3 * t_prof)
+    result["cpu_baseline"] = None
+    if world == 1 and with_cpu_baseline and not args.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline_render(args, scene, views[my_views[0]], fea_up)
+        except Exception as exc:                                 # the GPU numbers stand on their own
+            result["cpu_baseline"] = {"value": None, "kind": "port", "sample": f"failed: {exc!r}"}
+    return result
+
+
+def run_render_only(args, rank, world, dev, ops, lib, barrier, max_over_ranks) -> int:
+    import torch.distributed as dist
+    result = render_only_result(args, rank, world, dev, ops, lib, barrier, max_over_ranks)
     if rank == 0:
-        result["roofline"] = build_roofline(args, kernels, n_vis, n_isect, ms_per_view) if kernels else None
-        result["kernels"] = {k: round(v["avg_ms"], 4) for k, v in sorted(kernels.items())}
-        if kernels:
-            result["kernel_time_fraction_of_wall"] = sum(v["total_ms"] for v in kernels.values()) / (1e3 * t_prof)
-        result["cpu_baseline"] = cpu_baseline_render(args, None, None, None) if world == 1 else None
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

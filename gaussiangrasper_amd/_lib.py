@@ -57,6 +57,7 @@ SIGNATURES = {
     "gg_count_intersects": (_I, [_I, _P, _P, _P, _SZ, _P]),
     "gg_bin_sort_workspace": (_SZ, [_I, _I64]),
     "gg_bin_sort": (_I, [_I, _I64, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
+    "gg_bin_sort_status": (_I, [_I, _I64, _P, _SZ, _P]),
     "gg_bin_sort_dev": (_I, [_I, _I64, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
     "gg_blend_workspace": (_SZ, [_I]),
     "gg_blend_fwd": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
@@ -87,7 +88,7 @@ SIGNATURES = {
     "gg_densify_rows": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P, _F, _P, _P, _P, _I,
                              C.POINTER(RowArray), _P]),
     "gg_densify_stats": (_I, [_I, _P, _P, _I, _I, _P, _P, _P, _P]),
-    "gg_densify_masks": (_I, [_I, _P, _P, _P, _P, _I, _F, _F, _F, _I, _P, _P, _P]),
+    "gg_densify_masks": (_I, [_I, _P, _P, _P, _P, _I, _F, _F, _F, _I, _F, _P, _P, _P]),
     "gg_cull_mask": (_I, [_I, _P, _P, _P, _F, _F, _F, _I, _I, _P, _P]),
     "gg_adam_step": (_I, [_I, C.POINTER(AdamGroup), _I, _P]),
     "gg_prof_enable": (_I, [_I]),

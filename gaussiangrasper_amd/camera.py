@@ -5,6 +5,8 @@
 from __future__ import annotations
 
 import math
+
+import numpy as np
 from dataclasses import dataclass
 
 import torch
@@ -57,8 +59,11 @@ def view_from_c2w(c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float,
     viewmat = torch.eye(4, dtype=torch.float32)
     viewmat[:3, :3] = R_inv
     viewmat[:3, 3:4] = T_inv
-    fovx = 2 * math.atan(width / (2 * fx))
-    fovy = 2 * math.atan(height / (2 * fy))
+    # :672-673 `2 * math.atan(camera.width / (2 * camera.fx))`: the quotient is formed from tensors (int64 by
+    # float32 -> float32), the arc tangent in double
+    f32 = np.float32
+    fovx = 2 * math.atan(float(f32(width) / (f32(2.0) * f32(fx))))
+    fovy = 2 * math.atan(float(f32(height) / (f32(2.0) * f32(fy))))
     projmat = projection_matrix(0.001, 1000, fovx, fovy)
     return ViewParams(viewmat.to(device), (projmat @ viewmat).to(device), float(fx), float(fy),
                       float(cx), float(cy), int(height), int(width), c2w[:3, 3].clone().to(device))

@@ -354,10 +354,13 @@ __global__ __launch_bounds__(256) void tile_bins_kernel(int64_t I, const int64_t
                                                         const uint32_t *__restrict__ tkeys_sorted,
                                                         uint32_t num_tiles,
                                                         int32_t *__restrict__ tile_bins,
-                                                        int32_t *__restrict__ tile_out) {
+                                                        int32_t *__restrict__ tile_out, const ScanState *st) {
     I = dev_count(I, I_dev);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= I) return;
+    // a look-back of the offsets scan gave up (never expected): the lists are not to be trusted, and Gaussian ids
+    // from them would index the records — every tile keeps its empty range (gg_bin_sort_status reports it)
+    if (scan_failed(st)) return;
     uint32_t cur = tkeys_sorted[i];
     if (tile_out) tile_out[i] = (int32_t)cur;
     // tile ids >= num_tiles can only appear if the caller's I exceeds sum(num_tiles_hit) (entries
@@ -502,9 +505,28 @@ static int bin_sort_impl(int N, int64_t I, const int64_t *I_dev, const float *xy
     }
     // 5. tile ranges
     hipLaunchKernelGGL(tile_bins_kernel, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, s, I, I_dev, kcur,
-                       (uint32_t)T, tile_bins, isect_tile_sorted);
+                       (uint32_t)T, tile_bins, isect_tile_sorted, (const ScanState *)w.block_sums);
     gg_prof_end(GG_K_BIN_SORT, s);
     GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+// synchronous: waits for the stream, then reads the offsets scan's status word out of the workspace the sort ran in
+extern "C" int gg_bin_sort_status(int N, int64_t I, const void *ws, size_t ws_bytes, gg_stream_t stream) {
+    GG_REQUIRE(N >= 0 && I >= 0, "negative size");
+    if (N == 0 || I == 0) return GG_OK;
+    BinWs w = bin_ws_layout(const_cast<void *>(ws), N, I);
+    GG_REQUIRE(ws != nullptr && ws_bytes >= w.bytes, "workspace too small");
+    ScanState st;
+    if (hipMemcpyAsync(&st, w.block_sums, sizeof(ScanState), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+        gg_set_error("gg_bin_sort_status: read-back failed");
+        return GG_ERR_LAUNCH;
+    }
+    if (st.error != 0u) {
+        gg_set_error("gg_bin_sort: the offsets scan's look-back timed out; the tile lists of this view were left empty");
+        return GG_ERR_LAUNCH;
+    }
     return GG_OK;
 }
 

@@ -224,7 +224,8 @@ __global__ __launch_bounds__(DN_THREADS) void densify_rows_kernel(
                     dst[row * w + c] = out;
                 }
             }
-            if (dr >= 0) dst[(dup_base + dr) * w + c] = (kind == GG_ROWS_ZERO_NEW) ? 0.0f : v;
+            // (dup_gaussians copies self.scales AFTER split_gaussians shrank the split rows in place: :524-526, :541)
+            if (dr >= 0) dst[(dup_base + dr) * w + c] = (kind == GG_ROWS_ZERO_NEW) ? 0.0f : old_v;
         }
     }
 }
@@ -314,16 +315,24 @@ __device__ __forceinline__ float max_exp3(const float *s) {
 __global__ __launch_bounds__(256) void densify_masks_kernel(
     int N, const float *__restrict__ grad_norm, const float *__restrict__ vis_counts,
     const float *__restrict__ max_2dsize, const float *__restrict__ scales, float max_dim,
-    float grad_thresh, float size_thresh, float split_screen_size, int use_screen,
+    float grad_thresh, float size_thresh, float split_screen_size, int use_screen, float size_fac,
     uint8_t *__restrict__ split_mask, uint8_t *__restrict__ dup_mask) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const float avg = ((grad_norm[i] / vis_counts[i]) * 0.5f) * max_dim;
     const bool high = avg > grad_thresh;                               // :416-417
-    const float smax = max_exp3(scales + 3 * (size_t)i);
+    const float *sc = scales + 3 * (size_t)i;
+    float smax = max_exp3(sc);
     bool split = smax > size_thresh;                                   // :418
     if (use_screen) split = split || (max_2dsize[i] > split_screen_size);   // :419-420
     split = split && high;                                             // :421
+    // split_gaussians has shrunk the scales of the split Gaussians IN PLACE by now (:524-526, called at :423-429),
+    // so the duplicate test (:430) sees log(exp(s) / 1.6) for them: a high-gradient Gaussian with
+    // thresh < max scale <= 1.6 thresh, or a small one split for its screen size, is split AND duplicated
+    if (split) {
+        const float sh[3] = {logf(expf(sc[0]) / size_fac), logf(expf(sc[1]) / size_fac), logf(expf(sc[2]) / size_fac)};
+        smax = max_exp3(sh);
+    }
     const bool dup = (smax <= size_thresh) && high;                    // :430-431
     split_mask[i] = split ? 1 : 0;
     dup_mask[i] = dup ? 1 : 0;
@@ -332,16 +341,17 @@ __global__ __launch_bounds__(256) void densify_masks_kernel(
 extern "C" int gg_densify_masks(int num_points, const float *grad_norm_accum, const float *vis_counts,
                                 const float *max_2dsize, const float *scales, int max_image_dim,
                                 float densify_grad_thresh, float densify_size_thresh,
-                                float split_screen_size, int use_screen_size, uint8_t *split_mask,
+                                float split_screen_size, int use_screen_size, float size_fac, uint8_t *split_mask,
                                 uint8_t *dup_mask, gg_stream_t stream) {
     GG_REQUIRE(num_points >= 0 && max_image_dim > 0, "bad size");
+    GG_REQUIRE(size_fac > 0.0f, "size_fac must be positive");
     if (num_points == 0) return GG_OK;
     GG_REQUIRE(grad_norm_accum && vis_counts && scales && split_mask && dup_mask, "null pointer");
     GG_REQUIRE(!use_screen_size || max_2dsize, "max_2dsize missing");
     hipLaunchKernelGGL(densify_masks_kernel, dim3((num_points + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, num_points, grad_norm_accum, vis_counts, max_2dsize, scales,
                        (float)max_image_dim, densify_grad_thresh, densify_size_thresh, split_screen_size,
-                       use_screen_size, split_mask, dup_mask);
+                       use_screen_size, size_fac, split_mask, dup_mask);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }

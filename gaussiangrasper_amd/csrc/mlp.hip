@@ -194,13 +194,148 @@ __global__ __launch_bounds__(256 * 2 / TPW) void mlp_fwd_kernel(long P, int out_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// in_dim = 128 (BASELINE config 5: a 128-dim feature image through fea_up = MLP(128, 512, [128]),
+// gaussian_splatting.py:258 with feature_dim = 128).  W1 (128 x 128) no longer fits the registers (256 VGPRs per
+// lane) and W1 + a 128 KB slice of W2 no longer fit the LDS, so the loop nest is turned inside out: W1 stays in
+// LDS as the A operand of layer 1 (64 KB, the layout layer 2 uses for W2: one conflict-free ds_read_b32 per MFMA),
+// x is the register-resident B operand (64 VGPRs), the hidden activations of a wave's 32-pixel tile stay in
+// registers (64) while the FOUR 64 KB slices of W2 pass through the other half of the LDS — re-staged from L2 per
+// 256-pixel block (256 KB per block: 0.5 GB per 1080p view against 34 TB/s of L2, but two workgroup barriers per
+// slice) instead of recomputing layer 1 per slice (which would cost +60 % MFMAs here).  Same contraction orders as
+// the narrow kernel — inputs 0, 1, 2, ... for layer 1, mlp_hidden_of() for layer 2 — so the oracle's mlp_fwd is
+// matched bit for bit as well.
+// ---------------------------------------------------------------------------------------------
+#define MLPW_IN 128
+#define MLPW_NB 4                               // 32-row output blocks per W2 slice (4 x 64 x 64 x 4 B = 64 KB)
+__global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(long P, int out_dim, const float *__restrict__ x,
+                                                           const float *__restrict__ w1, const float *__restrict__ b1,
+                                                           const float *__restrict__ w2, const float *__restrict__ b2,
+                                                           float *__restrict__ y) {
+    constexpr int IN = MLPW_IN, THREADS = 512, STEPS1 = IN / 2;
+    extern __shared__ float lds[];
+    float *w1s = lds;                                         // [blk 4][step 64][lane 64]
+    float *w2s = w1s + 4 * STEPS1 * 64;                       // [nb 4][step 64][lane 64]
+    float *b1s = w2s + MLPW_NB * MLP_STEPS * 64;              // [128]
+    float *b2s = b1s + MLP_HID;                               // [out_dim]
+    const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // w1s[blk][s][lane] = W1[32 blk + lane % 32][2 s + lane / 32]: a thread takes four consecutive inputs of one W1
+    // row (one 16-byte load) = k-steps s, s + 1 for both lane halves
+    for (int i = threadIdx.x; i < MLP_HID * (IN / 4); i += THREADS) {
+        const int row = i % MLP_HID, q = i / MLP_HID;         // lanes of a wave: consecutive rows
+        const float4 v = *reinterpret_cast<const float4 *>(w1 + (size_t)row * IN + 4 * q);
+        float *dst = w1s + ((size_t)(row >> 5) * STEPS1 + 2 * q) * 64 + (row & 31);
+        dst[0] = v.x;         // input 4 q     : step 2 q,     half 0
+        dst[32] = v.y;        // input 4 q + 1 : step 2 q,     half 1
+        dst[64] = v.z;        // input 4 q + 2 : step 2 q + 1, half 0
+        dst[96] = v.w;        // input 4 q + 3 : step 2 q + 1, half 1
+    }
+    for (int i = threadIdx.x; i < MLP_HID; i += THREADS) b1s[i] = b1[i];
+    for (int i = threadIdx.x; i < out_dim; i += THREADS) b2s[i] = b2[i];
+    __syncthreads();
+
+    const long nblocks = (P + 255) / 256;
+    const int nb_total = out_dim / 32;
+    for (long blkid = blockIdx.x; blkid < nblocks; blkid += gridDim.x) {   // (every wave runs every barrier)
+        const long pix = blkid * 256 + wave * 32 + col;
+        const bool ok = pix < P;
+        // ---------------- layer 1: H^T[hid][pixel] = W1 · X^T + b1, ReLU ------------------------
+        f32x16 h[4];
+        {
+            float xr[STEPS1];   // X^T as B operand: x[pixel][2 s + half]
+            const float4 *xp = reinterpret_cast<const float4 *>(x + (size_t)(ok ? pix : 0) * IN);
+#pragma unroll
+            for (int j = 0; j < IN / 4; ++j) {
+                const float4 v = ok ? xp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                xr[2 * j] = half ? v.y : v.x;
+                xr[2 * j + 1] = half ? v.w : v.z;
+            }
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                f32x16 acc;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(b1s + 32 * blk + 8 * j + 4 * half);
+                    acc[4 * j] = bv.x;
+                    acc[4 * j + 1] = bv.y;
+                    acc[4 * j + 2] = bv.z;
+                    acc[4 * j + 3] = bv.w;
+                }
+                const float *arow = w1s + (size_t)blk * STEPS1 * 64 + lane;
+#pragma unroll
+                for (int s = 0; s < STEPS1; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[s * 64], xr[s], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.0f);
+                h[blk] = acc;
+            }
+        }
+        // ---------------- layer 2, slice by slice ------------------------------------------------
+        for (int nb0 = 0; nb0 < nb_total; nb0 += MLPW_NB) {
+            const int nbs = min(MLPW_NB, nb_total - nb0);
+            __syncthreads();   // the previous slice is fully consumed
+            for (int i = threadIdx.x; i < nbs * 32 * (MLP_HID / 4); i += THREADS) {
+                const int row = i % (nbs * 32), q = i / (nbs * 32);
+                const float4 v = *reinterpret_cast<const float4 *>(w2 + (size_t)(32 * nb0 + row) * MLP_HID + 4 * q);
+                const int blk = q >> 3, w8 = q & 7;
+                const int hf = w8 & 1, rhi = w8 >> 1;
+                const int step = 16 * blk + 4 * rhi;
+                float *dst = w2s + ((size_t)(row >> 5) * MLP_STEPS + step) * 64 + (row & 31) + 32 * hf;
+                dst[0] = v.x;
+                dst[64] = v.y;
+                dst[128] = v.z;
+                dst[192] = v.w;
+            }
+            __syncthreads();
+            for (int nb = 0; nb < nbs; nb += 2) {   // two output blocks at a time: two independent accumulator chains
+                f32x16 acc[2];
+                const float *arow[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int nbu = min(nb + u, nbs - 1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 bv = *reinterpret_cast<const float4 *>(b2s + 32 * (nb0 + nbu) + 8 * j + 4 * half);
+                        acc[u][4 * j] = bv.x;
+                        acc[u][4 * j + 1] = bv.y;
+                        acc[u][4 * j + 2] = bv.z;
+                        acc[u][4 * j + 3] = bv.w;
+                    }
+                    arow[u] = w2s + (size_t)nbu * MLP_STEPS * 64 + lane;
+                }
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[u][(16 * blk + r) * 64], h[blk][r], acc[u], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (nb + u >= nbs) break;
+                    if (ok) {
+                        float *yp = y + (size_t)pix * out_dim + 32 * (nb0 + nb + u) + 4 * half;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            *reinterpret_cast<float4 *>(yp + 8 * j) =
+                                make_float4(acc[u][4 * j], acc[u][4 * j + 1], acc[u][4 * j + 2], acc[u][4 * j + 3]);
+                    }
+                }
+            }
+        }
+    }
+}
+
 extern "C" int gg_mlp_fwd(int64_t num_rows, int in_dim, int hidden_dim, int out_dim, const float *x,
                           const float *w1, const float *b1, const float *w2, const float *b2, float *y,
                           gg_stream_t stream) {
     GG_REQUIRE(num_rows >= 0, "num_rows < 0");
     GG_REQUIRE(hidden_dim == MLP_HID, "hidden_dim must be 128 (the reference's fea_up)");
-    GG_REQUIRE(in_dim == 8 || in_dim == 16 || in_dim == 32 || in_dim == 64,
-               "in_dim must be 8, 16, 32 or 64");
+    GG_REQUIRE(in_dim == 8 || in_dim == 16 || in_dim == 32 || in_dim == 64 || in_dim == 128,
+               "in_dim must be 8, 16, 32, 64 or 128");
+    GG_REQUIRE(in_dim != 128 || out_dim <= 4096, "in_dim 128: out_dim <= 4096 (the output biases live in LDS)");
     GG_REQUIRE(out_dim > 0 && out_dim % 32 == 0, "out_dim must be a positive multiple of 32");
     if (num_rows == 0) return GG_OK;
     GG_REQUIRE(x && w1 && b1 && w2 && b2 && y, "null pointer");
@@ -215,6 +350,23 @@ extern "C" int gg_mlp_fwd(int64_t num_rows, int in_dim, int hidden_dim, int out_
     const long nblocks = (num_rows + 255) / 256;
     const int grid = (int)(nblocks < cus ? nblocks : cus);
     hipError_t e = hipSuccess;
+    if (in_dim == MLPW_IN) {
+        const size_t wide_lds = sizeof(float) * ((size_t)4 * (MLPW_IN / 2) * 64 + (size_t)MLPW_NB * MLP_STEPS * 64 +
+                                                 MLP_HID + (size_t)out_dim);
+        gg_prof_begin(GG_K_MLP_FWD, s);
+        e = hipFuncSetAttribute((const void *)mlp_fwd_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)wide_lds);
+        if (e == hipSuccess)
+            hipLaunchKernelGGL(mlp_fwd_wide_kernel, dim3(grid), dim3(512), wide_lds, s, (long)num_rows, out_dim, x, w1,
+                               b1, w2, b2, y);
+        gg_prof_end(GG_K_MLP_FWD, s);
+        if (e != hipSuccess) {
+            gg_set_error("gg_mlp_fwd: cannot reserve %zu bytes of LDS: %s", wide_lds, hipGetErrorString(e));
+            return GG_ERR_LAUNCH;
+        }
+        GG_CHECK_LAUNCH();
+        return GG_OK;
+    }
 #define MLP_LAUNCH(IN_)                                                                                   \
     do {                                                                                                  \
         e = hipFuncSetAttribute((const void *)mlp_fwd_kernel<IN_, MLP_TPW>,                               \

@@ -11,7 +11,11 @@
 // (`sc1` loads, served by L2 / the fabric, never by the CU's L1) — no separate flag, so no fence.
 // Forward progress: a workgroup takes its logical index from an atomic ticket, so every predecessor it
 // waits on has already started running; spins are bounded and a stuck wait sets a status word
-// instead of hanging the GPU.  The state block must be zeroed (hipMemsetAsync) before every launch.
+// instead of hanging the GPU.  That word is not left for nobody to read: the last workgroup publishes an IMPOSSIBLE
+// grand total (all ones) when it is set — the callers that read the total back (gg_mask_scan, gg_compact_rows)
+// turn it into an error code on the host — and consumers on the device ask scan_failed() and write nothing
+// (binning.hip: no list entry is emitted and no tile range is set, so every tile renders its background;
+// gg_bin_sort_status reports it).  The state block must be zeroed (hipMemsetAsync) before every launch.
 #pragma once
 #include "gg_common.h"
 
@@ -99,8 +103,18 @@ __device__ __forceinline__ unsigned int scan_lookback(ScanState *st, int bid, in
     }
     __syncthreads();
     const unsigned int excl = *s_excl;
-    if (bid == nblocks - 1 && threadIdx.x == 0) st->total = (unsigned long long)excl + block_total;
+    if (bid == nblocks - 1 && threadIdx.x == 0) {
+        // (the failing workgroup raised the word before it published its prefix, and both went to L2 in that order)
+        const unsigned int err = __hip_atomic_load(&st->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st->total = err ? ~0ull : (unsigned long long)excl + block_total;
+    }
     return excl;
+}
+
+#define GG_SCAN_FAILED_TOTAL (~0ull)
+// for kernels launched behind the scan on the same stream
+__device__ __forceinline__ bool scan_failed(const ScanState *st) {
+    return __hip_atomic_load(&st->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
 }
 
 // exclusive scan of one value per thread inside a 256-thread workgroup; total -> every thread

@@ -100,6 +100,8 @@ def compact(arrays: Sequence[Tensor], deleted_mask: Tensor) -> List[Tensor]:
         _lib.check(lib.gg_compact_rows(n, _ptr(m), len(chunk), desc, _ptr(kept), _ptr(ws), ws.numel(),
                                        _stream(dev)), "gg_compact_rows")
     k = int(kept.item())
+    if not 0 <= k <= n:         # impossible total: a look-back of the scan gave up (csrc/scan.h)
+        raise _lib.GGError("gg_compact_rows: the prefix scan's look-back timed out; the compacted rows are not valid")
     return [o[:k] for o in outs]
 
 
@@ -205,7 +207,7 @@ class Refiner:
         _lib.check(_lib.load().gg_densify_masks(
             n, _ptr(self.xys_grad_norm), _ptr(self.vis_counts), _ptr(self.max_2Dsize), _ptr(sc),
             int(max(self.last_size)), c.densify_grad_thresh, c.densify_size_thresh, c.split_screen_size,
-            use_screen, _ptr(split), _ptr(dup), _stream(dev)), "gg_densify_masks")
+            use_screen, SIZE_FAC, _ptr(split), _ptr(dup), _stream(dev)), "gg_densify_masks")
         return split, dup
 
     def cull_mask(self) -> Tensor:

@@ -129,10 +129,16 @@ class GradBucket:
             self._work.append(dist.all_reduce(self.slices[i], op=dist.ReduceOp.SUM, async_op=True))
             self._next += 1
 
-    def _flush_deferred(self) -> None:
+    def flush(self) -> None:
+        """Make every gradient the operators still hold in factored form (the SH gradient of the step's views,
+        `enable_direct(defer_sh=True)`) part of the bucket.  finish() / all_reduce() do it themselves; a caller
+        that steps its optimizer WITHOUT a reduction (train_step(reduce=False), one process) must call it before
+        reading `.grad` — otherwise those contributions are silently missing and zero_() discards them."""
         ops = getattr(self, "_direct_ops", None)
         if ops is not None and hasattr(ops, "flush_grad_sinks"):
             ops.flush_grad_sinks()
+
+    _flush_deferred = flush
 
     def zero_(self) -> None:
         ops = getattr(self, "_direct_ops", None)
@@ -192,6 +198,116 @@ class GradBucket:
         return torch.cat([sl.reshape(-1) for sl in self.slices])
 
 
+# ------------------------------------------------------------------------------------------------
+# reduce-scatter + Adam on a shard + all-gather (the second reduction scheme; `bench.py --reduce rs_ag`)
+# ------------------------------------------------------------------------------------------------
+def torch_adam_piece(p, g, m, v, lr, betas, eps, weight_decay, step) -> None:
+    """torch.optim.Adam's update (amsgrad off) on one flat piece, with torch ops: the CPU / gloo tests' stand-in
+    for gg_adam_step (same expressions as torch/optim/adam.py _single_tensor_adam)."""
+    b1, b2 = betas
+    if weight_decay != 0:
+        g = g.add(p, alpha=weight_decay)
+    m.lerp_(g, 1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    denom = (v.sqrt() / (bc2 ** 0.5)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+class ShardedAdamStep:
+    """Optimizer step of the replicated Gaussians with the work and the traffic of ONE replica spread over the ranks:
+
+        reduce-scatter   rank r receives the sum over ranks of elements [r S, (r + 1) S) of the gradient bucket
+        Adam             on that shard only: parameters, gradients and BOTH moments of 1 / world of the elements
+                         (the moments of the other shards do not exist on this rank: 2 x 472 MB -> 2 x 59 MB at 8)
+        all-gather       every rank receives every shard of the updated parameters
+
+    instead of all-reduce + a full Adam step on every rank.  The bytes on xGMI are the same (a ring all-reduce IS a
+    reduce-scatter followed by an all-gather); what is saved is 7 / 8 of the optimizer's HBM traffic per rank
+    (0.61 ms -> 0.08 ms at 1 M Gaussians, profiles/r02_adam_bench.json) and 7 / 8 of the moment memory, and the
+    all-gather half moves PARAMETERS, which are needed only by the next step's first projection — a window the
+    all-reduce of gradients does not have.
+    The parameters are re-homed into one flat buffer with the bucket's layout (`p.data` becomes a view), so a shard
+    is one contiguous range of both; hyper-parameters stay per parameter (the reference's six groups:
+    method_configs.py:618-660), a shard that spans several parameters is stepped piece by piece in ONE launch.
+    gloo has no reduce-scatter: there the gradient is all-reduced and the shard cut out (tests only)."""
+
+    def __init__(self, bucket: GradBucket, hyper: Sequence[dict], adam_piece=None):
+        """hyper: one dict per bucket parameter (lr, betas, eps, weight_decay); adam_piece(p, g, m, v, lr, betas,
+        eps, weight_decay, step): the update of one flat piece (default: gg_adam_step through optim.adam_pieces)."""
+        self.bucket = bucket
+        self.world = dist.get_world_size() if _dist_on() else 1
+        self.rank = dist.get_rank() if _dist_on() else 0
+        assert len(hyper) == len(bucket.params)
+        self.hyper = [dict(lr=h["lr"], betas=tuple(h.get("betas", (0.9, 0.999))), eps=h.get("eps", 1e-8),
+                           weight_decay=h.get("weight_decay", 0.0)) for h in hyper]
+        self.adam_piece = adam_piece
+        self.step_count = 0
+        # flat parameters in the bucket's layout, padded so that every rank's shard has the same length
+        L = bucket.flat.numel()
+        unit = 64 * self.world
+        self.padded = (L + unit - 1) // unit * unit
+        self.shard = self.padded // self.world
+        dev = bucket.flat.device
+        self.flat_params = torch.zeros(self.padded, dtype=torch.float32, device=dev)
+        self.flat_grads = bucket.flat if self.padded == L else None     # (padding needed: a padded copy per step)
+        self.offsets = []
+        for p, sl in zip(bucket.params, bucket.slices):
+            off = sl.storage_offset() - bucket.flat.storage_offset()
+            self.offsets.append(off)
+            view = self.flat_params[off:off + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+        lo, hi = self.rank * self.shard, (self.rank + 1) * self.shard
+        self.pieces = []      # (parameter index, start, stop) of this rank's shard, in flat coordinates
+        for i, (p, off) in enumerate(zip(bucket.params, self.offsets)):
+            a, b = max(lo, off), min(hi, off + p.numel())
+            if a < b:
+                self.pieces.append((i, a, b))
+        self.exp_avg = [torch.zeros(b - a, dtype=torch.float32, device=dev) for _, a, b in self.pieces]
+        self.exp_avg_sq = [torch.zeros(b - a, dtype=torch.float32, device=dev) for _, a, b in self.pieces]
+        self.grad_shard = torch.zeros(self.shard, dtype=torch.float32, device=dev)
+
+    def step(self) -> None:
+        """after the step's backward passes: reduce-scatter, Adam on the shard, all-gather"""
+        b = self.bucket
+        b.flush()
+        lo = self.rank * self.shard
+        if self.world > 1:
+            src = b.flat
+            if self.padded != src.numel():
+                src = torch.zeros(self.padded, dtype=torch.float32, device=src.device)
+                src[:b.flat.numel()].copy_(b.flat)
+            if dist.get_backend() == "gloo":
+                dist.all_reduce(src, op=dist.ReduceOp.SUM)
+                self.grad_shard.copy_(src[lo:lo + self.shard])
+            else:
+                dist.reduce_scatter_tensor(self.grad_shard, src, op=dist.ReduceOp.SUM)
+        else:
+            self.grad_shard[:b.flat.numel()].copy_(b.flat) if self.padded != b.flat.numel() else \
+                self.grad_shard.copy_(b.flat)
+        self.step_count += 1
+        entries = []
+        for k, (i, a, z) in enumerate(self.pieces):
+            h = self.hyper[i]
+            entries.append((self.flat_params[a:z], self.grad_shard[a - lo:z - lo], self.exp_avg[k], self.exp_avg_sq[k],
+                            h["lr"], h["betas"], h["eps"], h["weight_decay"], self.step_count))
+        if self.adam_piece is not None:
+            with torch.no_grad():
+                for e in entries:
+                    self.adam_piece(*e)
+        else:
+            from .optim import adam_pieces
+            adam_pieces(entries)
+        if self.world > 1:
+            mine = self.flat_params[lo:lo + self.shard]
+            if dist.get_backend() == "gloo":
+                outs = [self.flat_params[r * self.shard:(r + 1) * self.shard] for r in range(self.world)]
+                dist.all_gather(outs, mine.clone())
+            else:
+                dist.all_gather_into_tensor(self.flat_params, mine)
+
+
 def train_step(render_and_backward: Callable[[int], None], bucket: GradBucket, view_ids: Sequence[int],
                reduce: bool = True, overlap: bool = True) -> None:
     """One optimizer step's worth of rasterizer work on this rank: fwd+bwd of its views with local
@@ -208,6 +324,8 @@ def train_step(render_and_backward: Callable[[int], None], bucket: GradBucket, v
             bucket.finish()
         else:
             bucket.all_reduce()
+    else:
+        bucket.flush()      # no reduction: the gradients must still be complete when the caller reads them
 
 
 def train_step_pipelined(render: Callable[[int], object], backward: Callable[[object], None], bucket: GradBucket,
@@ -249,6 +367,8 @@ def train_step_pipelined(render: Callable[[int], object], backward: Callable[[ob
             bucket.finish()
         else:
             bucket.all_reduce()
+    else:
+        bucket.flush()
 
 
 # ------------------------------------------------------------------------------------------------

@@ -8,8 +8,8 @@ Same constructor, same sub-module layout (`layers = Sequential(Linear, ReLU, Lin
 checkpoints' `fea_up.layers.{0,2}.{weight,bias}` load unchanged) and same call.  The forward is ONE
 fused fp32 MFMA kernel (csrc/mlp.hip) behind `gg_mlp_fwd`; there is no CPU path.  The backward at the
 reference's training size (1000 sampled pixels, :917) is ONE launch of `gg_mlp_bwd` (csrc/losses.hip);
-above `NATIVE_BWD_MAX_ROWS` rows the weight gradients are plain GEMMs and go to the library, as does a
-first layer wider than the fused forward kernel holds in registers (in_dim 128: BASELINE config 5)."""
+above `NATIVE_BWD_MAX_ROWS` rows the weight gradients are plain GEMMs and go to the library.  A first layer of
+128 inputs (BASELINE config 5) has its own forward kernel (W1 in LDS, the hidden tile in registers, W2 streamed)."""
 from __future__ import annotations
 
 from typing import Sequence
@@ -22,7 +22,7 @@ from . import _lib
 from .ops import _f32, _ptr, _require_hip, _stream
 
 HIDDEN = 128
-SUPPORTED_IN = (8, 16, 32, 64)          # fused forward kernel (W1 in registers)
+SUPPORTED_IN = (8, 16, 32, 64, 128)     # fused forward kernels (W1 in registers; 128: W1 in LDS, W2 slices streamed)
 SUPPORTED_IN_BWD = (8, 16, 32, 64, 128)
 NATIVE_BWD_MAX_ROWS = 1 << 16
 

@@ -75,6 +75,25 @@ def _launch(entries, zero_grad: bool) -> None:
         _lib.check(lib.gg_adam_step(len(chunk), arr, int(zero_grad), _stream(dev)), "gg_adam_step")
 
 
+@torch.no_grad()
+def adam_pieces(entries) -> None:
+    """Adam on raw flat pieces — (param, grad, exp_avg, exp_avg_sq, lr, betas, eps, weight_decay, step) each — in one
+    launch per 8 pieces (dist.ShardedAdamStep: a rank's shard of the flat parameter buffer)."""
+    if not entries:
+        return
+    lib = _lib.load()
+    dev = _require_hip(*[e[0] for e in entries])
+    for start in range(0, len(entries), _lib.ADAM_MAX_GROUPS):
+        chunk = entries[start:start + _lib.ADAM_MAX_GROUPS]
+        arr = (_lib.AdamGroup * len(chunk))()
+        for k, (p, g, m, v, lr, betas, eps, wd, step) in enumerate(chunk):
+            if not (p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()):
+                raise RuntimeError("adam_pieces needs contiguous pieces")
+            arr[k] = _lib.AdamGroup(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr),
+                                    float(betas[0]), float(betas[1]), float(eps), float(wd), int(step))
+        _lib.check(lib.gg_adam_step(len(chunk), arr, 0, _stream(dev)), "gg_adam_step")
+
+
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam (amsgrad off) as one streaming HIP kernel per step."""
 

@@ -48,9 +48,17 @@ def fused_view(model, means, log_scales, quats, opacities, colors_all, feature, 
     else:
         scales_e, quats_n = torch.exp(log_scales), quats / quats.norm(dim=-1, keepdim=True)
         opac = torch.sigmoid(opacities)
+    full_proj = projmat @ viewmat                                    # :707
+    model._gg_last_view = (viewmat, full_proj)                        # (what the operators were given: tests, debugging)
     model.xys, depths, model.radii, conics, num_tiles_hit, _cov3d = ops.ProjectGaussians.apply(
-        means, scales_e, 1, quats_n, viewmat[:3, :], projmat @ viewmat, fx, fy, cx, cy, H, W, tile_bounds)
-    if (model.radii).sum() == 0:                                   # :714
+        means, scales_e, 1, quats_n, viewmat[:3, :], full_proj, fx, fy, cx, cy, H, W, tile_bounds)
+    # :714 `if (self.radii).sum() == 0: return background` is a host round trip in front of every render.  With the
+    # product operators the answer comes for free AFTER the render: the tile lists' length was read back
+    # asynchronously while the sort and the blend were being enqueued (ops.Binning.resolve), and it is 0 exactly
+    # when no radius is positive (a positive radius covers at least one tile: csrc/project.hip).  Operator
+    # namespaces without that read-back (the oracle-backed test operators) keep the reference's check.
+    count_known_late = hasattr(ops, "last_num_intersects")
+    if not count_known_late and (model.radii).sum() == 0:
         return None
     if model.training:
         model.xys.retain_grad()                                    # :724-725
@@ -75,18 +83,95 @@ def fused_view(model, means, log_scales, quats, opacities, colors_all, feature, 
     # feature | rgb | depth (background 10, :769) | normal from one binning (pipeline.fused_images)
     feat_im, rgb, depth_im, normal_im = fused_images(ops, model.xys, depths, model.radii, conics, num_tiles_hit,
                                                      opac, H, W, feature, rgbs, model.normals, tail=tail)
+    if count_known_late and ops.last_num_intersects() == 0:
+        return None
     return {"rgb": rgb, "feature": feat_im, "depth": depth_im, "normal": normal_im}
 
 
-def make_fused_model_class(base, ops=_ops, background_override=lambda: None):
+class LazyOutputs(dict):
+    """The output dictionary of get_outputs with `normal_vis` / `feature_vis` computed when first read.
+    The reference computes both on every call (:785-795) — a rank-3 `torch.pca_lowrank` of the (H W, 32) feature
+    image included — although training reads neither (get_metrics_dict / get_loss_dict index rgb, depth, normal,
+    feature: :804-935); the viewer, eval images and render.sh do, and get exactly the reference's values (they are
+    materialised by `[]`, `get`, `items`, `values`, `pop`, `copy`, `==` and iteration over values)."""
+
+    def __init__(self, base: Dict, lazy: Dict):
+        super().__init__(base)
+        self._lazy = dict(lazy)
+        for k in self._lazy:
+            super().__setitem__(k, None)     # the keys exist from the start (`in`, `keys()`, `len`)
+
+    def _force(self, key=None):
+        for k in ([key] if key is not None else list(self._lazy)):
+            fn = self._lazy.pop(k, None)
+            if fn is not None:
+                super().__setitem__(k, fn())
+
+    def __getitem__(self, key):
+        self._force(key)
+        return super().__getitem__(key)
+
+    def get(self, key, default=None):
+        if key in self:
+            return self[key]
+        return default
+
+    def pop(self, key, *a):
+        self._force(key)
+        return super().pop(key, *a)
+
+    def items(self):
+        self._force()
+        return super().items()
+
+    def values(self):
+        self._force()
+        return super().values()
+
+    def copy(self):
+        self._force()
+        return dict(self)
+
+    def __eq__(self, other):
+        self._force()
+        return dict.__eq__(self, other)
+
+    def __setitem__(self, key, value):
+        self._lazy.pop(key, None)
+        super().__setitem__(key, value)
+
+
+def _camera_scalars(camera):
+    """fx, fy, cx, cy, the fovs' arguments, W, H of a one-camera `Cameras` in ONE device-to-host copy (the
+    reference reads them with six `.item()` / implicit float() conversions, each a stream synchronisation when the
+    camera lives on the GPU, as the datamanager's does: gaussian_splatting.py:669-674,706-707).  The two fov
+    arguments are the fp32 quotients the reference forms on the device (`camera.width / (2 * camera.fx)`: int64 by
+    float32 divides in float32), formed here from the same fp32 values."""
+    import numpy as np
+    vals = torch.cat([camera.fx.reshape(1), camera.fy.reshape(1), camera.cx.reshape(1), camera.cy.reshape(1),
+                      camera.width.reshape(1), camera.height.reshape(1)]).tolist()      # (promoted to fp32: exact)
+    fx, fy, cx, cy = vals[:4]
+    w, h = int(round(vals[4])), int(round(vals[5]))
+    f32 = np.float32
+    ax = float(f32(w) / (f32(2.0) * f32(fx)))
+    ay = float(f32(h) / (f32(2.0) * f32(fy)))
+    return fx, fy, cx, cy, ax, ay, w, h
+
+
+def make_fused_model_class(base, ops=_ops, background_override=lambda: None, fused_training: bool = False):
     """Subclass of the reference's GaussianSplattingModel whose get_outputs uses `fused_view`.
-    `base` is nerfstudio.models.gaussian_splatting.GaussianSplattingModel (or a stub with the same
-    attributes in the tests)."""
+    `base` is nerfstudio.models.gaussian_splatting.GaussianSplattingModel (or `stub.StubGaussianSplattingModel`,
+    which restates the attributes used here, where nerfstudio is not installed).
+    fused_training: the optimizer-side callbacks run on csrc/densify.hip too (`after_train`,
+    `refinement_after` through `densify.Refiner`: statistics, masks, split / duplicate / cull and the Adam-state
+    surgery of the six groups in a handful of launches, reference :373-546)."""
 
     class FusedGaussianSplattingModel(base):
         """GaussianSplattingModel on the fused MI355X rasterizer call (gaussiangrasper_amd.plugin)."""
 
-        compute_feature_vis = True     # the reference runs a rank-3 PCA of the feature image every call (:792-795)
+        # "lazy": normal_vis / feature_vis (the reference's rank-3 PCA of the feature image, :785-795) are computed
+        # when something reads them; "eager": on every call, as the reference does; "off": feature_vis = first 3 channels
+        feature_vis_mode = "lazy"
 
         def get_outputs(self, camera) -> Dict[str, Union[torch.Tensor, List]]:
             if not hasattr(camera, "camera_to_worlds"):            # :633-635
@@ -105,20 +190,43 @@ def make_fused_model_class(base, ops=_ops, background_override=lambda: None):
                 if crop_ids.sum() == 0:
                     return {"rgb": background.repeat(camera.height.item(), camera.width.item(), 1)}
             camera_downscale = self._get_downscale_factor()
-            camera.rescale_output_resolution(1 / camera_downscale)
+            if camera_downscale != 1:     # (x 1.0 changes nothing: seven launches and a host-to-device copy saved)
+                camera.rescale_output_resolution(1 / camera_downscale)
             # world -> camera, gsplat convention: rotate pi about x, analytic inverse (:658-668)
             c2w = camera.camera_to_worlds[0]
-            R = c2w[:3, :3] @ torch.diag(torch.tensor([1.0, -1.0, -1.0], device=c2w.device, dtype=c2w.dtype))
+            flips = self.__dict__.setdefault("_gg_flip", {})
+            fkey = (str(c2w.device), c2w.dtype)
+            if fkey not in flips:
+                flips[fkey] = torch.diag(torch.tensor([1.0, -1.0, -1.0], device=c2w.device, dtype=c2w.dtype))
+            R = c2w[:3, :3] @ flips[fkey]
             R_inv = R.T
             viewmat = torch.eye(4, device=c2w.device, dtype=c2w.dtype)
             viewmat[:3, :3] = R_inv
             viewmat[:3, 3:4] = -R_inv @ c2w[:3, 3:4]
-            cx, cy = camera.cx.item(), camera.cy.item()
-            fx, fy = camera.fx.item(), camera.fy.item()
-            W, H = camera.width.item(), camera.height.item()
-            fovx, fovy = 2 * math.atan(W / (2 * fx)), 2 * math.atan(H / (2 * fy))
+            # The intrinsics are host values in every operator signature, and reading them off a device-resident
+            # camera is a stream synchronisation: the host then cannot enqueue view k + 1 while view k runs (measured
+            # on the bench workload: 520 -> 459 views/s with one read-back per view).  The datamanager stamps every
+            # training camera with its dataset index (full_images_datamanager.py:375-377, `metadata["cam_idx"]`)
+            # and intrinsics are per-dataset constants (camera optimisation, if on, moves poses only), so each
+            # (index, downscale) is read back once.  Cameras without the stamp, and eval mode (where train and eval
+            # datasets share index values), are read every time.
+            md = getattr(camera, "metadata", None)
+            key = (int(md["cam_idx"]), camera_downscale) if (self.training and isinstance(md, dict)
+                                                            and "cam_idx" in md) else None
+            cache = self.__dict__.setdefault("_gg_camera_scalars", {})
+            scal = cache.get(key) if key is not None else None
+            if scal is None:
+                scal = _camera_scalars(camera)
+                if key is not None:
+                    cache[key] = scal
+            fx, fy, cx, cy, ax, ay, W, H = scal
+            fovx, fovy = 2 * math.atan(ax), 2 * math.atan(ay)       # :672-673 (fp32 quotients, atan in double)
             self.last_size = (H, W)
-            projmat = projection_matrix(0.001, 1000, fovx, fovy, device=self.device)
+            pcache = self.__dict__.setdefault("_gg_projmat", {})
+            pkey = (ax, ay, str(self.device))
+            if pkey not in pcache:       # a function of the intrinsics only: one host-built matrix per camera model
+                pcache[pkey] = projection_matrix(0.001, 1000, fovx, fovy, device=self.device)
+            projmat = pcache[pkey]
             tile_bounds = ((W + BLOCK - 1) // BLOCK, (H + BLOCK - 1) // BLOCK, 1)
             pick = (lambda t: t[crop_ids]) if crop_ids is not None else (lambda t: t)
             cam_pos = camera.camera_to_worlds.detach()[..., :3, 3]
@@ -126,55 +234,140 @@ def make_fused_model_class(base, ops=_ops, background_override=lambda: None):
             out = fused_view(self, pick(self.means), pick(self.scales), pick(self.quats), pick(self.opacities),
                              pick(self.colors_all), pick(self.feature), viewmat, projmat, cam_pos, fx, fy, cx, cy,
                              H, W, tile_bounds, n, ops)
-            camera.rescale_output_resolution(camera_downscale)      # :798 (both exits)
             if out is None:
-                return {"rgb": background.repeat(camera.height.item(), camera.width.item(), 1)}
-            out["normal_vis"] = (out["normal"] + 1) / 2
-            feat = out["feature"]
-            if feat.shape[-1] == 3:
-                out["feature_vis"] = (torch.nn.functional.normalize(feat, dim=-1) + 1) / 2
-            elif self.compute_feature_vis:
+                # :714-715 — the reference leaves through this exit WITHOUT scaling the camera back (:798 is not
+                # reached); kept as it is (PARITY.md)
+                return {"rgb": background.repeat(H, W, 1)}
+            if camera_downscale != 1:
+                camera.rescale_output_resolution(camera_downscale)  # :798
+            feat, normal = out["feature"], out["normal"]
+
+            def normal_vis():
+                return (normal + 1) / 2
+
+            def feature_vis():
+                if feat.shape[-1] == 3:
+                    return (torch.nn.functional.normalize(feat, dim=-1) + 1) / 2
+                if self.feature_vis_mode == "off":
+                    return feat[..., :3]
                 flat = feat.view(-1, feat.size(-1))
                 _, _, V = torch.pca_lowrank(flat, q=3)
-                out["feature_vis"] = torch.matmul(flat, V[:, :3]).view(feat.size()[:-1] + (3,))
-            else:
-                out["feature_vis"] = feat[..., :3]
+                return torch.matmul(flat, V[:, :3]).view(feat.size()[:-1] + (3,))
+
+            lazy = {"normal_vis": normal_vis, "feature_vis": feature_vis}
+            if self.feature_vis_mode == "lazy":
+                return LazyOutputs(out, lazy)
+            out.update({k: f() for k, f in lazy.items()})
             return out
+
+        # ---- optimizer side (fused_training) -----------------------------------------------------
+        def _refiner(self, optimizers=None):
+            from .densify import GROUPS, RefineConfig, Refiner
+            r = getattr(self, "_gg_refiner", None)
+            if r is None:
+                c = self.config
+                cfg = RefineConfig(**{k: getattr(c, k) for k in RefineConfig.__dataclass_fields__ if hasattr(c, k)})
+                r = Refiner({a: getattr(self, a) for a in GROUPS.values()}, {}, cfg,
+                            num_train_data=getattr(self, "num_train_data", 0))
+                object.__setattr__(self, "_gg_refiner", r)
+            if optimizers is not None:   # nerfstudio's Optimizers: .optimizers maps group name -> torch optimizer
+                r.optimizers = {g: o for g, o in optimizers.optimizers.items() if g in GROUPS}
+            return r
+
+        def after_train(self, step: int):
+            if not fused_training:
+                return super().after_train(step)
+            assert step == self.step
+            if self.xys.grad is None:
+                raise RuntimeError("after_train: self.xys has no gradient (get_outputs retains it in training mode)")
+            r = self._refiner()
+            r.params = {a: getattr(self, a) for a in r.params}      # (load_state_dict may have replaced them)
+            r.after_train(self.xys.grad, self.radii, self.last_size)
+            self.xys_grad_norm, self.vis_counts, self.max_2Dsize = r.xys_grad_norm, r.vis_counts, r.max_2Dsize
+
+        def refinement_after(self, optimizers, step):
+            if not fused_training:
+                return super().refinement_after(optimizers, step)
+            assert step == self.step
+            r = self._refiner(optimizers)
+            r.params = {a: getattr(self, a) for a in r.params}
+            info = r.refinement_after(step)
+            from .densify import GROUPS
+            for group, attr in GROUPS.items():
+                setattr(self, attr, r.params[attr])                 # the new Parameters (:434-439, :497-502)
+                if hasattr(optimizers, "parameters") and group in optimizers.parameters:
+                    optimizers.parameters[group] = [r.params[attr]]
+            self.xys_grad_norm, self.vis_counts, self.max_2Dsize = r.xys_grad_norm, r.vis_counts, r.max_2Dsize
+            return info
 
     FusedGaussianSplattingModel.__qualname__ = "FusedGaussianSplattingModel"
     return FusedGaussianSplattingModel
 
 
-_model_class = None
+_model_class = {}
+FUSED_GROUPS = ("xyz", "color", "feature", "opacity", "scaling", "rotation")   # method_configs.py:618-660
 
 
-def model_class():
+def fused_training_default() -> bool:
+    """GG_FUSED_TRAINING=0 keeps the reference's torch.optim.Adam instances and its own refinement callbacks."""
+    import os
+    return os.environ.get("GG_FUSED_TRAINING", "1") not in ("0", "false", "no", "")
+
+
+def model_class(fused_training: bool = False):
     """The subclass of the real reference model (imports nerfstudio)."""
-    global _model_class
-    if _model_class is None:
+    if fused_training not in _model_class:
         from nerfstudio.model_components import renderers
         from nerfstudio.models.gaussian_splatting import GaussianSplattingModel
-        _model_class = make_fused_model_class(GaussianSplattingModel,
-                                              background_override=lambda: renderers.BACKGROUND_COLOR_OVERRIDE)
-    return _model_class
+        _model_class[fused_training] = make_fused_model_class(
+            GaussianSplattingModel, background_override=lambda: renderers.BACKGROUND_COLOR_OVERRIDE,
+            fused_training=fused_training)
+    return _model_class[fused_training]
 
 
-def _spec(method_name: str):
+def _spec(method_name: str, fused_training: Optional[bool] = None):
     from nerfstudio.configs.method_configs import method_configs    # populated before plugins are discovered
     from nerfstudio.plugins.types import MethodSpecification
+    if fused_training is None:
+        fused_training = fused_training_default()
     config = copy.deepcopy(method_configs["gaussian-splatting"])
     config.method_name = method_name
-    config.pipeline.model._target = model_class()
+    config.pipeline.model._target = model_class(fused_training)
+    if fused_training:
+        # engine/optimizers.py:45-58: AdamOptimizerConfig.setup(params) calls _target(params, lr=..., eps=..., ...):
+        # the six Gaussian groups step through ONE streaming kernel each (optim.FusedAdam: torch.optim.Adam's
+        # constructor, param_groups and state, bit-identical update); camera_opt / up_net stay torch.optim.Adam
+        from .optim import FusedAdam
+        for group in FUSED_GROUPS:
+            if group in config.optimizers:
+                config.optimizers[group]["optimizer"]._target = FusedAdam
     return MethodSpecification(config=config, description=DESCRIPTION)
 
 
 def gaussian_splatting():
     """NERFSTUDIO_METHOD_CONFIGS="gaussian-splatting=gaussiangrasper_amd.plugin:gaussian_splatting":
-    replaces the reference's method of that name, so train.sh / render.sh / update.sh run unchanged."""
+    replaces the reference's method of that name, so train.sh / render.sh / update.sh run unchanged — the fused
+    renderer, and (unless GG_FUSED_TRAINING=0) the fused Adam step and refinement callbacks."""
     return _spec("gaussian-splatting")
 
 
 def gaussian_splatting_amd():
-    """NERFSTUDIO_METHOD_CONFIGS="gaussian-splatting-amd=gaussiangrasper_amd.plugin:gaussian_splatting_amd"
-    (or the entry point of the same name): the fused method next to the reference's."""
+    """NERFSTUDIO_METHOD_CONFIGS="gaussian-splatting-amd=gaussiangrasper_amd.plugin:gaussian_splatting_amd":
+    the same method next to the reference's."""
     return _spec("gaussian-splatting-amd")
+
+
+def __getattr__(name: str):
+    """Entry-point route.  `discover_methods` (nerfstudio/plugins/registry.py:42-51) takes what an entry point of
+    group `nerfstudio.method_configs` loads only if it already IS a MethodSpecification (callables are called for
+    the environment variable only, :65-66), so the module offers the two specifications as attributes built on
+    first access (PEP 562):
+
+        [project.entry-points."nerfstudio.method_configs"]
+        gaussian-splatting-amd = "gaussiangrasper_amd.plugin:gaussian_splatting_amd_spec"
+    """
+    if name == "gaussian_splatting_spec":
+        return gaussian_splatting()
+    if name == "gaussian_splatting_amd_spec":
+        return gaussian_splatting_amd()
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

@@ -177,6 +177,10 @@ int gg_bin_sort(int num_points, int64_t num_intersects, const float *xys, const 
  * min(count, capacity) entries.  The caller reads the count back later (asynchronously) and, in the
  * rare case count > capacity (lists truncated), calls again with a larger capacity.  Removes the one
  * host<->device round trip per view the reference has at this point (`.item()`). */
+/* Status of the sort that last ran in `ws` (same num_points / num_intersects or capacity as that call): waits for
+ * the stream and returns an error if the offsets scan's decoupled look-back gave up — never expected; the sort then
+ * left every tile range empty instead of publishing lists built from wrong offsets. */
+int gg_bin_sort_status(int num_points, int64_t num_intersects, const void *ws, size_t ws_bytes, gg_stream_t stream);
 int gg_bin_sort_dev(int num_points, int64_t capacity, const int64_t *num_intersects_dev,
                     const float *xys, const float *depths, const int32_t *radii,
                     const int32_t *num_tiles_hit, int tiles_x, int tiles_y,
@@ -415,11 +419,14 @@ int gg_densify_rows(int num_rows, const uint8_t *split_mask, const uint8_t *dup_
 int gg_densify_stats(int num_points, const float *xys_grad, const int32_t *radii, int max_image_dim,
                      int first, float *grad_norm_accum, float *vis_counts, float *max_2dsize,
                      gg_stream_t stream);
-/* split / dup masks of refinement_after (:412-421, :430-431); scales are log-scales (N,3). */
+/* split / dup masks of refinement_after (:412-421, :430-431); scales are log-scales (N,3).  The duplicate test
+ * runs on the scales split_gaussians has already shrunk in place (log(exp(s) / size_fac) for the split rows,
+ * :524-526), as the reference's does: a Gaussian can be in both masks. */
 int gg_densify_masks(int num_points, const float *grad_norm_accum, const float *vis_counts,
                      const float *max_2dsize, const float *scales, int max_image_dim,
                      float densify_grad_thresh, float densify_size_thresh, float split_screen_size,
-                     int use_screen_size, uint8_t *split_mask, uint8_t *dup_mask, gg_stream_t stream);
+                     int use_screen_size, float size_fac, uint8_t *split_mask, uint8_t *dup_mask,
+                     gg_stream_t stream);
 /* cull mask of cull_gaussians (:485-496); opacities are logits (N,), scales log-scales (N,3). */
 int gg_cull_mask(int num_points, const float *opacities, const float *scales, const float *max_2dsize,
                  float cull_alpha_thresh, float cull_scale_thresh, float cull_screen_size,

@@ -1182,8 +1182,8 @@ void NAME(densify_rows)(int N, const uint8_t *split_mask, const uint8_t *dup_mas
                     dst[row * w + c] = out;
                 }
             }
-            if (is_dup)
-                dst[((size_t)N + (size_t)nsamps * n_split + dr) * w + c] = (kind == 3) ? R_(0.0f) : val;
+            if (is_dup)   /* dup_gaussians reads self.scales after split_gaussians shrank the split rows (:524-526, :541) */
+                dst[((size_t)N + (size_t)nsamps * n_split + dr) * w + c] = (kind == 3) ? R_(0.0f) : old_v;
         }
         sr += is_split;
         dr += is_dup;
@@ -1217,18 +1217,33 @@ void NAME(densify_stats)(int N, const REAL *xys_grad, const int32_t *radii, int 
     }
 }
 
-/* refinement_after (:412-421, :430-431) */
+/* refinement_after (:412-421, :430-431).  The order of the reference's statements matters: split_gaussians
+ * (:423-429) shrinks self.scales[split_mask] in place (:524-526) BEFORE `dups = scales.exp().max() <= thresh`
+ * (:430), so the duplicate test of a split Gaussian runs on log(exp(s) / size_fac). */
 void NAME(densify_masks)(int N, const REAL *grad_norm, const REAL *vis_counts, const REAL *max_2dsize,
                          const REAL *scales, int max_dim, REAL grad_thresh, REAL size_thresh,
-                         REAL split_screen_size, int use_screen, uint8_t *split_mask, uint8_t *dup_mask) {
+                         REAL split_screen_size, int use_screen, REAL size_fac, uint8_t *split_mask,
+                         uint8_t *dup_mask) {
     for (int i = 0; i < N; ++i) {
         const REAL avg = ((grad_norm[i] / vis_counts[i]) * R_(0.5f)) * (REAL)max_dim;
         const int high = avg > grad_thresh;
-        const REAL smax = ggo_max_exp3(scales + 3 * (size_t)i);
+        const REAL *sc = scales + 3 * (size_t)i;
+        REAL smax = ggo_max_exp3(sc);
         int split = smax > size_thresh;
         if (use_screen) split = split || (max_2dsize[i] > split_screen_size);
         split = split && high;
         split_mask[i] = (uint8_t)split;
+        if (split) {
+            REAL sh[3];
+            for (int k = 0; k < 3; ++k) {
+#ifdef GGO_F64
+                sh[k] = log(exp(sc[k]) / size_fac);
+#else
+                sh[k] = logf(expf(sc[k]) / size_fac);
+#endif
+            }
+            smax = ggo_max_exp3(sh);
+        }
         dup_mask[i] = (uint8_t)((smax <= size_thresh) && high);
     }
 }

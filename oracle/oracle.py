@@ -411,14 +411,14 @@ def densify_stats(xys_grad, radii, max_dim, first, grad_norm, vis_counts, max_2d
 
 
 def densify_masks(grad_norm, vis_counts, max_2dsize, scales, max_dim, grad_thresh, size_thresh,
-                  split_screen_size, use_screen, dtype=np.float32):
+                  split_screen_size, use_screen, dtype=np.float32, size_fac=1.6):
     lib, pre, RT = _lib(dtype)
     n = np.asarray(grad_norm).shape[0]
     sm, dm = np.empty(n, np.uint8), np.empty(n, np.uint8)
     getattr(lib, pre + "densify_masks")(C.c_int(n), _p(_c(grad_norm, dtype)), _p(_c(vis_counts, dtype)),
                                         _p(_c(max_2dsize, dtype)), _p(_c(scales, dtype)), C.c_int(max_dim),
                                         RT(grad_thresh), RT(size_thresh), RT(split_screen_size),
-                                        C.c_int(int(use_screen)), _p(sm), _p(dm))
+                                        C.c_int(int(use_screen)), RT(size_fac), _p(sm), _p(dm))
     return sm.astype(bool), dm.astype(bool)
 
 

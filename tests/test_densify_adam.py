@@ -46,8 +46,9 @@ def torch_split_dup(p, split, dup, samps, z, quat_to_rotmat):
     scales_old = p["scales"].clone()
     scales_old[split] = shrunk
     rep = lambda t: t[split].repeat(samps, *([1] * (t.dim() - 1)))
+    # dup_gaussians (:541) copies self.scales AFTER split_gaussians shrank the split rows in place (:524-526)
     return {"means": torch.cat([p["means"], new_means, p["means"][dup]]),
-            "scales": torch.cat([scales_old, shrunk.repeat(samps, 1), p["scales"][dup]]),
+            "scales": torch.cat([scales_old, shrunk.repeat(samps, 1), scales_old[dup]]),
             "quats": torch.cat([p["quats"], rep(p["quats"]), p["quats"][dup]]),
             "opacities": torch.cat([p["opacities"], rep(p["opacities"]), p["opacities"][dup]]),
             "colors_all": torch.cat([p["colors_all"], rep(p["colors_all"]), p["colors_all"][dup]]),
@@ -83,7 +84,13 @@ def torch_masks(norm, counts, size, scales, max_dim, cfg, step):
     splits = big.clone()
     if step < cfg.stop_screen_size_at:
         splits |= size > cfg.split_screen_size
-    return splits & high, (~big) & high
+    splits = splits & high
+    # the reference's statement order: split_gaussians (:423-429) has shrunk self.scales[splits] in place (:524-526)
+    # when `dups = self.scales.exp().max(dim=-1).values <= thresh` (:430) is evaluated
+    scales = scales.clone()
+    scales[splits] = torch.log(torch.exp(scales[splits]) / 1.6)
+    dups = (scales.exp().max(dim=-1).values <= cfg.densify_size_thresh) & high
+    return splits, dups
 
 
 def torch_cull(opac, scales, size, cfg, step):
@@ -156,13 +163,20 @@ def test_oracle_compaction_and_scan_match_torch_indexing(oracle):
             assert np.array_equal(out, t[~mask].numpy())
 
 
-def test_oracle_split_dup_matches_the_reference_torch_code(oracle):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_oracle_split_dup_matches_the_reference_torch_code(oracle, overlap):
+    """overlap: Gaussians in BOTH masks (split for their screen size or with thresh < size <= 1.6 thresh, then
+    small enough after the in-place shrink to be duplicated as well): their dup row carries the shrunk scale"""
     import oracle_ops
     n, samps = 700, 2
     p = _params(n, d=8, seed=4)
     g = torch.Generator().manual_seed(5)
     split = torch.rand(n, generator=g) < 0.2
-    dup = (torch.rand(n, generator=g) < 0.3) & ~split
+    dup = (torch.rand(n, generator=g) < 0.3)
+    if not overlap:
+        dup = dup & ~split
+    else:
+        assert int((dup & split).sum()) > 10
     z = torch.randn(samps * int(split.sum()), 3, generator=g)
     want = torch_split_dup(p, split, dup, samps, z, oracle_ops.quat_to_rotmat)
     kinds = {"means": oracle.ROWS_MEANS, "scales": oracle.ROWS_SCALES}
@@ -202,6 +216,7 @@ def test_oracle_stats_and_masks_match_the_reference_torch_code(oracle):
         assert np.array_equal(oc, counts.numpy()) and np.array_equal(osz, size.numpy())
         assert _ulp_diff(on, norm.numpy()).max() <= 1 + it  # sqrt(x^2+y^2): torch sums the squares its own way
     scales = _away(torch.randn(n, 3, generator=g) * 1.5 - 4.6, float(np.log(cfg.densify_size_thresh)))
+    scales = _away(scales, float(np.log(1.6 * cfg.densify_size_thresh)))   # the duplicate test of a split Gaussian
     scales = _away(scales, float(np.log(cfg.cull_scale_thresh)))
     opac = _away(2 * torch.randn(n, 1, generator=g), float(np.log(0.1 / 0.9)))
     norm_t = torch.from_numpy(on)
@@ -212,6 +227,14 @@ def test_oracle_stats_and_masks_match_the_reference_torch_code(oracle):
                                         step < cfg.stop_screen_size_at)
         assert np.array_equal(s_o, s_t.numpy()) and np.array_equal(d_o, d_t.numpy())
         assert s_o.any() and d_o.any()
+        # both masks at once, the reference's statement order (:423-431): a size in (thresh, 1.6 thresh] ...
+        smax = scales.exp().max(dim=-1).values.numpy()
+        mid = (smax > cfg.densify_size_thresh) & (smax <= 1.6 * cfg.densify_size_thresh * (1 - 1e-3))
+        assert (s_o & d_o & mid).any() and np.array_equal((s_o & mid), (d_o & mid))
+        # ... and a small Gaussian split for its screen size
+        if step < cfg.stop_screen_size_at:
+            small = smax <= cfg.densify_size_thresh
+            assert (s_o & d_o & small).any()
         c_t = torch_cull(opac, scales, size, cfg, step)
         c_o = oracle.cull_mask(opac.numpy(), scales.numpy(), osz, cfg.cull_alpha_thresh, cfg.cull_scale_thresh,
                                cfg.cull_screen_size, step > cfg.refine_every * cfg.reset_alpha_every,
@@ -289,15 +312,21 @@ def test_gpu_compaction_of_eighteen_arrays_in_one_launch():
 
 
 @gpu
-@pytest.mark.parametrize("n,samps", [(700, 2), (40_000, 2), (3000, 3)])
-def test_gpu_split_dup_vs_oracle_and_torch(oracle, n, samps):
+@pytest.mark.parametrize("n,samps,overlap", [(700, 2, False), (40_000, 2, True), (3000, 3, True)])
+def test_gpu_split_dup_vs_oracle_and_torch(oracle, n, samps, overlap):
+    """overlap: Gaussians in both masks (the reference's statement order allows it, :423-431): their duplicate row
+    carries the scale split_gaussians has already shrunk"""
     from gaussiangrasper_amd import _lib
     from gaussiangrasper_amd import ops as P
     from gaussiangrasper_amd.densify import append_rows
     p = _params(n, d=32, seed=n)
     g = torch.Generator().manual_seed(n + 1)
     split = torch.rand(n, generator=g) < 0.15
-    dup = (torch.rand(n, generator=g) < 0.25) & ~split
+    dup = (torch.rand(n, generator=g) < 0.25)
+    if not overlap:
+        dup = dup & ~split
+    else:
+        assert int((dup & split).sum()) > 10
     z = torch.randn(samps * int(split.sum()), 3, generator=g)
     kinds = {"means": _lib.ROWS_MEANS, "scales": _lib.ROWS_SCALES}
     names = list(p)
@@ -317,7 +346,8 @@ def test_gpu_split_dup_vs_oracle_and_torch(oracle, n, samps):
             assert np.allclose(got, want_o, rtol=2e-6, atol=2e-6), k           # expf / logf: ocml vs glibc
             assert np.allclose(got, want_t[k].cpu().numpy(), rtol=2e-6, atol=2e-6), k
             assert np.array_equal(got[:n][~split.numpy()], p[k].numpy()[~split.numpy()])
-            assert np.array_equal(got[n + samps * ns:], p[k][dup].numpy())
+            only_dup = (dup & ~split)[dup].numpy()      # rows that are duplicated without having been split
+            assert np.array_equal(got[n + samps * ns:][only_dup], p[k][dup].numpy()[only_dup])
         else:
             assert np.array_equal(got, want_o), k
             assert torch.equal(o, want_t[k]), k
@@ -331,7 +361,8 @@ def test_gpu_stats_masks_bitexact_vs_oracle(oracle):
     n, size_hw = 30_000, (1200, 1600)
     p = _params(n, seed=21)
     g = torch.Generator().manual_seed(22)
-    p["scales"] = _away(_away(torch.randn(n, 3, generator=g) * 1.5 - 4.6, float(np.log(cfg.densify_size_thresh))),
+    p["scales"] = _away(_away(_away(torch.randn(n, 3, generator=g) * 1.5 - 4.6, float(np.log(cfg.densify_size_thresh))),
+                              float(np.log(1.6 * cfg.densify_size_thresh))),
                         float(np.log(cfg.cull_scale_thresh)))
     p["opacities"] = _away(2 * torch.randn(n, 1, generator=g), float(np.log(0.1 / 0.9)))
     ref = Refiner({k: v.to(DEV) for k, v in p.items()}, {}, cfg)
@@ -430,7 +461,8 @@ def test_gpu_refinement_after_end_to_end_against_the_torch_restatement():
     n, hw = 12_000, (1200, 1600)
     base = _params(n, seed=41)
     g = torch.Generator().manual_seed(42)
-    base["scales"] = _away(_away(torch.randn(n, 3, generator=g) * 1.2 - 4.6, float(np.log(cfg.densify_size_thresh))),
+    base["scales"] = _away(_away(_away(torch.randn(n, 3, generator=g) * 1.2 - 4.6, float(np.log(cfg.densify_size_thresh))),
+                                 float(np.log(1.6 * cfg.densify_size_thresh))),
                            float(np.log(cfg.cull_scale_thresh)))
     base["opacities"] = _away(2 * torch.randn(n, 1, generator=g), float(np.log(0.1 / 0.9)))
     params = {k: torch.nn.Parameter(v.clone().to(DEV)) for k, v in base.items()}
@@ -490,3 +522,74 @@ def test_gpu_refinement_after_end_to_end_against_the_torch_restatement():
     assert torch.all(ref.params["opacities"] == val)
     st = opts["opacity"].state[ref.params["opacities"]]
     assert not st["exp_avg"].any() and not st["exp_avg_sq"].any()
+
+
+@gpu
+def test_plugin_class_trains_with_the_fused_optimizer_side():
+    """What train.sh gets from the plugin (fused_training): the trainer's own loop (trainer.py:459-498 —
+    zero_grad, model(camera), loss.backward(), optimizer steps, then the AFTER_TRAIN_ITERATION callbacks in the order
+    get_training_callbacks registers them, gaussian_splatting.py:548-571) on the plugin's model class, with
+    optim.FusedAdam for the six Gaussian groups (what plugin._spec puts into the config) and its after_train /
+    refinement_after on densify.Refiner.  250 iterations across three refinements: the class swaps the new Parameters
+    into the model AND into the optimizers with moments of matching shape, statistics restart, rendering continues at
+    the new N; and the first refinement equals the reference's torch sequence on the same state."""
+    import types
+    from gaussiangrasper_amd import ops as P
+    from gaussiangrasper_amd.camera import ring_cameras
+    from gaussiangrasper_amd.optim import FusedAdam
+    from gaussiangrasper_amd.plugin import make_fused_model_class
+    from gaussiangrasper_amd.scene import make_scene
+    from gaussiangrasper_amd.stub import StubCameras, StubGaussianSplattingModel, default_config
+    torch.manual_seed(0)
+    n, h, w, nviews = 4000, 96, 128, 6
+    sc = make_scene(n, feature_dim=32, config_index=2)
+    sc.scales.add_(1.0)
+    cfg = default_config(num_downscales=0, densify_grad_thresh=2e-7)     # full resolution; this toy scene's gradients are small
+    Model = make_fused_model_class(StubGaussianSplattingModel, fused_training=True)
+    m = Model(sc, config=cfg, num_train_data=nviews, step=500).to(DEV)
+    m.train()
+    groups = m.get_gaussian_param_groups()
+    optimizers = types.SimpleNamespace(
+        optimizers={g: FusedAdam(ps, **REF_GROUPS[g]) for g, ps in groups.items()},
+        parameters={g: list(ps) for g, ps in groups.items()})
+    cams = [StubCameras.from_view(v, device=DEV, cam_idx=i) for i, v in enumerate(ring_cameras(nviews, h, w))]
+    gen = torch.Generator().manual_seed(1)
+    targets = [torch.rand(h, w, 3, generator=gen).to(DEV) for _ in range(nviews)]
+    counts, first_checked = [], False
+    for step in range(500, 750):
+        m.step_cb(step)
+        for o in optimizers.optimizers.values():
+            o.zero_grad(set_to_none=True)
+        out = m(cams[step % nviews])
+        loss = (out["rgb"] - targets[step % nviews]).abs().mean() + 0.1 * out["feature"].pow(2).mean() \
+            + 0.01 * out["depth"].mean() + 0.01 * out["normal"].pow(2).mean()
+        loss.backward()
+        for o in optimizers.optimizers.values():
+            o.step()
+        m.after_train(step)
+        if step % cfg.refine_every == 0:
+            if not first_checked and step % (cfg.reset_alpha_every * cfg.refine_every) > nviews + cfg.refine_every:
+                # the state the refinement starts from, for the reference's torch sequence (:412-431, :485-496)
+                norm, cnt, size = m.xys_grad_norm.clone(), m.vis_counts.clone(), m.max_2Dsize.clone()
+                p0 = {a: getattr(m, a).detach().clone() for a in GROUPS.values()}
+                split, dup = torch_masks(norm, cnt, size, p0["scales"], max(h, w), cfg, step)
+            before = m.num_points
+            info = m.refinement_after(optimizers, step)
+            if not first_checked and info["split"] + info["dup"] > 0:
+                first_checked = True
+                assert info["split"] == int(split.sum()) and info["dup"] == int(dup.sum())
+                assert m.num_points == before + cfg.n_split_samples * info["split"] + info["dup"] - info["culled"]
+            counts.append(m.num_points)
+            # the wiring: model attributes, optimizer param_groups and moments, the trainer's parameter table
+            for g, a in GROUPS.items():
+                p = getattr(m, a)
+                opt = optimizers.optimizers[g]
+                assert opt.param_groups[0]["params"][0] is p and optimizers.parameters[g][0] is p
+                assert p.shape[0] == m.num_points and p.is_leaf and p.requires_grad
+                st = opt.state[p]
+                assert st["exp_avg"].shape == p.shape == st["exp_avg_sq"].shape
+            assert m.xys_grad_norm is None and m.vis_counts is None and m.max_2Dsize is None
+    assert first_checked and len(counts) == 3 and counts[-1] != n     # refinements at steps 500, 600, 700
+    assert all(bool(torch.isfinite(getattr(m, a)).all()) for a in GROUPS.values())
+    assert m.xys.shape[0] == m.num_points == m.radii.shape[0]
+    P.clear_bin_cache()

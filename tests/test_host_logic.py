@@ -217,6 +217,16 @@ def test_bench_spawns_its_own_ranks_and_reduces_gradients(tmp_path):
     assert torch.allclose(b, c, rtol=1e-5, atol=tol)
 
 
+def test_bench_reduce_scatter_adam_all_gather_scheme_runs_on_two_gloo_ranks(tmp_path):
+    """`--reduce rs_ag`: the step ends with reduce-scatter, Adam on the rank's shard and an all-gather of the
+    parameters (dist.ShardedAdamStep; its arithmetic is pinned in tests/test_sharded_step.py)"""
+    r = _run_bench(["--reduce", "rs_ag"], tmp_path, 2)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2
+    assert lines[0]["config"]["grad_allreduce"].startswith("reduce-scatter")
+
+
 def test_bench_refuses_a_world_size_that_is_not_gpus(tmp_path):
     """no silent single-GPU fallback: WORLD_SIZE=1 with --gpus 2 is an error, not a 1-GPU run"""
     r = _run_bench([], tmp_path, 2, env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})

@@ -3,7 +3,8 @@
 headline metric stays bench.py's operator path with synthetic cotangents):
 
     per view (the reference trains one view per step; here `--views` views share a step as in bench.py):
-        render through the plugin route (ActivateGaussians, ProjectGaussians, ShadeTail, RasterizeSegments)
+        render through the plugin's model class (get_outputs: ActivateGaussians, ProjectGaussians, ShadeTail,
+        RasterizeSegments)
         main_loss   = (1 - 0.2) L1 + 0.2 (1 - SSIM)          gaussian_splatting.py:882-885, :931
         depth_loss  = L1, normal_loss = 0.5 mse + 0.5 cosine   :879-880   over the masked pixels
         feature_loss: cosine similarity of 800 sampled pixel pairs, up_loss: fea_up MLP on 1000 sampled pixels
@@ -54,9 +55,15 @@ def main():
     dev = torch.device("cuda:0")
     h, w = a.height, a.width
     scene = make_scene(a.points, config_index=3).to(dev)
-    for p in scene.params():
-        p.requires_grad_(True)
     views = ring_cameras(a.views, h, w, device=dev)
+    # the render goes through the class train.sh loads (plugin.FusedGaussianSplattingModel.get_outputs, on stub.py's
+    # stand-ins for nerfstudio's base model and Cameras); its six Parameters are the scene's leaves
+    from gaussiangrasper_amd.plugin import make_fused_model_class
+    from gaussiangrasper_amd.stub import StubCameras, StubGaussianSplattingModel
+    model = make_fused_model_class(StubGaussianSplattingModel, fused_training=True)(scene).train()
+    for n_ in ("means", "scales", "quats", "opacities", "colors_all", "feature"):
+        setattr(scene, n_, getattr(model, n_))
+    cams = [StubCameras.from_view(v, device=dev, cam_idx=i) for i, v in enumerate(views)]
     g = torch.Generator(device="cpu").manual_seed(7)
     # synthetic supervision of the right shapes (resident in HBM)
     gt_rgb = torch.rand(h, w, 3, generator=g).to(dev)
@@ -87,7 +94,7 @@ def main():
         for k, v in enumerate(views):
             if k == len(views) - 1:
                 bucket.arm()                          # the step's last backward
-            out = render_view(scene, v, ops, fused=True)
+            out = model(cams[k])
             rgb, depth, normal, feature = out["rgb"], out["depth"], out["normal"], out["feature"]
             if fused:
                 main_l = losses.main_loss(rgb, gt_rgb, valid, 0.2)[0]

@@ -244,6 +244,11 @@ def load_pmc():
         return {}, None
 
 
+# cycles one fp32 MFMA holds the matrix pipe (to turn busy cycles into an instruction count): the forward kernels use
+# v_mfma_f32_32x32x2_f32 (64), the 16-slot backward kernels v_mfma_f32_16x16x4_f32 (32)
+MFMA_CYCLES_F32 = {"blend_fwd_pair_kernel<40>": 64.0, "blend_fwd_kernel<32>": 64.0}
+
+
 def build_roofline(args, kernels, n_vis, n_isect, ms_per_view):
     P = args.height * args.width
     pmc, pmc_file = load_pmc()
@@ -267,6 +272,15 @@ def build_roofline(args, kernels, n_vis, n_isect, ms_per_view):
                 entry["valu"] = {"insts": rec["insts_valu"], "issue_weight": w,
                                  "weighted_issue_cycles": weighted, "peak_cycles": peak,
                                  "frac": weighted / peak}
+                # fp32 MFMAs take the SAME issue budget as fp32 VALU instructions on gfx950 (tools/ubench_coexec.hip:
+                # an MFMA wave beside a VALU wave on one SIMD takes the SUM of their times, not the maximum), so the
+                # roof these kernels answer to is VALU cycles + matrix-pipe busy cycles per SIMD
+                mf = float(rec.get("mfma_busy_cycles") or 0.0)
+                if mf > 0.0:
+                    n_mfma = mf / MFMA_CYCLES_F32.get(name, 32.0)      # the MFMA instructions are in SQ_INSTS_VALU too
+                    valu_only = max(weighted - 2.0 * n_mfma, 0.0)
+                    entry["fp32_issue"] = {"valu_cycles": valu_only, "mfma_busy_cycles": mf, "peak_cycles": peak,
+                                           "frac": (valu_only + mf) / peak}
         elif rec is not None:
             entry["traffic"] = rec
         per[name] = entry
@@ -282,15 +296,18 @@ def build_roofline(args, kernels, n_vis, n_isect, ms_per_view):
             "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
             "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
             "dominant_by": "total kernel time over the profiled step",
-            "valu": d.get("valu"),
+            "valu": d.get("valu"), "fp32_issue": d.get("fp32_issue"),
             "whole_view": {"bytes": b_view, "ms_per_view": ms_per_view, "achieved": gbs_view,
                            "frac": gbs_view / HBM_PEAK_GBS,
                            "note": "SURVEY 8d B_alg from the measured N_vis and I over wall time per view"},
             "kernels": {k: {kk: vv for kk, vv in v.items() if kk != "launches"} for k, v in per.items()},
-            "pmc_source": pmc_file,
-            "note": "VALU-issue-bound kernels (DESIGN.md 3.5): `frac` is against HBM as BASELINE asks, "
+            "pmc_source": pmc_file, "pmc_commit": pmc.get("_commit") if isinstance(pmc, dict) else None,
+            "note": "fp32-issue-bound kernels (DESIGN.md 3.5c): `frac` is against HBM as BASELINE asks, "
                     "`valu.frac` against the VALU issue peak (1024 SIMDs x 2.4 GHz, 2 cycles per plain "
-                    "wave64 instruction, DPP / permlane / transcendental weighted by measured cost)"}
+                    "wave64 instruction, DPP / permlane / transcendental weighted by measured cost), "
+                    "`fp32_issue.frac` adds the matrix pipe's busy cycles: fp32 MFMAs and fp32 VALU instructions "
+                    "share one issue budget per SIMD (tools/ubench_coexec.hip).  traffic / valu / fp32_issue come "
+                    "from the committed counter passes named in pmc_source, only the durations are measured live"}
 
 
 # ------------------------------------------------------------------------------------------------

@@ -3,7 +3,7 @@
 # Separate passes, --pmc only with --kernel-trace (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not
 # fit one pass; gpurun refuses --pmc combined with the trace domains).
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null

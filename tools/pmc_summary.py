@@ -5,7 +5,7 @@ roofline.traffic / roofline.valu).  HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 
 counts half of a wide coalesced read; MI355X_MICROARCH.md)."""
 import csv, glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 NAMES = {"blend2_fwd_kernel<32, true, true, true": "blend_fwd_pair_kernel<40>",
          "blend2_fwd_kernel<3,": "blend_fwd_kernel<3>", "blend2_fwd_kernel<8,": "blend_fwd_kernel<8>",
@@ -51,7 +51,14 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_pmc.csv"), "w") as f:
         f.write(f"\"{r[0]}\",{r[1]},{r[2]:.2f},{r[3]}\n")
 mean = {(r[0], r[1]): r[2] for r in rows}
 mix = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "isa_mix.py")]))
-out = {"_source": f"profiles/{tag}_pmc.csv (separate rocprofv3 --pmc passes over tools/kprobe.py: 1 M Gaussians, "
+try:
+    head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    dirty = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "gaussiangrasper_amd/csrc",
+                                          "include"], text=True).strip())
+except Exception:
+    head, dirty = "unknown", False
+out = {"_commit": head + (" + uncommitted kernel changes" if dirty else ""),
+       "_source": f"profiles/{tag}_pmc.csv (separate rocprofv3 --pmc passes over tools/kprobe.py: 1 M Gaussians, "
                   "1600x1200 bench view); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch; "
                   "valu_issue_weight from tools/isa_mix.py (static mix of the loop bodies)"}
 for name in sorted({r[0] for r in rows}):
@@ -61,7 +68,9 @@ for name in sorted({r[0] for r in rows}):
         rec["hbm_bytes"] = (2 * rec["fetch_kb"] + rec["write_kb"]) * 1024
     for ctr, key in (("SQ_INSTS_VALU", "insts_valu"), ("SQ_INSTS_SALU", "insts_salu"), ("SQ_INSTS_SMEM", "insts_smem"),
                      ("SQ_WAVE_CYCLES", "wave_cycles"), ("SQ_WAIT_ANY", "wait_any"), ("SQ_WAIT_INST_ANY", "wait_inst_any"),
-                     ("SQ_ACTIVE_INST_ANY", "active_inst_any"), ("VALUBusy", "valu_busy_pct"),
+                     ("SQ_ACTIVE_INST_ANY", "active_inst_any"), ("SQ_VALU_MFMA_BUSY_CYCLES", "mfma_busy_cycles"),
+                     ("SQ_INSTS_LDS", "insts_lds"), ("SQ_LDS_BANK_CONFLICT", "lds_bank_conflict"),
+                     ("VALUBusy", "valu_busy_pct"),
                      ("OccupancyPercent", "occupancy_pct"), ("TCC_EA0_ATOMIC_sum", "atomic_requests_64B"),
                      ("TCP_UTCL1_TRANSLATION_MISS_sum", "utcl1_misses")):
         if (name, ctr) in mean:

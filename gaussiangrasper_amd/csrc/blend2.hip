@@ -727,7 +727,13 @@ __global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_bwd_narrow_kernel(
 // fac / D slab [slot][pixel]: 65 floats per slot — a column access (32 slots, one pixel: the MFMA operand
 // layouts) and a row access both spread over the banks, and every address stays base + immediate (an XOR
 // swizzle at stride 64 costs one live address register per access: 134 spilled VGPRs)
-#define FIDX(slot, pix) ((slot) * 65 + (pix))
+// (16-slot builds, measured r03: at stride 66 the flushes' A operands — lane = (slot = lane & 15, pixel 4 t +
+//  (lane >> 4)) — sit in 32 distinct banks per half-wave instead of colliding pairwise (SQ_LDS_BANK_CONFLICT: 41 M
+//  cycles per launch of the pair backward at 65); the kernel's time does not move: 0.970 / 0.980 against 0.966 / 0.976 ms)
+#ifndef GG_S16_STRIDE
+#define GG_S16_STRIDE 65
+#endif
+#define FIDX(slot, pix) ((slot) * FS + (pix))
 
 // =============================================================================================
 // backward, wide (32-channel chunk): wave-autonomous, matrix pipe for D = <colour, v_out> AND for the colour
@@ -831,7 +837,8 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     using R = Red6<KB>;
     typedef WaveQueueT<QR ? BQ_CAP_QR : BQ_CAP> QUEUE;
     __shared__ QUEUE queues[GG_WPB_WIDE_BWD];
-    __shared__ float s_fac[GG_WPB_WIDE_BWD][NSLOT * 65];
+    constexpr int FS = S16 ? GG_S16_STRIDE : 65;   // slab row stride in floats (FIDX)
+    __shared__ float s_fac[GG_WPB_WIDE_BWD][NSLOT * FS];
     __shared__ int s_slote[GG_WPB_WIDE_BWD][DET ? B2_SLOTS : 1];
     __shared__ __attribute__((aligned(16))) float s_vt[GG_WPB_WIDE_BWD][EX ? 64 * 8 : 4];   // EX: V_OUT2[pixel][8]
 

@@ -141,12 +141,10 @@ __device__ __forceinline__ int stage_chunk(LIST &L, int lane, int e, bool valid,
                                            const float *__restrict__ colors, int C, int ch_off, int nch,
                                            float xlo, float xhi, float ylo, float yhi,
                                            const Seg2 *seg2 = nullptr,
-                                           const float4 *pre = nullptr /* the record, loaded by the caller */,
-                                           const float *pre2 = nullptr /* 8 colours of the second array, ditto */,
                                            float4 *qdst = nullptr /* quad list: next free record of this quadrant */,
                                            int qprev_cnt = 0 /* quad list: survivors of the previous chunk (still in L) */) {
-    const float4 ra = pre ? pre[0] : reinterpret_cast<const float4 *>(rec + g)[0];
-    const float4 rb = pre ? pre[1] : reinterpret_cast<const float4 *>(rec + g)[1];
+    const float4 ra = reinterpret_cast<const float4 *>(rec + g)[0];
+    const float4 rb = reinterpret_cast<const float4 *>(rec + g)[1];
     if (QWT) {
         // quad list, late form: the PREVIOUS chunk's survivors leave from the list (still intact: compacted, in list
         // order) behind this chunk's record request.  The vector memory counter is in order: stores issued in front
@@ -174,10 +172,7 @@ __device__ __forceinline__ int stage_chunk(LIST &L, int lane, int e, bool valid,
         float4 ra2 = ra;
         if (WIDE) {
             cc.x = __builtin_bit_cast(float, g);
-            if (seg2 && pre2) {
-                L.d[pos] = make_float4(pre2[0], pre2[1], pre2[2], pre2[3]);
-                L.e[pos] = make_float4(pre2[4], pre2[5], pre2[6], pre2[7]);
-            } else if (seg2) {   // the second array's colours ride in the record (d, e)
+            if (seg2) {   // the second array's colours ride in the record (d, e)
                 const float *c2 = seg2->colors + (size_t)g * seg2->C2;
                 const int n2 = seg2->nch2;
                 L.d[pos] = make_float4(c2[0], n2 > 1 ? c2[1] : 0.f, n2 > 2 ? c2[2] : 0.f, n2 > 3 ? c2[3] : 0.f);
@@ -224,15 +219,12 @@ __device__ __forceinline__ int stage_chunk(LIST &L, int lane, int e, bool valid,
 // =============================================================================================
 // EX: a second colour array of <= 8 channels (Seg2) is blended in the same walk as this 32-channel chunk
 // (gg_blend_fwd_pair: the plugin's feature | rgb+depth+normal forward in one walk instead of two)
-#ifndef GG_FWD_LEAN
-#define GG_FWD_LEAN 1
-#endif
 #ifndef GG_FWD_WAVES
 #define GG_FWD_WAVES 5
 #endif
 // QW: the wave persists the survivors of its quadrant cull (quad lists, blend_common.h) for the backward walk
 template <int CH, bool WIDE, bool FULL, bool EX = false, int FABL = 0, bool QW = false>
-__global__ __launch_bounds__(64 * GG_WPB_OTHER) __attribute__((amdgpu_waves_per_eu((GG_FWD_LEAN != 0 && WIDE && EX) ? GG_FWD_WAVES : 1)))
+__global__ __launch_bounds__(64 * GG_WPB_OTHER) __attribute__((amdgpu_waves_per_eu((WIDE && EX) ? GG_FWD_WAVES : 1)))
 void blend2_fwd_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
@@ -278,52 +270,16 @@ void blend2_fwd_kernel(
     const bool wch_ok = FULL || wch < nch;
 
     STAMP(0);
-    // The two dependent loads of the staging (list id, then the 32-byte record) run ahead of the walk: the id two
-    // chunks, the record one chunk (in-kernel stamps: staging, i.e. waiting for them, was 23-33 % of a forward
-    // wave's lifetime).  PIPE: only the wide builds have the registers for it (9 more).
-    // (measured: pair forward 0.490 -> 0.480 ms; the plain 32-channel build loses its fifth wave per SIMD to the 9
-    //  registers, 0.372 -> 0.394: EX only.  Requesting the second array's colour row of every list entry a chunk
-    //  ahead as well — 8 more registers, 3x the rows the survivors of the cull need — measured slower: 0.498.)
-    constexpr bool PIPE = WIDE && EX && (GG_FWD_LEAN == 0);
-    constexpr bool PIPE2 = false;
-    auto id_at = [&](int b) { return (b + lane < range.y) ? ids[b + lane] : 0; };
-    int g_n1 = PIPE ? id_at(range.x) : 0, g_n2 = PIPE ? id_at(range.x + 64) : 0;
-    float4 rec_n[2];
-    float c2_n[8];
-    auto load_c2 = [&](int g, float (&dst)[8]) {
-        const float *c2 = seg2.colors + (size_t)g * seg2.C2;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) dst[c] = c < seg2.nch2 ? c2[c] : 0.0f;
-    };
-    if (PIPE) {
-        rec_n[0] = reinterpret_cast<const float4 *>(rec + g_n1)[0];
-        rec_n[1] = reinterpret_cast<const float4 *>(rec + g_n1)[1];
-        if (PIPE2) load_c2(g_n1, c2_n);
-    }
+    // (Requesting the staging's two dependent loads — list id, then the 32-byte record — two / one chunks ahead of
+    //  the walk measured 0.490 -> 0.480 ms on the pair build in r02, but costs the 9 registers that the five-waves
+    //  build (96) does not have; the second array's colour rows a chunk ahead as well: slower, 0.498.  Removed in r03.)
     for (int base = range.x; base < range.y; base += 64) {
         if (__ballot(!done) == 0ull) break;
         const int e = base + lane;
-        int g_cur;
-        float4 rec_c[2];
-        float c2_c[8];
-        if (PIPE) {
-            g_cur = g_n1;
-            rec_c[0] = rec_n[0];
-            rec_c[1] = rec_n[1];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) c2_c[c] = PIPE2 ? c2_n[c] : 0.0f;
-            g_n1 = g_n2;                                  // ids of chunk + 1 (requested an iteration ago)
-            rec_n[0] = reinterpret_cast<const float4 *>(rec + g_n1)[0];
-            rec_n[1] = reinterpret_cast<const float4 *>(rec + g_n1)[1];
-            if (PIPE2) load_c2(g_n1, c2_n);
-            g_n2 = id_at(base + 128);
-        } else {
-            g_cur = e < range.y ? ids[e] : 0;
-        }
+        const int g_cur = e < range.y ? ids[e] : 0;
         if (QW) qn_prev += cnt_last;
         const int cnt = stage_chunk<CH, WIDE, false, LIST, QW>(L, lane, e, e < range.y, g_cur, rec, colors, C,
                                                            ch_off, nch, xlo, xhi, ylo, yhi, EX ? &seg2 : nullptr,
-                                                           PIPE ? rec_c : nullptr, PIPE2 ? c2_c : nullptr,
                                                            QW ? qseg + 2 * (size_t)qn_prev : nullptr, QW ? cnt_last : 0);
         if (QW) cnt_last = cnt;
         WALK_STAT(0, min(64, range.y - base));
@@ -334,10 +290,10 @@ void blend2_fwd_kernel(
         for (int k = 0; k < cnt; k += GRP) {
             if (k > 0 && __ballot(!done) == 0ull) break;
             WALK_STAT(1, min(GRP, cnt - k));
-            // LEANF (pair build, experiment -DGG_FWD_LEAN=1): the records of a group are not all requested up front
+            // LEANF (pair build): the records of a group are not all requested up front
             // (12 ds_read_b128 = 48 registers in flight) but two Gaussians at a time, and the list position is read
             // again where it is needed: a fifth wave per SIMD needs <= 96 registers.
-            constexpr bool LEANF = (GG_FWD_LEAN != 0) && WIDE && EX;
+            constexpr bool LEANF = WIDE && EX;
             float4 A[GRP], B[GRP], Cc[GRP], Cd[GRP];
 #pragma unroll
             for (int q = 0; q < GRP; ++q) {
@@ -779,11 +735,9 @@ struct Seg2B {
 // the second array's v_out tile (64 pixels x 8) sits in LDS, and its colour gradients are a second, small flush
 // (FAC[32 x 64] * V_OUT2[64 x 8] as v_mfma_f32_16x16x4_f32).  What the plugin route's feature | rgb+depth+normal
 // operator uses: one backward walk per view instead of two.
-// LEAN (measured, not launched: kept as the starting point for a 2-Gaussians-per-iteration walk): the build for
-// FOUR resident workgroups per CU instead of three.  Needs <= 128 VGPRs — the quadrant's cotangents are not held in
-// registers (64 of them) but re-read from the cache-resident image at every batch — and <= 40 960 B of LDS:
-// batches of 28 slots (slab 7 280 B).  It gets its four workgroups (40 896 B, 128 VGPRs), but the walk of four
-// Gaussians at a time alone wants more than 128 registers: 81 spilled, 1.50 ms against 1.00.
+// (A build for four workgroups per CU that re-read the cotangents per batch instead of holding them — 128 VGPRs,
+// batches of 28 slots — spilled 81 registers in the walk and ran 1.50 ms against 1.00: removed in r03; the 16-slot
+// build below took the fourth wave instead.)
 // S16 (experiment for FOUR waves per SIMD, -DGG_BWD_S16=1): batches of 16 slots on v_mfma_f32_16x16x4_f32 — D
 // accumulators 16 registers instead of 32, flush accumulators 8 instead of 16, slab 4 160 B instead of 8 320, the walk
 // re-reading its records.  k-step s of lane group q = lane >> 4 is channel 8 q + s, so a lane's B operand is still two
@@ -792,9 +746,8 @@ struct Seg2B {
 // QR (round 3): the walk streams the quadrant's survivors from the forward's quad list (blend_common.h) instead of
 // staging the tile list again: no list ids, no record gather, no cull, no queue compaction — the queue is 64
 // consecutive records of a contiguous array, the next 64 requested while the current ones are walked.
-template <bool FULL, int ABL = 0, int CHD = 32, bool DET = false, bool EX = false, bool LEAN = false, bool S16 = false,
-          bool QR = false>
-__global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_per_eu((LEAN || S16) ? 4 : 3))) void blend2_bwd_wide_kernel(
+template <bool FULL, int ABL = 0, int CHD = 32, bool DET = false, bool EX = false, bool S16 = false, bool QR = false>
+__global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_per_eu(S16 ? 4 : 3))) void blend2_bwd_wide_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
     const float *__restrict__ colors, const float *__restrict__ background,
@@ -804,36 +757,16 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     DetSlab det = DetSlab(), Seg2B seg2 = Seg2B(), QList ql = QList()) {
     static_assert(!QR || S16, "quad lists: the 16-slot builds");
     static_assert(!EX || (FULL && CHD == 32 && !DET), "the second array rides on the full 32-channel build");
-    static_assert(!LEAN || (!EX && !DET), "LEAN: plain builds only (so far)");
-    static_assert(!S16 || (FULL && CHD == 32 && !DET && !LEAN && ABL == 0), "S16: the full 32-channel build");
-    constexpr int NSLOT = S16 ? 16 : (LEAN ? 28 : B2_SLOTS);
+    static_assert(!S16 || (FULL && CHD == 32 && !DET && ABL == 0), "S16: the full 32-channel build");
+    constexpr int NSLOT = S16 ? 16 : B2_SLOTS;
     constexpr int CH = CHD;
     constexpr int KS = CHD / 2;     // k-steps of the D product; lane half h supplies channels [KS h, KS h + KS)
     constexpr int KG = 6;
     constexpr int KB = GRP * KG;
-#ifndef GG_WALK_REREAD
-#define GG_WALK_REREAD 0
-#endif
-    constexpr bool REREAD = GG_WALK_REREAD != 0 || S16;
-    // DEFER: the colour gradients of a batch are not added right after its flush.  The vector memory counter is in
-    // order, so every load issued behind the flush's 16-24 float-atomic instructions (the next chunk's records, the
-    // next batch's colour rows) waited for all of them (in-kernel stamps: staging 22-35 %, colour-row wait 12 % of a
-    // wave's lifetime).  The flush results are parked in the fac slab (dead by then) and their atomics are issued
-    // when the NEXT batch has its D product in registers, right in front of its walk — 25 k cycles without a single
-    // vector load, in which they retire.  The geometry sums go the same way (out of the butterfly into the dead
-    // x, y, opacity / conic fields of their slot's queue record, from there to the slab beside the colour rows):
-    // no atomic is issued during a walk, a flush or the staging, so no load ever waits behind one.
-    // Slab while parked: [0, 1024) colour rows (register r of lane l at 64 r + l), [1024, 1536) the second array's,
-    // [1536, 1728) the geometry sums (6 slot + k).
-    // MEASURED (r02, -DGG_BWD_DEFER=1 against 0 on the bench view): pair backward 1.064 against 1.051 ms, 32-channel
-    // 0.836 against 0.827 — no gain, and the stamps still show the same staging and colour-row waits with no atomic
-    // in flight at those points: the waits are plain load latency (several microseconds under this kernel's traffic),
-    // not the counter's ordering.  Kept behind the switch, off.
-#ifndef GG_BWD_DEFER
-#define GG_BWD_DEFER 0
-#endif
-    constexpr bool DEFER = (GG_BWD_DEFER != 0) && !DET && !LEAN && ABL == 0 && !S16;
-    __shared__ int s_hid[GG_WPB_WIDE_BWD][DEFER ? 32 : 1];   // DEFER: Gaussian of every slot of the parked batch
+    constexpr bool REREAD = S16;   // the 16-slot builds read a group's records again in the second pass (28 registers)
+    // (Deferring a batch's float atomics to the start of the next batch's walk, so that no load waits behind them in
+    //  the in-order memory counter, measured no gain in r02 — pair 1.064 against 1.051 ms: the waits are load latency,
+    //  not the counter's ordering — and was removed in r03.)
     using R = Red6<KB>;
     typedef WaveQueueT<QR ? BQ_CAP_QR : BQ_CAP> QUEUE;
     __shared__ QUEUE queues[GG_WPB_WIDE_BWD];
@@ -851,8 +784,6 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     QUEUE &Q = queues[wslot];
     float *fac_w = s_fac[wslot];
     int *slote = s_slote[wslot];
-    int *hid = s_hid[wslot];
-    unsigned h_mask = 0u;   // DEFER, wave-uniform: slots of the parked batch whose rows are still to be added
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int qx0 = tx * GG_BLOCK + (wave & 1) * 8, qy0 = ty * GG_BLOCK + (wave >> 1) * 8;
     const int j = qx0 + (lane & 7), i = qy0 + (lane >> 3);
@@ -880,9 +811,9 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     // prologue.  TILE: the 8 KB tile is loaded ONCE, 1 KB per instruction (one image row of the quadrant, float4
     // per lane), parked in the (still unused) fac slab — [pixel][32] with the 16-byte chunks of a row XOR-swizzled
     // by the pixel — and the three views are read from there.
-    const bool tile_lds = !LEAN && FULL && CH == 32 && (C % 4 == 0) && (ch_off % 4 == 0) &&
+    const bool tile_lds = FULL && CH == 32 && (C % 4 == 0) && (ch_off % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(v_out) & 15) == 0);   // wave-uniform
-    float voa_keep[2][(LEAN || S16) ? 1 : KS], vob_keep[(LEAN || S16) ? 1 : 32];
+    float voa_keep[2][S16 ? 1 : KS], vob_keep[S16 ? 1 : 32];
     float va16[S16 ? 4 : 1][S16 ? 8 : 1], vb16[S16 ? 16 : 1][S16 ? 2 : 1];   // S16: A operands of D, B operands of the flush
     float Bsum = 0.0f;
     // A wave starts with a chain of dependent loads: tile range -> final_idx -> (wave maximum) -> list ids -> records.
@@ -998,16 +929,16 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
 #pragma unroll
             for (int jq = 0; jq < KS / 4; ++jq) {
                 const float4 v = *reinterpret_cast<const float4 *>(fac_w + pm * 32 + 4 * (((KS / 4) * half + jq) ^ (pm & 7)));
-                voa_keep[c][(LEAN || S16) ? 0 : 4 * jq] = v.x;
-                voa_keep[c][(LEAN || S16) ? 0 : 4 * jq + 1] = v.y;
-                voa_keep[c][(LEAN || S16) ? 0 : 4 * jq + 2] = v.z;
-                voa_keep[c][(LEAN || S16) ? 0 : 4 * jq + 3] = v.w;
+                voa_keep[c][S16 ? 0 : 4 * jq] = v.x;
+                voa_keep[c][S16 ? 0 : 4 * jq + 1] = v.y;
+                voa_keep[c][S16 ? 0 : 4 * jq + 2] = v.z;
+                voa_keep[c][S16 ? 0 : 4 * jq + 3] = v.w;
             }
         }
 #pragma unroll
         for (int s = 0; s < 32; ++s) {  // B operands: pixel 2 s + half, channel wch
             const int pq = 2 * s + half;
-            vob_keep[(LEAN || S16) ? 0 : s] = fac_w[pq * 32 + 4 * ((wch >> 2) ^ (pq & 7)) + (wch & 3)];
+            vob_keep[S16 ? 0 : s] = fac_w[pq * 32 + 4 * ((wch >> 2) ^ (pq & 7)) + (wch & 3)];
         }
         __builtin_amdgcn_wave_barrier();   // the slab is free again
     } else {
@@ -1069,16 +1000,16 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
             dst[s] = ok ? vo[((size_t)pi * img_w + pj) * C + ch_off + wch] : 0.0f;
         }
     };
-    if (!LEAN && !S16 && !tile_lds) {
+    if (!S16 && !tile_lds) {
         float ta[2][KS], tb[32];
         load_voa(v_out, ta);
         load_vob(v_out, tb);
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int s = 0; s < KS; ++s) voa_keep[c][(LEAN || S16) ? 0 : s] = ta[c][s];
+            for (int s = 0; s < KS; ++s) voa_keep[c][S16 ? 0 : s] = ta[c][s];
 #pragma unroll
-        for (int s = 0; s < 32; ++s) vob_keep[(LEAN || S16) ? 0 : s] = tb[s];
+        for (int s = 0; s < 32; ++s) vob_keep[S16 ? 0 : s] = tb[s];
     }
     bool owner;
     const int myvar = R::var(lane, owner);
@@ -1088,65 +1019,11 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     if (my_k < 2) { my_base = v_xy + my_k; my_stride = gstride ? gstride : 2; }
     else if (my_k < 5) { my_base = v_conic + (my_k - 2); my_stride = gstride ? gstride : 3; }
     else { my_base = v_opacity; my_stride = gstride ? gstride : 1; }
-    // DEFER: float offset of my value's parking field from &Q.a[first slot of the group] (Q.b follows Q.a)
-    const int my_park = 4 * my_q + (my_k < 3 ? my_k : 4 * BQ_CAP + (my_k - 3));
     const int cs = cstride ? cstride : C;
     // vector loads of the colour half-rows need 16-byte aligned rows
     const bool vec = FULL && (C % 4 == 0) && (ch_off % 4 == 0) && ((reinterpret_cast<uintptr_t>(colors) & 15) == 0);
 
     int g_nxt = 0;   // ids of the next chunk (loaded one chunk ahead)
-    // DEFER: the parked batch's colour gradients: acc register r of lane l at slab[64 r + l], the second array's
-    // at slab[1024 + 64 (4 mb + r) + l]
-    auto issue_pending = [&]() {
-        if (h_mask == 0u) return;
-        // (lane-derived slot numbers, mask bits and table addresses are computed HERE: as loop invariants the
-        //  allocator spilled them and reloaded each one between two atomics, behind a wait for the first)
-        int half_l = half, k4_l = lane >> 4;
-        asm volatile("" : "+v"(half_l), "+v"(k4_l));
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int slot = (r & 3) + 8 * (r >> 2) + 4 * half_l;
-            const float v = fac_w[64 * r + lane];
-            const bool on = ((h_mask >> slot) & 1u) != 0u && wch_ok;
-            if (on && v != 0.0f) atomicAdd(v_colors + (size_t)hid[slot] * cs + ch_off + wch, v);
-            // (four at a time: scheduled freely, the 24 values and 24 addresses of all the atomics are live at once,
-            //  on top of the D accumulators)
-            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
-        if (EX) {
-            const int n16 = lane & 15, k4 = k4_l;
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                if (((h_mask >> (16 * mb)) & 0xffffu) == 0u) continue;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int slot = 16 * mb + 4 * k4 + r;
-                    const float v = fac_w[1024 + 64 * (4 * mb + r) + lane];
-                    const bool on = ((h_mask >> slot) & 1u) != 0u && n16 < seg2.nch2;
-                    if (on && v != 0.0f) atomicAdd(seg2.v_colors + (size_t)hid[slot] * seg2.cs2 + n16, v);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        {   // geometry sums: three instructions for the 32 x 6 values
-            int lane_l = lane;
-            asm volatile("" : "+v"(lane_l));
-            const int sxy = gstride ? gstride : 2, scn = gstride ? gstride : 3, sop = gstride ? gstride : 1;
-#pragma unroll
-            for (int v = 0; v < 3; ++v) {
-                const int i6 = 64 * v + lane_l, slot = i6 / 6, k = i6 - 6 * slot;
-                const float val = fac_w[1536 + i6];
-                const bool on = ((h_mask >> slot) & 1u) != 0u;
-                if (on && val != 0.0f) {
-                    const size_t gid = (size_t)hid[slot];
-                    float *dst = k < 2 ? v_xy + gid * sxy + k : (k < 5 ? v_conic + gid * scn + (k - 2) : v_opacity + gid * sop);
-                    atomicAdd(dst, val);
-                }
-            }
-        }
-        h_mask = 0u;
-        __builtin_amdgcn_wave_barrier();
-    };
     // one batch: queue entries [base, base + n), n = 28 or 32 (fewer only for the last batch of the walk, which
     // is followed by null records up to a multiple of GRP)
     auto run_batch = [&](const int base, const int n, const bool fetch_next) {
@@ -1224,16 +1101,10 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                 va1 = *reinterpret_cast<const float4 *>(vt + ((lane & 31) + 32) * 8 + 4 * half);
             }
             float voa[2][KS];
-            if (LEAN) {
-                const float *vo = v_out;
-                asm volatile("" : "+s"(vo));     // a fresh read per batch: not to be hoisted back into registers
-                load_voa(vo, voa);
-            } else {
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) voa[c][s] = voa_keep[c][(LEAN || S16) ? 0 : s];
-            }
+                for (int s = 0; s < KS; ++s) voa[c][s] = voa_keep[c][S16 ? 0 : s];
 #ifdef GG_STAMPS
             {   // make the colour rows arrive inside phase 2
                 float sink_ = 0.0f;
@@ -1261,7 +1132,6 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
             }
         }
         if (DET && lane < 32) slote[jl] = __builtin_bit_cast(int, Q.a[base + min(jl, n - 1)].w);
-        if (DEFER) issue_pending();   // the parked batch leaves the slab before D goes in
         // D[pixel m][slot n]: lane holds n = lane & 31, m = (r & 3) + 8 (r >> 2) + 4 half (+ 32 for d1)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1344,10 +1214,6 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                 if (owner && my_gid >= 0) det.p[(e * 4 + wave) * det.ks + det.goff + my_k] = mine;
                 continue;
             }
-            if (DEFER) {   // k-th sum of slot base + g + my_q: field k of the slot's (dead) record
-                if (owner) reinterpret_cast<float *>(&Q.a[base + g])[my_park] = mine;
-                continue;
-            }
             if (owner && my_gid >= 0 && mine != 0.0f) atomicAdd(my_base + (size_t)my_gid * my_stride, mine);
         }
         STAMP(4);
@@ -1390,14 +1256,8 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
         float vob[32];
-        if (LEAN) {
-            const float *vo = v_out;
-            asm volatile("" : "+s"(vo));
-            load_vob(vo, vob);
-        } else {
 #pragma unroll
-            for (int s = 0; s < 32; ++s) vob[s] = vob_keep[(LEAN || S16) ? 0 : s];
-        }
+        for (int s = 0; s < 32; ++s) vob[s] = vob_keep[S16 ? 0 : s];
         const int arow = NSLOT == 32 ? (lane & 31) : min(lane & 31, NSLOT - 1);   // rows >= NSLOT: never written out
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
@@ -1415,7 +1275,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         asm volatile("" : "+v"(half_f), "+v"(k4_f));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            if (DEFER || S16) continue;   // parked below, after the second array's flush has read fac
+            if (S16) continue;
             const int slot = (r & 3) + 8 * (r >> 2) + 4 * half_f;
             if (ABL >= 1) { KEEP(acc[r]); continue; }
             const bool on = ((slotmask >> slot) & 1u) != 0u && wch_ok;
@@ -1436,10 +1296,8 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
             const int n16 = lane & 15, k4 = k4_f;
             const float *vbp = vt + k4 * 8 + (n16 & 7);
             const float vmask = n16 < 8 ? 1.0f : 0.0f;   // lanes of channels 8..15 supply zeros
-            f32x4 a4h[2];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
-                a4h[mb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                 if (S16 && mb > 0) continue;
                 if (((slotmask >> (16 * mb)) & 0xffffu) == 0u) continue;
                 f32x4 a4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1448,10 +1306,8 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                 for (int s = 0; s < 16; ++s)
                     a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fac_w[FIDX(m, 4 * s + k4)], vbp[32 * s] * vmask, a4,
                                                               0, 0, 0);
-                a4h[mb] = a4;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (DEFER) continue;
                     const int slot = 16 * mb + 4 * k4 + r;
                     if (ABL >= 1) { KEEP(a4[r]); continue; }
                     const bool on = ((slotmask >> slot) & 1u) != 0u && n16 < seg2.nch2;
@@ -1461,25 +1317,6 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                     }
                 }
             }
-            if (DEFER) {   // every MFMA above has read its fac operands: the slab is free for the parked results
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) fac_w[1024 + 64 * (4 * mb + r) + lane] = a4h[mb][r];
-            }
-        }
-        if (DEFER) {
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) fac_w[64 * r + lane] = acc[r];
-            if (lane < 32) hid[lane] = __builtin_bit_cast(int, Q.b[base + lane].w);   // (slots >= n: never used)
-#pragma unroll
-            for (int v = 0; v < 3; ++v) {   // geometry sums: queue record fields -> slab[1536 + 6 slot + k]
-                const int i6 = 64 * v + lane, slot = i6 / 6, k = i6 - 6 * slot;
-                fac_w[1536 + i6] = reinterpret_cast<const float *>(&Q.a[base])[4 * slot + (k < 3 ? k : 4 * BQ_CAP + (k - 3))];
-            }
-            h_mask = slotmask;
         }
         __builtin_amdgcn_wave_barrier();
         STAMP(7);
@@ -1566,9 +1403,9 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         int done = 0;
         // 28 or 32 (a multiple of GRP): at most 27 stay behind, BQ_CAP; after the last chunk: what is left (<= 27)
         while (more ? (qn - done >= (S16 ? 16 : 28)) : (done == 0)) {
-            const int nb = !more ? qn : ((LEAN || S16) ? NSLOT : min(32, (qn - done) & ~3));
+            const int nb = !more ? qn : (S16 ? NSLOT : min(32, (qn - done) & ~3));
             // (not in the pair build: 8 more registers across its two flushes spill 30 more, 1.30 -> 1.33 ms)
-            const bool last = more && (!EX || DEFER) && (qn - done - nb < (S16 ? 16 : 28)) && (top - 64 > range.x);   // staging comes next
+            const bool last = more && !EX && (qn - done - nb < (S16 ? 16 : 28)) && (top - 64 > range.x);   // staging comes next
             run_batch(done, nb, last);
             have_p = last;
             done += nb;
@@ -1586,7 +1423,6 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         }
         STAMP(8);
     }
-    if (DEFER) issue_pending();   // the last batch's colour gradients
     STAMP_END();
 }
 
@@ -1684,7 +1520,7 @@ void gg_launch_blend2_bwd(int width, int C, int off, int n, int img_h, int img_w
         hipLaunchKernelGGL((blend2_bwd_narrow_kernel<8>), grid, block, 0, s, B2_BWDN_ARGS);
     else if (n == 32 && GG_BWD_S16 && C % 4 == 0 && off % 4 == 0 && (reinterpret_cast<uintptr_t>(colors) & 15) == 0 &&
              (reinterpret_cast<uintptr_t>(v_out) & 15) == 0)   // the 16-slot build (four waves per SIMD)
-        hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, 0, 32, false, false, false, GG_BWD_S16 != 0>), gridw, blockw, 0, s,
+        hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, 0, 32, false, false, GG_BWD_S16 != 0>), gridw, blockw, 0, s,
                            B2_BWDW_ARGS);
     else if (n == 32)
         hipLaunchKernelGGL((blend2_bwd_wide_kernel<true>), gridw, blockw, 0, s, B2_BWDW_ARGS);
@@ -1739,13 +1575,13 @@ void gg_launch_blend2_bwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
     if (GG_BWD_S16 && !ablated && C % 4 == 0 && (reinterpret_cast<uintptr_t>(colors) & 15) == 0 &&
         (reinterpret_cast<uintptr_t>(v_out) & 15) == 0) {   // the 16-slot build (four waves per SIMD)
         if (ql.recs) {   // ... streaming the forward's quad lists
-            hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, 0, 32, false, true, false, GG_BWD_S16 != 0, GG_BWD_S16 != 0>), grid,
+            hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, 0, 32, false, true, GG_BWD_S16 != 0, GG_BWD_S16 != 0>), grid,
                                block, 0, s, C, 0, 32, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background,
                                final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, gstride, cstride, DetSlab(),
                                seg2, ql);
             return;
         }
-        hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, 0, 32, false, true, false, GG_BWD_S16 != 0>), grid, block, 0, s, C,
+        hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, 0, 32, false, true, GG_BWD_S16 != 0>), grid, block, 0, s, C,
                            0, 32, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, final_Ts, final_idx,
                            v_out, v_xy, v_conic, v_colors, v_opacity, gstride, cstride, DetSlab(), seg2);
         return;

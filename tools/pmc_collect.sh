@@ -14,5 +14,5 @@ run fetch --pmc FETCH_SIZE
 run write --pmc WRITE_SIZE
 run occ --pmc VALUBusy OccupancyPercent MemUnitStalled
 run atom --pmc TCC_EA0_ATOMIC_sum TCP_UTCL1_TRANSLATION_MISS_sum
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $out/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-config5 > $out/stats.log 2>&1
 find $out -name "*.csv" | head -40

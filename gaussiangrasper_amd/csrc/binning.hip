@@ -6,7 +6,7 @@
 // produces the SAME lists with far less HBM traffic by splitting the key:
 //
 //   1. stable LSD radix sort of the N Gaussians by their 32 depth bits (4 byte-wide passes over
-//      N items; culled Gaussians get key 0xFFFFFFFF and sink to the end);
+//      N items; culled Gaussians get key 0xFFFFFFFF and sink to the end; the first pass forms the keys itself);
 //   2. exclusive scan of num_tiles_hit taken in that depth order (one launch, decoupled look-back);
 //   3. every Gaussian, in depth order, emits (tile id, Gaussian id) for the tiles of its bbox;
 //   4. stable LSD radix sort of the I pairs by tile id only (ceil(log2 T)/8 = 2 passes).
@@ -78,25 +78,23 @@ extern "C" int gg_count_intersects(int N, const int32_t *num_tiles_hit, int64_t 
 }
 
 // ---------------------------------------------------------------------------------------------
-// depth keys
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void depth_keys_kernel(int N, const float *__restrict__ depths,
-                                                         const int32_t *__restrict__ radii,
-                                                         uint32_t *__restrict__ keys,
-                                                         uint32_t *__restrict__ vals) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    keys[i] = (radii[i] > 0) ? __builtin_bit_cast(uint32_t, depths[i]) : 0xFFFFFFFFu;
-    vals[i] = (uint32_t)i;
-}
-
-// ---------------------------------------------------------------------------------------------
 // radix pass, step 1: per-block digit histogram, stored digit-major: G[d * nblocks + b]
 // ---------------------------------------------------------------------------------------------
+// First pass of the depth sort: keys and values are not read but formed — key = depth bits of a visible Gaussian
+// (radius > 0), 0xFFFFFFFF otherwise (culled ones sink to the end), value = its index (r03: this was a kernel of its
+// own, 9 us and 8 MB written + read back per view)
+struct DepthSrc {
+    const float *depths;      // nullptr: keys / values come from memory
+    const int32_t *radii;
+};
+__device__ __forceinline__ uint32_t depth_key(const DepthSrc d, int64_t idx) {
+    return (d.radii[idx] > 0) ? __builtin_bit_cast(uint32_t, d.depths[idx]) : 0xFFFFFFFFu;
+}
+
 template <int RS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(
     int64_t n, const int64_t *__restrict__ n_dev, const uint32_t *__restrict__ keys, int shift,
-    uint32_t mask, int nblocks, uint32_t *__restrict__ G) {
+    uint32_t mask, int nblocks, uint32_t *__restrict__ G, DepthSrc dsrc) {
     constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
     __shared__ uint32_t hist[256];
     n = dev_count(n, n_dev);
@@ -106,7 +104,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(
 #pragma unroll 4
     for (int it = 0; it < RS_ITEMS; ++it) {
         int64_t idx = base + (int64_t)it * RS_THREADS + threadIdx.x;
-        if (idx < n) atomicAdd(&hist[(keys[idx] >> shift) & mask], 1u);
+        if (idx < n) atomicAdd(&hist[((dsrc.depths ? depth_key(dsrc, idx) : keys[idx]) >> shift) & mask], 1u);
     }
     __syncthreads();
     G[(size_t)threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
@@ -148,7 +146,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     int64_t n, const int64_t *__restrict__ n_dev, const uint32_t *__restrict__ keys_in,
     const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, int shift, uint32_t mask, int nblocks,
-    const uint32_t *__restrict__ G, const uint32_t *__restrict__ totals) {
+    const uint32_t *__restrict__ G, const uint32_t *__restrict__ totals, DepthSrc dsrc) {
     constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
     n = dev_count(n, n_dev);
     __shared__ uint32_t whist[RS_WAVES][256];
@@ -180,8 +178,8 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     for (int it = 0; it < RS_ITEMS; ++it) {
         int64_t idx = wbase + (int64_t)it * GG_WAVE + lane;
         bool valid = idx < n;
-        key[it] = valid ? keys_in[idx] : 0u;
-        val[it] = valid ? vals_in[idx] : 0u;
+        key[it] = valid ? (dsrc.depths ? depth_key(dsrc, idx) : keys_in[idx]) : 0u;
+        val[it] = valid ? (dsrc.depths ? (uint32_t)idx : vals_in[idx]) : 0u;
     }
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
@@ -254,6 +252,9 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // exclusive scan of num_tiles_hit[order[r]]: ONE launch (decoupled look-back across workgroups, scan.h)
+// (r03: the same look-back moved INTO the emission kernel — 3 907 workgroups of 256 Gaussians instead of 489 of 2 048,
+//  no offsets array — measured 0.312 ms for the whole binning against 0.282: the chain of 3 907 published prefixes is
+//  longer than the launch and the 8 MB it saves; reverted)
 // ---------------------------------------------------------------------------------------------
 #define SC_THREADS 256
 #define SC_ITEMS 8
@@ -423,21 +424,22 @@ extern "C" size_t gg_bin_sort_workspace(int num_points, int64_t num_intersects) 
 }
 
 static void radix_pass(int64_t n, const int64_t *n_dev, const uint32_t *kin, const uint32_t *vin,
-                       uint32_t *kout, uint32_t *vout, int shift, uint32_t mask, BinWs &w, hipStream_t s) {
+                       uint32_t *kout, uint32_t *vout, int shift, uint32_t mask, BinWs &w, hipStream_t s,
+                       DepthSrc dsrc = DepthSrc{nullptr, nullptr}) {
     int nb = radix_nblocks(n);
     if (rs_items(n) == 16)
         hipLaunchKernelGGL(radix_hist_kernel<16>, dim3(nb), dim3(RS_THREADS), 0, s, n, n_dev, kin, shift,
-                           mask, nb, w.G);
+                           mask, nb, w.G, dsrc);
     else
         hipLaunchKernelGGL(radix_hist_kernel<4>, dim3(nb), dim3(RS_THREADS), 0, s, n, n_dev, kin, shift,
-                           mask, nb, w.G);
+                           mask, nb, w.G, dsrc);
     hipLaunchKernelGGL(radix_colscan_kernel, dim3(256), dim3(256), 0, s, nb, w.G, w.totals);
     if (rs_items(n) == 16)
         hipLaunchKernelGGL(radix_scatter_kernel<16>, dim3(nb), dim3(RS_THREADS), 0, s, n, n_dev, kin, vin,
-                           kout, vout, shift, mask, nb, w.G, w.totals);
+                           kout, vout, shift, mask, nb, w.G, w.totals, dsrc);
     else
         hipLaunchKernelGGL(radix_scatter_kernel<4>, dim3(nb), dim3(RS_THREADS), 0, s, n, n_dev, kin, vin,
-                           kout, vout, shift, mask, nb, w.G, w.totals);
+                           kout, vout, shift, mask, nb, w.G, w.totals, dsrc);
 }
 
 static int bin_sort_impl(int N, int64_t I, const int64_t *I_dev, const float *xys, const float *depths,
@@ -463,11 +465,10 @@ static int bin_sort_impl(int N, int64_t I, const int64_t *I_dev, const float *xy
     }
     gg_prof_begin(GG_K_BIN_SORT, s);
     // 1. depth order of the Gaussians
-    hipLaunchKernelGGL(depth_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, depths, radii,
-                       w.dkeyA, w.dvalA);
     uint32_t *ka = w.dkeyA, *kb = w.dkeyB, *va = w.dvalA, *vb = w.dvalB;
     for (int pass = 0; pass < 4; ++pass) {
-        radix_pass(N, nullptr, ka, va, kb, vb, 8 * pass, 0xFFu, w, s);
+        radix_pass(N, nullptr, ka, va, kb, vb, 8 * pass, 0xFFu, w, s,
+                   pass == 0 ? DepthSrc{depths, radii} : DepthSrc{nullptr, nullptr});
         uint32_t *t = ka; ka = kb; kb = t;
         t = va; va = vb; vb = t;
     }

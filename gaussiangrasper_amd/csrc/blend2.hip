@@ -323,7 +323,7 @@ void blend2_fwd_kernel(
                 const float dx = A[q].x - px, dy = A[q].y - py;
                 const float sigma = __builtin_fmaf(
                     0.5f, __builtin_fmaf(B[q].x * dx, dx, (B[q].z * dy) * dy), (B[q].y * dx) * dy);
-                alpha[q] = fminf(GG_ALPHA_MAX_FWD, A[q].z * gg_expf(-sigma));
+                alpha[q] = fminf(GG_ALPHA_MAX_FWD, A[q].z * gg_expf_walk(-sigma));
                 pass[q] = sigma >= 0.0f && !(alpha[q] < GG_ALPHA_MIN);
                 if (LEANF && q == 1) __builtin_amdgcn_sched_barrier(0);
             }
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_bwd_narrow_kernel(
                 dys[q] = dy;
                 const float sigma = __builtin_fmaf(
                     0.5f, __builtin_fmaf(B[q].x * dx, dx, (B[q].z * dy) * dy), (B[q].y * dx) * dy);
-                vis[q] = gg_expf(-sigma);
+                vis[q] = gg_expf_walk(-sigma);
                 alpha[q] = fminf(GG_ALPHA_MAX_BWD, A[q].z * vis[q]);
                 // .w = position inside the chunk; null pads have opacity 0 -> alpha 0 -> no pass
                 pass[q] = (__builtin_bit_cast(int, N8 ? A[q].w : Cc[q].w) < fin_rel) && sigma >= 0.0f &&
@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                 const float dx = A.x - px, dy = A.y - py;
                 const float sigma = __builtin_fmaf(
                     0.5f, __builtin_fmaf(B.x * dx, dx, (B.z * dy) * dy), (B.y * dx) * dy);
-                vis[q] = gg_expf(-sigma);
+                vis[q] = gg_expf_walk(-sigma);
                 alpha[q] = fminf(GG_ALPHA_MAX_BWD, A.z * vis[q]);
                 pass[q] = (pos < fin) && sigma >= 0.0f && !(alpha[q] < GG_ALPHA_MIN);
             }

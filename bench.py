@@ -81,6 +81,9 @@ def parse(argv=None):
     ap.add_argument("--no-config5", action="store_true",
                     help="skip the short BASELINE-config-5 (render-only) object of the default one-GPU line")
     ap.add_argument("--no-prof", action="store_true", help="skip the profiled step (no per-kernel times)")
+    ap.add_argument("--torch-profile", default=None, metavar="PATH",
+                    help="after the timed steps, one more step under torch.profiler (shapes recorded); the per-operator "
+                         "table goes to PATH — which torch operators launch what, beside the library's own kernels")
     ap.add_argument("--route", default="plugin", choices=("plugin", "shim"),
                     help="headline route: the nerfstudio plugin's fused operator (default) or the shim's "
                          "four separate rasterize calls; the other one is measured as well")
@@ -473,6 +476,15 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
     #           calls per view (they share the binning) — reported next to it.
     plugin_first = args.route == "plugin"
     elapsed, kernels, t_prof, grads = measure(fused=plugin_first, warmup=args.warmup)
+    if args.torch_profile and rank == 0:
+        from torch.profiler import ProfilerActivity, profile
+        fn = make_step(plugin_first)
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as tp:
+            one_step(fn)
+            sync()
+        with open(args.torch_profile, "w") as f:
+            f.write(tp.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=60,
+                                                                      max_name_column_width=60))
     if grads is not None:
         torch.save(grads, args.dump_grads)
     other = None

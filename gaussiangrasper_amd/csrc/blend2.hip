@@ -691,6 +691,29 @@ __global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_bwd_narrow_kernel(
 #endif
 #define FIDX(slot, pix) ((slot) * FS + (pix))
 
+// fp32 -> three bf16 pieces by truncation (x = hi + mid + lo exactly: 3 x 8 significand bits), two values per
+// register: 11 VALU instructions per pair
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split3(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
+    unsigned b0 = __builtin_bit_cast(unsigned, x0), b1 = __builtin_bit_cast(unsigned, x1);
+    hi = __builtin_amdgcn_perm(b1, b0, 0x07060302);
+    float r0 = x0 - __builtin_bit_cast(float, b0 & 0xffff0000u), r1 = x1 - __builtin_bit_cast(float, b1 & 0xffff0000u);
+    b0 = __builtin_bit_cast(unsigned, r0); b1 = __builtin_bit_cast(unsigned, r1);
+    mid = __builtin_amdgcn_perm(b1, b0, 0x07060302);
+    r0 = r0 - __builtin_bit_cast(float, b0 & 0xffff0000u); r1 = r1 - __builtin_bit_cast(float, b1 & 0xffff0000u);
+    b0 = __builtin_bit_cast(unsigned, r0); b1 = __builtin_bit_cast(unsigned, r1);
+    lo = __builtin_amdgcn_perm(b1, b0, 0x07060302);
+}
+#define BF8(a, b, c, d) __builtin_bit_cast(bf16x8, (u32x4){(a), (b), (c), (d)})
+#define FB(x) __builtin_bit_cast(unsigned, (x))
+#ifndef GG_BF16_PROBE
+#define GG_BF16_PROBE 0
+#endif
+#ifndef GG_S16_WAVES
+#define GG_S16_WAVES 4    // waves per SIMD the 16-slot backward is compiled for (128 registers)
+#endif
+
 // =============================================================================================
 // backward, wide (32-channel chunk): wave-autonomous, matrix pipe for D = <colour, v_out> AND for the colour
 // gradients; survivors queued to full batches of 32
@@ -746,8 +769,15 @@ struct Seg2B {
 // QR (round 3): the walk streams the quadrant's survivors from the forward's quad list (blend_common.h) instead of
 // staging the tile list again: no list ids, no record gather, no cull, no queue compaction — the queue is 64
 // consecutive records of a contiguous array, the next 64 requested while the current ones are walked.
-template <bool FULL, int ABL = 0, int CHD = 32, bool DET = false, bool EX = false, bool S16 = false, bool QR = false>
-__global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_per_eu(S16 ? 4 : 3))) void blend2_bwd_wide_kernel(
+// MG (round 3, the pair build with a 16-float gradient record per Gaussian — geometry 0..5 | second array 6..6 + C2 — on
+// a 64-byte boundary): the geometry sums of a batch are parked in LDS by the walk and leave together with the second
+// array's colour gradients, ONE atomic request per Gaussian and batch instead of three to four.  Float atomics execute
+// at the L2 at ~20 G 64-byte requests/s chip-wide whatever the lanes of an instruction cover (tools/ubench_atomics.hip),
+// and the pair backward ran at 17 G/s (TCC_EA0_ATOMIC 16.7 M per launch): per batch of 16 Gaussians 32 requests for the
+// feature rows, ~22 for the 7 floats at offset 24 of 52-byte rows, ~21 for the 6 geometry floats.
+template <bool FULL, int ABL = 0, int CHD = 32, bool DET = false, bool EX = false, bool S16 = false, bool QR = false,
+          bool MG = false>
+__global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_per_eu(S16 ? GG_S16_WAVES : 3))) void blend2_bwd_wide_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
     const float *__restrict__ colors, const float *__restrict__ background,
@@ -756,6 +786,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     float *__restrict__ v_colors, float *__restrict__ v_opacity, int gstride, int cstride,
     DetSlab det = DetSlab(), Seg2B seg2 = Seg2B(), QList ql = QList()) {
     static_assert(!QR || S16, "quad lists: the 16-slot builds");
+    static_assert(!MG || (S16 && EX), "merged record flush: the 16-slot pair build");
     static_assert(!EX || (FULL && CHD == 32 && !DET), "the second array rides on the full 32-channel build");
     static_assert(!S16 || (FULL && CHD == 32 && !DET && ABL == 0), "S16: the full 32-channel build");
     constexpr int NSLOT = S16 ? 16 : B2_SLOTS;
@@ -774,6 +805,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     __shared__ float s_fac[GG_WPB_WIDE_BWD][NSLOT * FS];
     __shared__ int s_slote[GG_WPB_WIDE_BWD][DET ? B2_SLOTS : 1];
     __shared__ __attribute__((aligned(16))) float s_vt[GG_WPB_WIDE_BWD][EX ? 64 * 8 : 4];   // EX: V_OUT2[pixel][8]
+    __shared__ float s_geo[GG_WPB_WIDE_BWD][MG ? 16 * 8 : 1];   // MG: the batch's geometry sums [slot][8]
 
     int wave;
     const int tile = blend_tile_wave<GG_WPB_WIDE_BWD>(blockIdx.x, threadIdx.x, ntiles, wave);
@@ -783,6 +815,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     float *vt = s_vt[wslot];
     QUEUE &Q = queues[wslot];
     float *fac_w = s_fac[wslot];
+    float *geo_w = s_geo[wslot];
     int *slote = s_slote[wslot];
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int qx0 = tx * GG_BLOCK + (wave & 1) * 8, qy0 = ty * GG_BLOCK + (wave >> 1) * 8;
@@ -1056,13 +1089,35 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                 }
             }
             f32x4 d[4];
+#if GG_BF16_PROBE
+            unsigned ch_[4], cm_[4], cl_[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                split3(cgid < 0 ? 0.0f : colb[2 * t], cgid < 0 ? 0.0f : colb[2 * t + 1], ch_[t], cm_[t], cl_[t]);
+            const bf16x8 Bh = BF8(ch_[0], ch_[1], ch_[2], ch_[3]), Bm = BF8(cm_[0], cm_[1], cm_[2], cm_[3]),
+                         Bl = BF8(cl_[0], cl_[1], cl_[2], cl_[3]);
+#endif
 #pragma unroll
             for (int blk = 0; blk < 4; ++blk) {
                 d[blk] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#if GG_BF16_PROBE
+                {   // TIMING PROBE: the instruction mix of a three-way bf16 split (operand values are not the split ones)
+                    const int bb = S16 ? blk : 0;
+                    const bf16x8 Ah = BF8(FB(va16[bb][0]), FB(va16[bb][S16 ? 1 : 0]), FB(va16[bb][S16 ? 2 : 0]), FB(va16[bb][S16 ? 3 : 0]));
+                    const bf16x8 Am = BF8(FB(va16[bb][S16 ? 4 : 0]), FB(va16[bb][S16 ? 5 : 0]), FB(va16[bb][S16 ? 6 : 0]), FB(va16[bb][S16 ? 7 : 0]));
+                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, d[blk], 0, 0, 0);
+                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bm, d[blk], 0, 0, 0);
+                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bh, d[blk], 0, 0, 0);
+                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bm, d[blk], 0, 0, 0);
+                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, d[blk], 0, 0, 0);
+                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bl, d[blk], 0, 0, 0);
+                }
+#else
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
                     d[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(va16[S16 ? blk : 0][S16 ? t : 0], cgid < 0 ? 0.0f : colb[t],
                                                                   d[blk], 0, 0, 0);
+#endif
                 if (EX) {
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
@@ -1214,6 +1269,10 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                 if (owner && my_gid >= 0) det.p[(e * 4 + wave) * det.ks + det.goff + my_k] = mine;
                 continue;
             }
+            if (MG) {   // parked: leaves with the second array's colour gradients in the flush
+                if (owner) geo_w[(g + my_q) * 8 + my_k] = mine;
+                continue;
+            }
             if (owner && my_gid >= 0 && mine != 0.0f) atomicAdd(my_base + (size_t)my_gid * my_stride, mine);
         }
         STAMP(4);
@@ -1229,16 +1288,45 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         // are not written
         slotmask = __builtin_amdgcn_readfirstlane(slotmask);
         if (ABL >= 2 || slotmask == 0u) return;
+#if GG_BF16_PROBE
+        unsigned fh[2][4], fm[2][4], fl[2][4];
+#endif
         if (S16) {   // FAC[16 slots x 64 pixels] * V_OUT[64 x 32 channels] as 2 x 16 v_mfma_f32_16x16x4_f32
             int sl = lane & 15, q4 = lane >> 4;
             asm volatile("" : "+v"(sl), "+v"(q4));
             f32x4 acc2[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+#if GG_BF16_PROBE
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    split3(fac_w[FIDX(sl, 32 * ks + 8 * q4 + 2 * t)], fac_w[FIDX(sl, 32 * ks + 8 * q4 + 2 * t + 1)],
+                           fh[ks][t], fm[ks][t], fl[ks][t]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 Fh = BF8(fh[ks][0], fh[ks][1], fh[ks][2], fh[ks][3]), Fm = BF8(fm[ks][0], fm[ks][1], fm[ks][2], fm[ks][3]),
+                             Fl = BF8(fl[ks][0], fl[ks][1], fl[ks][2], fl[ks][3]);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const int nn = S16 ? nb : 0, k8 = S16 ? 8 * ks : 0;
+                    const bf16x8 Vh = BF8(FB(vb16[k8][nn]), FB(vb16[k8 + (S16 ? 1 : 0)][nn]), FB(vb16[k8 + (S16 ? 2 : 0)][nn]), FB(vb16[k8 + (S16 ? 3 : 0)][nn]));
+                    const bf16x8 Vm = BF8(FB(vb16[k8 + (S16 ? 4 : 0)][nn]), FB(vb16[k8 + (S16 ? 5 : 0)][nn]), FB(vb16[k8 + (S16 ? 6 : 0)][nn]), FB(vb16[k8 + (S16 ? 7 : 0)][nn]));
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fh, Vh, acc2[nb], 0, 0, 0);
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fh, Vm, acc2[nb], 0, 0, 0);
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fm, Vh, acc2[nb], 0, 0, 0);
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fm, Vm, acc2[nb], 0, 0, 0);
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fl, Vh, acc2[nb], 0, 0, 0);
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fh, Vm, acc2[nb], 0, 0, 0);
+                }
+            }
+#else
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const float a = fac_w[FIDX(sl, 4 * t + q4)];
                 acc2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vb16[S16 ? t : 0][0], acc2[0], 0, 0, 0);
                 acc2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vb16[S16 ? t : 0][S16 ? 1 : 0], acc2[1], 0, 0, 0);
             }
+#endif
             // lane holds channel 16 nb + sl of slots 4 q4 + r
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
@@ -1302,10 +1390,46 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                 if (((slotmask >> (16 * mb)) & 0xffffu) == 0u) continue;
                 f32x4 a4 = {0.0f, 0.0f, 0.0f, 0.0f};
                 const int m = 16 * mb + n16;
+#if GG_BF16_PROBE
+                if (S16) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const bf16x8 Fh = BF8(fh[ks][0], fh[ks][1], fh[ks][2], fh[ks][3]), Fm = BF8(fm[ks][0], fm[ks][1], fm[ks][2], fm[ks][3]),
+                                     Fl = BF8(fl[ks][0], fl[ks][1], fl[ks][2], fl[ks][3]);
+                        const u32x4 w0 = *reinterpret_cast<const u32x4 *>(vt + 4 * lane + 256 * ks);       // (stand-ins for the
+                        const u32x4 w1 = *reinterpret_cast<const u32x4 *>(vt + 4 * (lane ^ 1) + 256 * ks);  //  pre-split pieces)
+                        const bf16x8 Vh = __builtin_bit_cast(bf16x8, w0), Vm = __builtin_bit_cast(bf16x8, w1);
+                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fh, Vh, a4, 0, 0, 0);
+                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fh, Vm, a4, 0, 0, 0);
+                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fm, Vh, a4, 0, 0, 0);
+                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fm, Vm, a4, 0, 0, 0);
+                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fl, Vh, a4, 0, 0, 0);
+                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fh, Vm, a4, 0, 0, 0);
+                    }
+                } else
+#endif
 #pragma unroll
                 for (int s = 0; s < 16; ++s)
                     a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fac_w[FIDX(m, 4 * s + k4)], vbp[32 * s] * vmask, a4,
                                                               0, 0, 0);
+                if (MG) {
+                    // record row of slot 4 k4 + r: lanes n16 < 8 carry channel n16 of the second array (column 6 + n16),
+                    // lanes 8..13 the geometry sum n16 - 8 (column n16 - 8): 14 floats of one 64-byte row per request
+                    const int col = n16 < 8 ? 6 + n16 : n16 - 8;
+                    const bool lane_on = n16 < 8 ? n16 < seg2.nch2 : n16 < 14;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int slot = 4 * k4 + r;
+                        const float gv = geo_w[slot * 8 + (n16 & 7)];
+                        const float val = n16 < 8 ? a4[r] : gv;
+                        const bool on = ((slotmask >> slot) & 1u) != 0u && lane_on;
+                        if (on && val != 0.0f) {
+                            const int sg = __builtin_bit_cast(int, Q.b[base + slot].w);
+                            atomicAdd(v_xy + (size_t)sg * 16 + col, val);
+                        }
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int slot = 16 * mb + 4 * k4 + r;
@@ -1431,6 +1555,9 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
 // =============================================================================================
 #ifndef GG_BWD_S16
 #define GG_BWD_S16 1
+#endif
+#ifndef GG_BWD_MERGE
+#define GG_BWD_MERGE 1   // 16-float records: geometry and second-array gradients in one atomic request per Gaussian (MG)
 #endif
 #define B2_FWD_ARGS C, off, n, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, \
                     out_img, final_Ts, final_idx, write_final
@@ -1581,9 +1708,18 @@ void gg_launch_blend2_bwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
                                seg2, ql);
             return;
         }
-        hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, 0, 32, false, true, GG_BWD_S16 != 0>), grid, block, 0, s, C,
-                           0, 32, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, final_Ts, final_idx,
-                           v_out, v_xy, v_conic, v_colors, v_opacity, gstride, cstride, DetSlab(), seg2);
+        // one 16-float record per Gaussian on a 64-byte boundary, geometry 0..5 | second array 6..: the merged flush
+        const bool merged = GG_BWD_MERGE && gstride == 16 && seg2.cs2 == 16 && v_colors2 == v_xy + 6 && v_conic == v_xy + 2 &&
+                            v_opacity == v_xy + 5 && (reinterpret_cast<uintptr_t>(v_xy) & 63) == 0;
+        if (merged)
+            hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, 0, 32, false, true, GG_BWD_S16 != 0, false, GG_BWD_S16 != 0>), grid,
+                               block, 0, s, C, 0, 32, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background,
+                               final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, gstride, cstride, DetSlab(),
+                               seg2);
+        else
+            hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, 0, 32, false, true, GG_BWD_S16 != 0>), grid, block, 0, s, C,
+                               0, 32, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, final_Ts, final_idx,
+                               v_out, v_xy, v_conic, v_colors, v_opacity, gstride, cstride, DetSlab(), seg2);
         return;
     }
 #ifdef GG_ABLATION

@@ -889,7 +889,10 @@ class RasterizeSegments(Function):
         small = [i for i in range(k) if cols[i].shape[1] <= 8]
         rider = min(small, key=lambda i: cols[i].shape[1]) if small else None
         gwidth = 6 + (cols[rider].shape[1] if rider is not None else 0)
-        gstride = gwidth    # (records padded to 16 floats = one 64-byte atomic request each: measured, no change)
+        wide = next((i for i in range(k) if cols[i].shape[1] >= 32), None)
+        # The pair walk: 16-float records on a 64-byte boundary — geometry sums and the rider's colour gradients of a
+        # Gaussian then leave the kernel as ONE atomic request (csrc/blend2.hip, MG); other walks: dense records
+        gstride = 16 if (rider is not None and wide is not None and not _DETERMINISTIC and gwidth <= 16) else gwidth
         rec_g = torch.empty(n, gstride, dtype=torch.float32, device=dev)
         v_xy, v_conic, v_opacity = rec_g[:, 0:2], rec_g[:, 2:5], rec_g[:, 5:6]
         order = ([rider] if rider is not None else []) + [i for i in range(k) if i != rider]
@@ -913,7 +916,6 @@ class RasterizeSegments(Function):
 
         # a >= 32-channel array carries the rider through its first backward walk (gg_blend_bwd_pair): one
         # walk computes alpha, T and the geometry gradients of both arrays
-        wide = next((i for i in range(k) if cols[i].shape[1] >= 32), None)
         if rider is not None and wide is not None and not _DETERMINISTIC:
             sink = ctx.sinks[wide]
             flags = 1

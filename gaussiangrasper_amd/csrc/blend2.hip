@@ -691,24 +691,40 @@ __global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_bwd_narrow_kernel(
 #endif
 #define FIDX(slot, pix) ((slot) * FS + (pix))
 
-// fp32 -> three bf16 pieces by truncation (x = hi + mid + lo exactly: 3 x 8 significand bits), two values per
-// register: 11 VALU instructions per pair
-typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+// ---- fp32 products on the fp16 matrix rate (the 16-slot backward's dense products, round 3) ----------------------
+// x s = hi + lo with hi = RNE_fp16(x s), lo = RNE_fp16(x s - hi): 2^-24 relative when both pieces are normal fp16 numbers,
+// i.e. for elements within 2^-12 of the largest one the scale s (a power of two, exact) was chosen for; below that the
+// absolute error stays <= 2^-40 of that largest element.  A[M x 32] * B[32 x N] is then four v_mfma_f32_16x16x32_f16
+// (lo lo, lo hi, hi lo, hi hi: 16 cycles each, fp32 accumulation) instead of eight v_mfma_f32_16x16x4_f32 (32 cycles
+// each): measured MORE accurate than the fp32 instruction against a double sum (tools/check_f16split.hip:
+// 4-5e-8 of sum|terms| against 8-9e-8) because the piece products are exact in fp32.  Six VALU instructions per
+// pair of values to split.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split3(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
-    unsigned b0 = __builtin_bit_cast(unsigned, x0), b1 = __builtin_bit_cast(unsigned, x1);
-    hi = __builtin_amdgcn_perm(b1, b0, 0x07060302);
-    float r0 = x0 - __builtin_bit_cast(float, b0 & 0xffff0000u), r1 = x1 - __builtin_bit_cast(float, b1 & 0xffff0000u);
-    b0 = __builtin_bit_cast(unsigned, r0); b1 = __builtin_bit_cast(unsigned, r1);
-    mid = __builtin_amdgcn_perm(b1, b0, 0x07060302);
-    r0 = r0 - __builtin_bit_cast(float, b0 & 0xffff0000u); r1 = r1 - __builtin_bit_cast(float, b1 & 0xffff0000u);
-    b0 = __builtin_bit_cast(unsigned, r0); b1 = __builtin_bit_cast(unsigned, r1);
-    lo = __builtin_amdgcn_perm(b1, b0, 0x07060302);
+__device__ __forceinline__ void split2h(float x0, float x1, unsigned &hi, unsigned &lo) {
+    const h16x2 h = __builtin_convertvector((f32x2){x0, x1}, h16x2);
+    const f32x2 back = __builtin_convertvector(h, f32x2);
+    const h16x2 l = __builtin_convertvector((f32x2){x0 - back[0], x1 - back[1]}, h16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
 }
-#define BF8(a, b, c, d) __builtin_bit_cast(bf16x8, (u32x4){(a), (b), (c), (d)})
-#define FB(x) __builtin_bit_cast(unsigned, (x))
-#ifndef GG_BF16_PROBE
-#define GG_BF16_PROBE 0
+// the power of two that brings |m| into [2^14, 2^15); at most 2^126 (m = 0 or tiny: the pieces are zeros whatever the
+// scale), 2^-114 for inf / nan (which stay inf / nan).  Branch-free: three instructions.
+__device__ __forceinline__ float pow2_scale(float m) {
+    const unsigned e = (__builtin_bit_cast(unsigned, m) >> 23) & 0xffu;
+    return __builtin_bit_cast(float, min(268u - e, 253u) << 23);
+}
+// 1 / s for a power of two s (exact)
+__device__ __forceinline__ float pow2_inv(float s) {
+    return __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(unsigned, s));
+}
+#define H8(a, b, c, d) __builtin_bit_cast(h16x8, (u32x4){(a), (b), (c), (d)})
+#define GG_FAC_SCALE 32768.0f          // fac = alpha T in [3.9e-7, 0.99]: x 2^15 before the split
+#define GG_FAC_UNSCALE (1.0f / 32768.0f)
+#ifndef GG_S16_F16
+#define GG_S16_F16 1    // 0: the 16-slot backward's products on v_mfma_f32_16x16x4_f32 (the build before)
 #endif
 #ifndef GG_S16_WAVES
 #define GG_S16_WAVES 4    // waves per SIMD the 16-slot backward is compiled for (128 registers)
@@ -848,6 +864,14 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                       ((reinterpret_cast<uintptr_t>(v_out) & 15) == 0);   // wave-uniform
     float voa_keep[2][S16 ? 1 : KS], vob_keep[S16 ? 1 : 32];
     float va16[S16 ? 4 : 1][S16 ? 8 : 1], vb16[S16 ? 16 : 1][S16 ? 2 : 1];   // S16: A operands of D, B operands of the flush
+    // F16: the same elements as two fp16 pieces each (packed pairs): D's A operands V_OUT[pixel 16 blk + (lane & 15)]
+    // [channel 8 (lane >> 4) + 0..7] x s_w, the flush's B operands V_OUT[pixel 32 ks + 8 (lane >> 4) + 0..7][channel
+    // 16 nb + (lane & 15)] x s_c.  s_w: one power of two for the quadrant's cotangents (all channels of both arrays),
+    // s_c: one per channel of this lane; the raw values above are dead after the prologue.
+    constexpr bool F16 = S16 && (GG_S16_F16 != 0);
+    unsigned vah[F16 ? 4 : 1][F16 ? 4 : 1], val[F16 ? 4 : 1][F16 ? 4 : 1];
+    unsigned vbh[F16 ? 2 : 1][F16 ? 2 : 1][F16 ? 4 : 1], vbl[F16 ? 2 : 1][F16 ? 2 : 1][F16 ? 4 : 1];
+    float sw = 1.0f, inv_sw = 1.0f, inv_scf[2] = {1.0f, 1.0f};
     float Bsum = 0.0f;
     // A wave starts with a chain of dependent loads: tile range -> final_idx -> (wave maximum) -> list ids -> records.
     // The ids of the first chunk are requested as soon as final_idx is there, i.e. BEFORE the cotangent tile is waited
@@ -924,7 +948,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
             }
 #pragma unroll
             for (int ss = 0; ss < 8; ++ss) {   // B operands of the flush: pixel 4 (8 hh + ss) + q4, channel 16 nb + sl
-                const int pl = 4 * ss + q4;
+                const int pl = F16 ? 8 * q4 + ss : 4 * ss + q4;   // (F16: pixel 32 hh + 8 q4 + ss — the K = 32 layout)
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
                     const int c = 16 * nb + sl;
@@ -989,6 +1013,21 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         ra_p = reinterpret_cast<const float4 *>(rec + g_first)[0];
         rb_p = reinterpret_cast<const float4 *>(rec + g_first)[1];
     }
+    // F16: s_w from the largest |cotangent| of the quadrant — every element of the first array's tile is in exactly one
+    // lane's va16, every element of the second array's in one lane's t8
+    float mloc = 0.0f;
+    if (F16) {
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) mloc = fmaxf(mloc, fabsf(va16[F16 ? blk : 0][F16 ? t : 0]));
+    }
+    auto tile_scale = [&]() {
+        for (int off = 32; off > 0; off >>= 1) mloc = fmaxf(mloc, __shfl_xor(mloc, off, 64));
+        sw = pow2_scale(mloc);
+        inv_sw = pow2_inv(sw);
+    };
+    if (F16 && !EX) tile_scale();
     if (EX) {
         float t8[8];
 #pragma unroll
@@ -1007,8 +1046,39 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
             t8[c] = (inside && c < seg2.nch2) ? t8[c] : 0.0f;
             if (c < seg2.nch2) Bsum = __builtin_fmaf(seg2.background[c], t8[c], Bsum);
         }
+        if (F16) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) mloc = fmaxf(mloc, fabsf(t8[c]));
+            tile_scale();
+#pragma unroll
+            for (int c = 0; c < 8; ++c) t8[c] *= sw;   // the LDS tile carries s_w: D's tail k-steps use it as it is, the
+        }                                               // second flush takes it out of its results
         reinterpret_cast<float4 *>(vt + lane * 8)[0] = make_float4(t8[0], t8[1], t8[2], t8[3]);
         reinterpret_cast<float4 *>(vt + lane * 8)[1] = make_float4(t8[4], t8[5], t8[6], t8[7]);
+    }
+    if (F16) {
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                split2h(va16[F16 ? blk : 0][F16 ? 2 * t : 0] * sw, va16[F16 ? blk : 0][F16 ? 2 * t + 1 : 0] * sw,
+                        vah[F16 ? blk : 0][F16 ? t : 0], val[F16 ? blk : 0][F16 ? t : 0]);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            float m = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) m = fmaxf(m, fabsf(vb16[F16 ? t : 0][F16 ? nb : 0]));
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            const float sc = pow2_scale(m);
+            inv_scf[nb] = pow2_inv(sc) * GG_FAC_UNSCALE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    split2h(vb16[F16 ? 8 * ks + 2 * t : 0][F16 ? nb : 0] * sc, vb16[F16 ? 8 * ks + 2 * t + 1 : 0][F16 ? nb : 0] * sc,
+                            vbh[F16 ? ks : 0][F16 ? nb : 0][F16 ? t : 0], vbl[F16 ? ks : 0][F16 ? nb : 0][F16 ? t : 0]);
+        }
     }
     W = T_final * Bsum;
     // D product, A operands: V_OUT[pixel (lane & 31) + 32 c][channel KS half + s];
@@ -1089,35 +1159,50 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                 }
             }
             f32x4 d[4];
-#if GG_BF16_PROBE
-            unsigned ch_[4], cm_[4], cl_[4];
+            if (F16) {
+                // s_g: the power of two for this slot's colour row (both arrays; the four lanes of a slot hold it all)
+                float m = 0.0f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                split3(cgid < 0 ? 0.0f : colb[2 * t], cgid < 0 ? 0.0f : colb[2 * t + 1], ch_[t], cm_[t], cl_[t]);
-            const bf16x8 Bh = BF8(ch_[0], ch_[1], ch_[2], ch_[3]), Bm = BF8(cm_[0], cm_[1], cm_[2], cm_[3]),
-                         Bl = BF8(cl_[0], cl_[1], cl_[2], cl_[3]);
-#endif
+                for (int t = 0; t < 8; ++t) m = fmaxf(m, fabsf(colb[t]));
+                m = fmaxf(m, fmaxf(fabsf(colb2[0]), fabsf(colb2[1])));
+                m = cgid < 0 ? 0.0f : m;
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                const float sg = cgid < 0 ? 0.0f : pow2_scale(m);   // (null slot: every operand 0)
+                const float unscale = pow2_inv(cgid < 0 ? 1.0f : sg) * inv_sw;
+                unsigned ch_[4], cl_[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) split2h(colb[2 * t] * sg, colb[2 * t + 1] * sg, ch_[t], cl_[t]);
+                const h16x8 Bh = H8(ch_[0], ch_[1], ch_[2], ch_[3]), Bl = H8(cl_[0], cl_[1], cl_[2], cl_[3]);
+                const float b2[2] = {colb2[0] * sg, colb2[1] * sg};   // (zeros without a second array)
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) {
+                    const int bb = F16 ? blk : 0;
+                    const h16x8 Ah = H8(vah[bb][0], vah[bb][F16 ? 1 : 0], vah[bb][F16 ? 2 : 0], vah[bb][F16 ? 3 : 0]);
+                    const h16x8 Al = H8(val[bb][0], val[bb][F16 ? 1 : 0], val[bb][F16 ? 2 : 0], val[bb][F16 ? 3 : 0]);
+                    d[blk] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bl, d[blk], 0, 0, 0);
+                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh, d[blk], 0, 0, 0);
+                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl, d[blk], 0, 0, 0);
+                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh, d[blk], 0, 0, 0);
+                    if (EX) {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)   // the second array's channels: fp32 k-steps on operands carrying s_w, s_g
+                            d[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(va2[blk][t], b2[t], d[blk], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) fac_w[FIDX(jl, 16 * blk + 4 * q4 + r)] = d[blk][r] * unscale;
+            } else {
 #pragma unroll
             for (int blk = 0; blk < 4; ++blk) {
                 d[blk] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#if GG_BF16_PROBE
-                {   // TIMING PROBE: the instruction mix of a three-way bf16 split (operand values are not the split ones)
-                    const int bb = S16 ? blk : 0;
-                    const bf16x8 Ah = BF8(FB(va16[bb][0]), FB(va16[bb][S16 ? 1 : 0]), FB(va16[bb][S16 ? 2 : 0]), FB(va16[bb][S16 ? 3 : 0]));
-                    const bf16x8 Am = BF8(FB(va16[bb][S16 ? 4 : 0]), FB(va16[bb][S16 ? 5 : 0]), FB(va16[bb][S16 ? 6 : 0]), FB(va16[bb][S16 ? 7 : 0]));
-                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, d[blk], 0, 0, 0);
-                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bm, d[blk], 0, 0, 0);
-                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bh, d[blk], 0, 0, 0);
-                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bm, d[blk], 0, 0, 0);
-                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, d[blk], 0, 0, 0);
-                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bl, d[blk], 0, 0, 0);
-                }
-#else
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
                     d[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(va16[S16 ? blk : 0][S16 ? t : 0], cgid < 0 ? 0.0f : colb[t],
                                                                   d[blk], 0, 0, 0);
-#endif
                 if (EX) {
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
@@ -1129,6 +1214,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
             for (int blk = 0; blk < 4; ++blk)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) fac_w[FIDX(jl, 16 * blk + 4 * q4 + r)] = d[blk][r];
+            }
         }
         f32x16 d0, d1;
 #pragma unroll
@@ -1288,45 +1374,42 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         // are not written
         slotmask = __builtin_amdgcn_readfirstlane(slotmask);
         if (ABL >= 2 || slotmask == 0u) return;
-#if GG_BF16_PROBE
-        unsigned fh[2][4], fm[2][4], fl[2][4];
-#endif
         if (S16) {   // FAC[16 slots x 64 pixels] * V_OUT[64 x 32 channels] as 2 x 16 v_mfma_f32_16x16x4_f32
             int sl = lane & 15, q4 = lane >> 4;
             asm volatile("" : "+v"(sl), "+v"(q4));
             f32x4 acc2[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
-#if GG_BF16_PROBE
+            if (F16) {   // A: FAC[slot sl][pixel 32 ks + 8 q4 + 0..7] x 2^15 in two pieces; 2 x 2 x 4 v_mfma_f32_16x16x32_f16
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+                for (int ks = 0; ks < 2; ++ks) {
+                    unsigned fh[4], fl[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    split3(fac_w[FIDX(sl, 32 * ks + 8 * q4 + 2 * t)], fac_w[FIDX(sl, 32 * ks + 8 * q4 + 2 * t + 1)],
-                           fh[ks][t], fm[ks][t], fl[ks][t]);
+                    for (int t = 0; t < 4; ++t)
+                        split2h(fac_w[FIDX(sl, 32 * ks + 8 * q4 + 2 * t)] * GG_FAC_SCALE,
+                                fac_w[FIDX(sl, 32 * ks + 8 * q4 + 2 * t + 1)] * GG_FAC_SCALE, fh[t], fl[t]);
+                    const h16x8 Fh = H8(fh[0], fh[1], fh[2], fh[3]), Fl = H8(fl[0], fl[1], fl[2], fl[3]);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 Fh = BF8(fh[ks][0], fh[ks][1], fh[ks][2], fh[ks][3]), Fm = BF8(fm[ks][0], fm[ks][1], fm[ks][2], fm[ks][3]),
-                             Fl = BF8(fl[ks][0], fl[ks][1], fl[ks][2], fl[ks][3]);
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    const int nn = S16 ? nb : 0, k8 = S16 ? 8 * ks : 0;
-                    const bf16x8 Vh = BF8(FB(vb16[k8][nn]), FB(vb16[k8 + (S16 ? 1 : 0)][nn]), FB(vb16[k8 + (S16 ? 2 : 0)][nn]), FB(vb16[k8 + (S16 ? 3 : 0)][nn]));
-                    const bf16x8 Vm = BF8(FB(vb16[k8 + (S16 ? 4 : 0)][nn]), FB(vb16[k8 + (S16 ? 5 : 0)][nn]), FB(vb16[k8 + (S16 ? 6 : 0)][nn]), FB(vb16[k8 + (S16 ? 7 : 0)][nn]));
-                    acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fh, Vh, acc2[nb], 0, 0, 0);
-                    acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fh, Vm, acc2[nb], 0, 0, 0);
-                    acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fm, Vh, acc2[nb], 0, 0, 0);
-                    acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fm, Vm, acc2[nb], 0, 0, 0);
-                    acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fl, Vh, acc2[nb], 0, 0, 0);
-                    acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fh, Vm, acc2[nb], 0, 0, 0);
+                    for (int nb = 0; nb < 2; ++nb) {
+                        const int kk = F16 ? ks : 0, nn = F16 ? nb : 0;
+                        const h16x8 Vh = H8(vbh[kk][nn][0], vbh[kk][nn][F16 ? 1 : 0], vbh[kk][nn][F16 ? 2 : 0], vbh[kk][nn][F16 ? 3 : 0]);
+                        const h16x8 Vl = H8(vbl[kk][nn][0], vbl[kk][nn][F16 ? 1 : 0], vbl[kk][nn][F16 ? 2 : 0], vbl[kk][nn][F16 ? 3 : 0]);
+                        acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Fl, Vl, acc2[nb], 0, 0, 0);
+                        acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Fl, Vh, acc2[nb], 0, 0, 0);
+                        acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Fh, Vl, acc2[nb], 0, 0, 0);
+                        acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Fh, Vh, acc2[nb], 0, 0, 0);
+                    }
                 }
-            }
-#else
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc2[nb][r] *= inv_scf[nb];
+            } else {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const float a = fac_w[FIDX(sl, 4 * t + q4)];
                 acc2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vb16[S16 ? t : 0][0], acc2[0], 0, 0, 0);
                 acc2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vb16[S16 ? t : 0][S16 ? 1 : 0], acc2[1], 0, 0, 0);
             }
-#endif
+            }
             // lane holds channel 16 nb + sl of slots 4 q4 + r
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
@@ -1390,24 +1473,6 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                 if (((slotmask >> (16 * mb)) & 0xffffu) == 0u) continue;
                 f32x4 a4 = {0.0f, 0.0f, 0.0f, 0.0f};
                 const int m = 16 * mb + n16;
-#if GG_BF16_PROBE
-                if (S16) {
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const bf16x8 Fh = BF8(fh[ks][0], fh[ks][1], fh[ks][2], fh[ks][3]), Fm = BF8(fm[ks][0], fm[ks][1], fm[ks][2], fm[ks][3]),
-                                     Fl = BF8(fl[ks][0], fl[ks][1], fl[ks][2], fl[ks][3]);
-                        const u32x4 w0 = *reinterpret_cast<const u32x4 *>(vt + 4 * lane + 256 * ks);       // (stand-ins for the
-                        const u32x4 w1 = *reinterpret_cast<const u32x4 *>(vt + 4 * (lane ^ 1) + 256 * ks);  //  pre-split pieces)
-                        const bf16x8 Vh = __builtin_bit_cast(bf16x8, w0), Vm = __builtin_bit_cast(bf16x8, w1);
-                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fh, Vh, a4, 0, 0, 0);
-                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fh, Vm, a4, 0, 0, 0);
-                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fm, Vh, a4, 0, 0, 0);
-                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fm, Vm, a4, 0, 0, 0);
-                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fl, Vh, a4, 0, 0, 0);
-                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fh, Vm, a4, 0, 0, 0);
-                    }
-                } else
-#endif
 #pragma unroll
                 for (int s = 0; s < 16; ++s)
                     a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fac_w[FIDX(m, 4 * s + k4)], vbp[32 * s] * vmask, a4,
@@ -1421,7 +1486,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                     for (int r = 0; r < 4; ++r) {
                         const int slot = 4 * k4 + r;
                         const float gv = geo_w[slot * 8 + (n16 & 7)];
-                        const float val = n16 < 8 ? a4[r] : gv;
+                        const float val = n16 < 8 ? (F16 ? a4[r] * inv_sw : a4[r]) : gv;
                         const bool on = ((slotmask >> slot) & 1u) != 0u && lane_on;
                         if (on && val != 0.0f) {
                             const int sg = __builtin_bit_cast(int, Q.b[base + slot].w);
@@ -1437,7 +1502,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                     const bool on = ((slotmask >> slot) & 1u) != 0u && n16 < seg2.nch2;
                     if (on && a4[r] != 0.0f) {
                         const int sg = __builtin_bit_cast(int, Q.b[base + slot].w);
-                        atomicAdd(seg2.v_colors + (size_t)sg * seg2.cs2 + n16, a4[r]);
+                        atomicAdd(seg2.v_colors + (size_t)sg * seg2.cs2 + n16, F16 ? a4[r] * inv_sw : a4[r]);
                     }
                 }
             }

@@ -723,6 +723,12 @@ __device__ __forceinline__ float pow2_inv(float s) {
 #define H8(a, b, c, d) __builtin_bit_cast(h16x8, (u32x4){(a), (b), (c), (d)})
 #define GG_FAC_SCALE 32768.0f          // fac = alpha T in [3.9e-7, 0.99]: x 2^15 before the split
 #define GG_FAC_UNSCALE (1.0f / 32768.0f)
+#ifndef GG_F16_SWAPMAX
+#define GG_F16_SWAPMAX 1   // the slot's row maximum across its four lanes: v_permlane16/32_swap (0: ds_bpermute; measured +2 %)
+#endif
+#ifndef GG_F16_NLL
+#define GG_F16_NLL 0       // 1: without the lo x lo piece products (2^-24 each; measured -1.5 % of the kernel: not taken)
+#endif
 #ifndef GG_S16_F16
 #define GG_S16_F16 1    // 0: the 16-slot backward's products on v_mfma_f32_16x16x4_f32 (the build before)
 #endif
@@ -1166,8 +1172,17 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                 for (int t = 0; t < 8; ++t) m = fmaxf(m, fabsf(colb[t]));
                 m = fmaxf(m, fmaxf(fabsf(colb2[0]), fabsf(colb2[1])));
                 m = cgid < 0 ? 0.0f : m;
+#if GG_F16_SWAPMAX
+                {
+                    auto r16 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+                    m = fmaxf(__builtin_bit_cast(float, (unsigned)r16[0]), __builtin_bit_cast(float, (unsigned)r16[1]));
+                    auto r32 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+                    m = fmaxf(__builtin_bit_cast(float, (unsigned)r32[0]), __builtin_bit_cast(float, (unsigned)r32[1]));
+                }
+#else
                 m = fmaxf(m, __shfl_xor(m, 16, 64));
                 m = fmaxf(m, __shfl_xor(m, 32, 64));
+#endif
                 const float sg = cgid < 0 ? 0.0f : pow2_scale(m);   // (null slot: every operand 0)
                 const float unscale = pow2_inv(cgid < 0 ? 1.0f : sg) * inv_sw;
                 unsigned ch_[4], cl_[4];
@@ -1181,7 +1196,9 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                     const h16x8 Ah = H8(vah[bb][0], vah[bb][F16 ? 1 : 0], vah[bb][F16 ? 2 : 0], vah[bb][F16 ? 3 : 0]);
                     const h16x8 Al = H8(val[bb][0], val[bb][F16 ? 1 : 0], val[bb][F16 ? 2 : 0], val[bb][F16 ? 3 : 0]);
                     d[blk] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#if !GG_F16_NLL
                     d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bl, d[blk], 0, 0, 0);
+#endif
                     d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh, d[blk], 0, 0, 0);
                     d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl, d[blk], 0, 0, 0);
                     d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh, d[blk], 0, 0, 0);
@@ -1392,7 +1409,9 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                         const int kk = F16 ? ks : 0, nn = F16 ? nb : 0;
                         const h16x8 Vh = H8(vbh[kk][nn][0], vbh[kk][nn][F16 ? 1 : 0], vbh[kk][nn][F16 ? 2 : 0], vbh[kk][nn][F16 ? 3 : 0]);
                         const h16x8 Vl = H8(vbl[kk][nn][0], vbl[kk][nn][F16 ? 1 : 0], vbl[kk][nn][F16 ? 2 : 0], vbl[kk][nn][F16 ? 3 : 0]);
+#if !GG_F16_NLL
                         acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Fl, Vl, acc2[nb], 0, 0, 0);
+#endif
                         acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Fl, Vh, acc2[nb], 0, 0, 0);
                         acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Fh, Vl, acc2[nb], 0, 0, 0);
                         acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Fh, Vh, acc2[nb], 0, 0, 0);

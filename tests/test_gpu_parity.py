@@ -1145,6 +1145,56 @@ def test_split_segment_returns_channel_slices_and_takes_separate_cotangents(orac
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("spread", ["channels 1e-4..1e4", "pixels 1e-3..1", "colour rows 1e-3..1e3", "all tiny 1e-20",
+                                    "all huge 1e15"])
+def test_pair_backward_fp16_piece_products_over_a_wide_dynamic_range(oracle, spread):
+    """The 16-slot pair backward forms D = <colour, v_out> and the colour gradients from fp16 two-piece operands scaled
+    by powers of two (csrc/blend2.hip: one scale per quadrant of cotangents, one per Gaussian's colour row, one per
+    cotangent channel).  Cotangents / colours whose magnitudes are spread over several decades — across channels,
+    across the pixels of a quadrant, across Gaussians — and whole arrays far from 1 must stay within the blend
+    tolerance of the oracle, channel by channel (a channel 1e8 times smaller than another is held to ITS scale)."""
+    n, h, w, c, c2 = 5000, 64, 80, 32, 7
+    xys, depths, radii, conics, nth, colors, opac, bg = _blend_inputs(oracle, n, h, w, c + c2, seed=77)
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal((h, w, c + c2)).astype(np.float32)
+    if spread.startswith("channels"):
+        v *= (10.0 ** rng.uniform(-4, 4, (1, 1, c + c2))).astype(np.float32)
+    elif spread.startswith("pixels"):
+        v *= (10.0 ** rng.uniform(-3, 0, (h, w, 1))).astype(np.float32)
+    elif spread.startswith("colour rows"):
+        colors = colors * (10.0 ** rng.uniform(-3, 3, (n, 1))).astype(np.float32)
+    elif spread.startswith("all tiny"):
+        v *= np.float32(1e-20)
+    else:
+        v *= np.float32(1e15)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    segs = [(colors[:, :c], bg[:c]), (colors[:, c:], bg[c:])]
+    ref = None
+    for (col, b), vv in zip(segs, (v[..., :c], v[..., c:])):
+        out, saved = oracle.rasterize_fwd(xys, depths, radii, conics, nth, col, opac, h, w, b)
+        bb = saved["bins"]
+        g = oracle.blend_bwd(bb["gaussian_ids_sorted"], bb["tile_bins"], xys, conics, col, opac, h, w, b,
+                             saved["final_Ts"], saved["final_idx"], np.ascontiguousarray(vv))
+        ref = [g[0].astype(np.float64), g[1].astype(np.float64), [g[2]], g[3].astype(np.float64)] if ref is None \
+            else [ref[0] + g[0], ref[1] + g[1], ref[2] + [g[2]], ref[3] + g[3]]
+    xt, ct, ot = t(xys).requires_grad_(True), t(conics).requires_grad_(True), t(opac).requires_grad_(True)
+    cts = [t(col).requires_grad_(True) for col, _ in segs]
+    P.clear_bin_cache()
+    imgs = P.rasterize_segments(xt, t(depths), t(radii), ct, t(nth), ot, h, w,
+                                [(cts[i], t(segs[i][1])) for i in range(2)])
+    torch.autograd.backward(imgs, [t(v[..., :c]), t(v[..., c:])])
+    tag = spread.split()[0] + " " + spread.split()[1]
+    assert_close(_np(xt.grad), ref[0], f"f16 range[{tag}].v_xy", rtol=5e-5, atol_frac=1e-6)
+    assert_close(_np(ct.grad), ref[1], f"f16 range[{tag}].v_conic", rtol=5e-5, atol_frac=1e-6)
+    assert_close(_np(ot.grad), ref[3].reshape(_np(ot.grad).shape), f"f16 range[{tag}].v_opacity", rtol=5e-5, atol_frac=1e-6)
+    for i in range(2):
+        got = _np(cts[i].grad)
+        for ch in range(got.shape[1]):      # every channel against its own scale
+            assert_close(got[:, ch], ref[2][i][:, ch], f"f16 range[{tag}].v_colors[{i}][:, {ch}]", rtol=5e-5,
+                         atol_frac=1e-6)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("c,c2", [(32, 1), (32, 8), (35, 4), (64, 7), (33, 2)])
 def test_pair_kernels_channel_counts(oracle, c, c2):
     """gg_blend_fwd_pair / gg_blend_bwd_pair for 1..8 rider channels and first arrays of 32, 33, 35 and 64 channels

@@ -247,9 +247,14 @@ def load_pmc():
         return {}, None
 
 
-# cycles one fp32 MFMA holds the matrix pipe (to turn busy cycles into an instruction count): the forward kernels use
-# v_mfma_f32_32x32x2_f32 (64), the 16-slot backward kernels v_mfma_f32_16x16x4_f32 (32)
-MFMA_CYCLES_F32 = {"blend_fwd_pair_kernel<40>": 64.0, "blend_fwd_kernel<32>": 64.0}
+# cycles one MFMA holds the matrix pipe (to turn busy cycles into an instruction count): the forward kernels use
+# v_mfma_f32_32x32x2_f32 (64); the 16-slot backward kernels v_mfma_f32_16x16x32_f16 (16) for D and the colour flush
+# and, in the pair build, v_mfma_f32_16x16x4_f32 (32) for the second array: 32 x 16 + 24 x 32 cycles per batch of 56
+MFMA_CYCLES_F32 = {"blend_fwd_pair_kernel<40>": 64.0, "blend_fwd_kernel<32>": 64.0,
+                   "blend_bwd_pair_kernel<40>": 1280.0 / 56.0, "blend_bwd_kernel<32>": 16.0}
+# float atomics execute at the L2: ~20.4 G 64-byte requests/s chip-wide whatever the lanes of an instruction cover
+# (tools/ubench_atomics.hip, profiles/r03_ubench_atomics.txt)
+ATOMIC_REQUESTS_PEAK = 20.4e9
 
 
 def build_roofline(args, kernels, n_vis, n_isect, ms_per_view):
@@ -284,6 +289,12 @@ def build_roofline(args, kernels, n_vis, n_isect, ms_per_view):
                     valu_only = max(weighted - 2.0 * n_mfma, 0.0)
                     entry["fp32_issue"] = {"valu_cycles": valu_only, "mfma_busy_cycles": mf, "peak_cycles": peak,
                                            "frac": (valu_only + mf) / peak}
+                if rec.get("valu_busy_pct") is not None:
+                    entry["valu_busy_pct"] = rec["valu_busy_pct"]      # (the profiled launch's VALUBusy)
+            if rec.get("atomic_requests_64B"):
+                rate = rec["atomic_requests_64B"] / (k["avg_ms"] * 1e-3)
+                entry["atomics"] = {"requests_64B": rec["atomic_requests_64B"], "achieved": rate,
+                                    "peak": ATOMIC_REQUESTS_PEAK, "unit": "requests/s", "frac": rate / ATOMIC_REQUESTS_PEAK}
         elif rec is not None:
             entry["traffic"] = rec
         per[name] = entry
@@ -299,18 +310,21 @@ def build_roofline(args, kernels, n_vis, n_isect, ms_per_view):
             "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
             "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
             "dominant_by": "total kernel time over the profiled step",
-            "valu": d.get("valu"), "fp32_issue": d.get("fp32_issue"),
+            "valu": d.get("valu"), "fp32_issue": d.get("fp32_issue"), "atomics": d.get("atomics"),
+            "valu_busy_pct": d.get("valu_busy_pct"),
             "whole_view": {"bytes": b_view, "ms_per_view": ms_per_view, "achieved": gbs_view,
                            "frac": gbs_view / HBM_PEAK_GBS,
                            "note": "SURVEY 8d B_alg from the measured N_vis and I over wall time per view"},
             "kernels": {k: {kk: vv for kk, vv in v.items() if kk != "launches"} for k, v in per.items()},
             "pmc_source": pmc_file, "pmc_commit": pmc.get("_commit") if isinstance(pmc, dict) else None,
-            "note": "fp32-issue-bound kernels (DESIGN.md 3.5c): `frac` is against HBM as BASELINE asks, "
+            "note": "issue-bound kernels (DESIGN.md 3.5c/3.5d): `frac` is against HBM as BASELINE asks, "
                     "`valu.frac` against the VALU issue peak (1024 SIMDs x 2.4 GHz, 2 cycles per plain "
                     "wave64 instruction, DPP / permlane / transcendental weighted by measured cost), "
-                    "`fp32_issue.frac` adds the matrix pipe's busy cycles: fp32 MFMAs and fp32 VALU instructions "
-                    "share one issue budget per SIMD (tools/ubench_coexec.hip).  traffic / valu / fp32_issue come "
-                    "from the committed counter passes named in pmc_source, only the durations are measured live"}
+                    "`fp32_issue.frac` adds the matrix pipe's busy cycles (MFMAs and VALU instructions share one "
+                    "issue budget per SIMD, tools/ubench_coexec.hip), `valu_busy_pct` is the profiler's VALUBusy, "
+                    "`atomics.frac` the float-atomic request rate against the chip's ~20.4 G requests/s "
+                    "(tools/ubench_atomics.hip).  traffic / valu / fp32_issue / atomics come from the committed "
+                    "counter passes named in pmc_source, only the durations are measured live"}
 
 
 # ------------------------------------------------------------------------------------------------

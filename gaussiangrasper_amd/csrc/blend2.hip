@@ -691,36 +691,7 @@ __global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_bwd_narrow_kernel(
 #endif
 #define FIDX(slot, pix) ((slot) * FS + (pix))
 
-// ---- fp32 products on the fp16 matrix rate (the 16-slot backward's dense products, round 3) ----------------------
-// x s = hi + lo with hi = RNE_fp16(x s), lo = RNE_fp16(x s - hi): 2^-24 relative when both pieces are normal fp16 numbers,
-// i.e. for elements within 2^-12 of the largest one the scale s (a power of two, exact) was chosen for; below that the
-// absolute error stays <= 2^-40 of that largest element.  A[M x 32] * B[32 x N] is then four v_mfma_f32_16x16x32_f16
-// (lo lo, lo hi, hi lo, hi hi: 16 cycles each, fp32 accumulation) instead of eight v_mfma_f32_16x16x4_f32 (32 cycles
-// each): measured MORE accurate than the fp32 instruction against a double sum (tools/check_f16split.hip:
-// 4-5e-8 of sum|terms| against 8-9e-8) because the piece products are exact in fp32.  Six VALU instructions per
-// pair of values to split.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split2h(float x0, float x1, unsigned &hi, unsigned &lo) {
-    const h16x2 h = __builtin_convertvector((f32x2){x0, x1}, h16x2);
-    const f32x2 back = __builtin_convertvector(h, f32x2);
-    const h16x2 l = __builtin_convertvector((f32x2){x0 - back[0], x1 - back[1]}, h16x2);
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, l);
-}
-// the power of two that brings |m| into [2^14, 2^15); at most 2^126 (m = 0 or tiny: the pieces are zeros whatever the
-// scale), 2^-114 for inf / nan (which stay inf / nan).  Branch-free: three instructions.
-__device__ __forceinline__ float pow2_scale(float m) {
-    const unsigned e = (__builtin_bit_cast(unsigned, m) >> 23) & 0xffu;
-    return __builtin_bit_cast(float, min(268u - e, 253u) << 23);
-}
-// 1 / s for a power of two s (exact)
-__device__ __forceinline__ float pow2_inv(float s) {
-    return __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(unsigned, s));
-}
-#define H8(a, b, c, d) __builtin_bit_cast(h16x8, (u32x4){(a), (b), (c), (d)})
+// (split2h / pow2_scale / pow2_inv / H8: gg_common.h, "fp32 products on the fp16 matrix rate")
 #define GG_FAC_SCALE 32768.0f          // fac = alpha T in [3.9e-7, 0.99]: x 2^15 before the split
 #define GG_FAC_UNSCALE (1.0f / 32768.0f)
 #ifndef GG_F16_SWAPMAX

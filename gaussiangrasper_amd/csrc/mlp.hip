@@ -31,6 +31,7 @@
 #include "gg_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MLP_HID 128
 #define MLP_SLICE_NB 8                       // 32-row output blocks per W2 slice (8 x 64 x 64 x 4 B = 128 KB)
@@ -326,6 +327,316 @@ __global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(long P, int out_dim, 
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast forward (round 3): both layers as fp32-grade products of fp16 two-piece operands on
+// v_mfma_f32_16x16x32_f16 (gg_common.h: four 16-cycle MFMAs per 16 x 16 x 32 block where the fp32 instruction takes
+// eight of 32 cycles) — a quarter of the matrix cycles of the kernels above, at the same or better accuracy against
+// a double-precision sum (tools/check_f16split.hip), but NOT the oracle's summation order: results agree with
+// oracle/gg_oracle.c:mlp_fwd to ~1e-6 of the largest output instead of bit for bit (gg_mlp_fwd stays the exact-order
+// call).  The reference's side is cuBLAS behind nn.Linear — no summation order to match there.
+//
+//   * gg_mlp_pack (once per weight set): every row of W1 and W2 gets a power-of-two scale (row maximum into
+//     [2^14, 2^15)) and is written as (hi, lo) fp16 pieces in the A-operand order of the MFMA — per (16-row tile,
+//     k-step of 32, piece) 64 lanes x 16 bytes, lane = (row % 16) + 16 (k-block) — so that staging a 128-row
+//     slice into LDS is a 64 KB copy and every A operand one conflict-free ds_read_b128.  W2's k order is the order
+//     layer 1's accumulators hold the hidden units in (below); 1 / scale per row goes beside them.
+//   * transposed chain as above: H^T = W1 X^T, Y^T = W2 H^T, N = 16 pixels per MFMA.  Lane (p = lane % 16,
+//     q = lane / 16) loads x[pixel p][32 ks + 8 q .. + 7] (two float4), scales by the pixel's power of two (row
+//     maximum over the lane's values and the three other q lanes: two permlane swaps) and splits: the B operand of
+//     layer 1.  Layer 1's accumulators — lane (p, q) holds hidden units 16 t + 4 q + r of pixel p — become layer 2's
+//     B operand WITHOUT moving: k-step ks of layer 2 contracts the hidden units of tiles 2 ks and 2 ks + 1, slot j of
+//     k-block q is hidden unit 16 (2 ks + j / 4) + 4 q + j % 4 (mlpf_hidden_of); W2 is packed in that order.
+//     Bias, un-scaling and ReLU are one multiply, one fma and one max per hidden value; the pixel's second scale
+//     comes from the ReLU outputs the same way as the first.
+//   * persistent workgroups of 8 waves (two per SIMD), 256 pixels per iteration, 32 per wave as two 16-pixel blocks
+//     (each A operand read feeds 8 MFMAs); two tiles x two blocks = four independent accumulator chains.  The five
+//     weight slices of an iteration (W1, four of W2 at out = 512) go through a two-deep ring of 64 KB LDS buffers:
+//     the next slice is requested from L2 into registers before a slice's MFMAs and written to the other buffer
+//     after them — one barrier per slice.
+// ---------------------------------------------------------------------------------------------
+#define MLPF_THREADS 512
+#define MLPF_SLICE_Q 4096                        // uint4 per 64 KB slice: 8 tiles x 4 k-steps x 2 pieces x 64 lanes
+__host__ __device__ __forceinline__ int mlpf_hidden_of(int ks, int q, int j) { return 16 * (2 * ks + (j >> 2)) + 4 * q + (j & 3); }
+
+// one wave per weight row: rows [0, 128) are W1's, [128, 128 + out) W2's
+template <int IN>
+__global__ __launch_bounds__(64) void mlpf_pack_kernel(int out_dim, const float *__restrict__ w1,
+                                                       const float *__restrict__ w2, uint4 *__restrict__ packed,
+                                                       float *__restrict__ inv_s) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const bool first = row < MLP_HID;
+    const int K = first ? IN : MLP_HID, KS = K / 32;
+    const float *src = first ? w1 + (size_t)row * IN : w2 + (size_t)(row - MLP_HID) * MLP_HID;
+    float m = 0.0f;
+    for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(src[k]));
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    const float sc = pow2_scale(m);
+    if (lane == 0) inv_s[row] = pow2_inv(sc);
+    // lane = (ks, q): 8 values of this row
+    const int ks = lane >> 2, q = lane & 3;
+    if (ks >= KS) return;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[first ? 32 * ks + 8 * q + j : mlpf_hidden_of(ks, q, j)] * sc;
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) split2h(v[2 * t], v[2 * t + 1], hi[t], lo[t]);
+    const int r2 = first ? row : row - MLP_HID;
+    const int slice = r2 >> 7, tile = (r2 & 127) >> 4, l16 = r2 & 15;
+    // W1's slice has KS1 k-steps per tile, W2's four
+    uint4 *base = packed + (first ? (size_t)0 : (size_t)8 * (IN / 32) * 2 * 64 + (size_t)slice * MLPF_SLICE_Q);
+    uint4 *dst = base + ((size_t)(tile * KS + ks) * 2) * 64 + 16 * q + l16;
+    dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    dst[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
+__device__ __forceinline__ float mlpf_max_over_q(float m) {   // maximum over the four lanes p, p + 16, p + 32, p + 48
+    auto r16 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+    m = fmaxf(__builtin_bit_cast(float, (unsigned)r16[0]), __builtin_bit_cast(float, (unsigned)r16[1]));
+    auto r32 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)r32[0]), __builtin_bit_cast(float, (unsigned)r32[1]));
+}
+
+template <int IN>
+__global__ __launch_bounds__(MLPF_THREADS) void mlp_fwd_f16_kernel(long P, int out_dim, const float *__restrict__ x,
+                                                                   const uint4 *__restrict__ packed,
+                                                                   const float *__restrict__ inv_s,
+                                                                   const float *__restrict__ b1,
+                                                                   const float *__restrict__ b2, float *__restrict__ y) {
+    constexpr int KS1 = IN / 32;
+    constexpr int W1_Q = 8 * KS1 * 2 * 64;                      // uint4 of the W1 slice
+    constexpr int PF = MLPF_SLICE_Q / MLPF_THREADS;             // uint4 a thread carries of a slice in flight (8)
+    extern __shared__ uint4 ldsq[];
+    uint4 *buf0 = ldsq, *buf1 = ldsq + MLPF_SLICE_Q;
+    float *tab = reinterpret_cast<float *>(ldsq + 2 * MLPF_SLICE_Q);
+    float *b1s = tab, *i1s = tab + MLP_HID, *b2s = tab + 2 * MLP_HID, *i2s = b2s + out_dim;
+    const int lane = threadIdx.x & 63, l16 = lane & 15, q4 = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nsl = (out_dim + 127) >> 7;                       // slices of W2
+    const uint4 *w2p = packed + W1_Q;
+    for (int i = threadIdx.x; i < MLP_HID; i += MLPF_THREADS) { b1s[i] = b1[i]; i1s[i] = inv_s[i]; }
+    for (int i = threadIdx.x; i < out_dim; i += MLPF_THREADS) { b2s[i] = b2[i]; i2s[i] = inv_s[MLP_HID + i]; }
+    for (int i = threadIdx.x; i < W1_Q; i += MLPF_THREADS) buf0[i] = packed[i];
+    __syncthreads();
+    int g = 0;   // stages done: the current stage's weights are in buffer g & 1
+    uint4 pf[PF];
+    // request a slice (W2's slice sl, or W1 for sl < 0) into registers / put it into the buffer the NEXT stage reads
+    auto request = [&](int sl) {
+        const uint4 *src = sl < 0 ? packed : w2p + (size_t)sl * MLPF_SLICE_Q;
+        const int n = sl < 0 ? W1_Q : min(MLPF_SLICE_Q, (out_dim - 128 * sl) / 16 * 4 * 2 * 64);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int i = threadIdx.x + u * MLPF_THREADS;
+            pf[u] = i < n ? src[i] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto deliver = [&]() {
+        uint4 *dst = (g & 1) ? buf0 : buf1;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) dst[threadIdx.x + u * MLPF_THREADS] = pf[u];
+        __syncthreads();
+        ++g;
+    };
+    const long nblocks = (P + 255) / 256;
+    for (long blkid = blockIdx.x; blkid < nblocks; blkid += gridDim.x) {   // (every wave runs every barrier)
+        long pix[2];
+        bool ok[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            pix[b] = blkid * 256 + wave * 32 + 16 * b + l16;
+            ok[b] = pix[b] < P;
+        }
+        request(0);
+        // ---------------- x: scale per pixel, two fp16 pieces ---------------------------------------
+        unsigned xh[2][KS1][4], xl[2][KS1][4];
+        float inv_sx[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float xv[KS1][8];
+            const float *xp = x + (size_t)(ok[b] ? pix[b] : 0) * IN + 8 * q4;
+            float m = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const float4 v0 = *reinterpret_cast<const float4 *>(xp + 32 * ks), v1 = *reinterpret_cast<const float4 *>(xp + 32 * ks + 4);
+                const float t[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    xv[ks][j] = ok[b] ? t[j] : 0.0f;
+                    m = fmaxf(m, fabsf(xv[ks][j]));
+                }
+            }
+            const float sx = pow2_scale(mlpf_max_over_q(m));
+            inv_sx[b] = pow2_inv(sx);
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) split2h(xv[ks][2 * t] * sx, xv[ks][2 * t + 1] * sx, xh[b][ks][t], xl[b][ks][t]);
+        }
+        // ---------------- layer 1: H^T = relu(W1 X^T + b1) -------------------------------------------
+        float h[2][32];
+        {
+            const uint4 *wb = (g & 1) ? buf1 : buf0;
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp) {
+                f32x4 acc[2][2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[u][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const uint4 ah = wb[(((2 * tp + u) * KS1 + ks) * 2) * 64 + lane], al = wb[(((2 * tp + u) * KS1 + ks) * 2 + 1) * 64 + lane];
+                        const h16x8 Ah = H8(ah.x, ah.y, ah.z, ah.w), Al = H8(al.x, al.y, al.z, al.w);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            const h16x8 Bh = H8(xh[b][ks][0], xh[b][ks][1], xh[b][ks][2], xh[b][ks][3]);
+                            const h16x8 Bl = H8(xl[b][ks][0], xl[b][ks][1], xl[b][ks][2], xl[b][ks][3]);
+                            acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bl, acc[u][b], 0, 0, 0);
+                            acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh, acc[u][b], 0, 0, 0);
+                            acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl, acc[u][b], 0, 0, 0);
+                            acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh, acc[u][b], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int m0 = 16 * (2 * tp + u) + 4 * q4;       // hidden units m0 .. m0 + 3
+                    const float4 bi = *reinterpret_cast<const float4 *>(b1s + m0), iv = *reinterpret_cast<const float4 *>(i1s + m0);
+                    const float bb[4] = {bi.x, bi.y, bi.z, bi.w}, ii[4] = {iv.x, iv.y, iv.z, iv.w};
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            h[b][4 * (2 * tp + u) + r] = fmaxf(__builtin_fmaf(acc[u][b][r], ii[r] * inv_sx[b], bb[r]), 0.0f);
+                }
+            }
+        }
+        deliver();
+        // ---------------- hidden: second scale per pixel, two fp16 pieces ----------------------------
+        unsigned hh[2][4][4], hl[2][4][4];
+        float inv_sh[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float m = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) m = fmaxf(m, h[b][i]);
+            const float sh = pow2_scale(mlpf_max_over_q(m));
+            inv_sh[b] = pow2_inv(sh);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    split2h(h[b][8 * ks + 2 * t] * sh, h[b][8 * ks + 2 * t + 1] * sh, hh[b][ks][t], hl[b][ks][t]);
+        }
+        // ---------------- layer 2, slice by slice ------------------------------------------------------
+        for (int sl = 0; sl < nsl; ++sl) {
+            request(sl + 1 < nsl ? sl + 1 : -1);       // (after the last slice: W1 for the next iteration)
+            const uint4 *wb = (g & 1) ? buf1 : buf0;
+            const int nt = min(8, (out_dim - 128 * sl) >> 4);
+            for (int tp = 0; 2 * tp < nt; ++tp) {
+                f32x4 acc[2][2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[u][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int tile = min(2 * tp + u, nt - 1);
+                        const uint4 ah = wb[((tile * 4 + ks) * 2) * 64 + lane], al = wb[((tile * 4 + ks) * 2 + 1) * 64 + lane];
+                        const h16x8 Ah = H8(ah.x, ah.y, ah.z, ah.w), Al = H8(al.x, al.y, al.z, al.w);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            const h16x8 Bh = H8(hh[b][ks][0], hh[b][ks][1], hh[b][ks][2], hh[b][ks][3]);
+                            const h16x8 Bl = H8(hl[b][ks][0], hl[b][ks][1], hl[b][ks][2], hl[b][ks][3]);
+                            acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bl, acc[u][b], 0, 0, 0);
+                            acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh, acc[u][b], 0, 0, 0);
+                            acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl, acc[u][b], 0, 0, 0);
+                            acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh, acc[u][b], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (2 * tp + u >= nt) break;
+                    const int m0 = 128 * sl + 16 * (2 * tp + u) + 4 * q4;   // outputs m0 .. m0 + 3
+                    const float4 bi = *reinterpret_cast<const float4 *>(b2s + m0), iv = *reinterpret_cast<const float4 *>(i2s + m0);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        if (!ok[b]) continue;
+                        float4 o;
+                        o.x = __builtin_fmaf(acc[u][b][0], iv.x * inv_sh[b], bi.x);
+                        o.y = __builtin_fmaf(acc[u][b][1], iv.y * inv_sh[b], bi.y);
+                        o.z = __builtin_fmaf(acc[u][b][2], iv.z * inv_sh[b], bi.z);
+                        o.w = __builtin_fmaf(acc[u][b][3], iv.w * inv_sh[b], bi.w);
+                        *reinterpret_cast<float4 *>(y + (size_t)pix[b] * out_dim + m0) = o;
+                    }
+                }
+            }
+            deliver();
+        }
+    }
+}
+
+extern "C" size_t gg_mlp_fwd_fast_workspace(int in_dim, int hidden_dim, int out_dim) {
+    if (hidden_dim != MLP_HID || in_dim <= 0 || in_dim % 32 || out_dim <= 0 || out_dim % 16) return 0;
+    const size_t nsl = ((size_t)out_dim + 127) / 128;
+    return sizeof(uint4) * ((size_t)8 * (in_dim / 32) * 2 * 64 + nsl * MLPF_SLICE_Q) + sizeof(float) * (size_t)(MLP_HID + out_dim);
+}
+
+extern "C" int gg_mlp_fwd_fast(int64_t num_rows, int in_dim, int hidden_dim, int out_dim, const float *x,
+                               const float *w1, const float *b1, const float *w2, const float *b2, float *y,
+                               void *ws, size_t ws_bytes, gg_stream_t stream) {
+    GG_REQUIRE(num_rows >= 0, "num_rows < 0");
+    GG_REQUIRE(hidden_dim == MLP_HID, "hidden_dim must be 128 (the reference's fea_up)");
+    GG_REQUIRE(in_dim == 32 || in_dim == 64 || in_dim == 128, "in_dim must be 32, 64 or 128 (gg_mlp_fwd takes 8 and 16)");
+    GG_REQUIRE(out_dim > 0 && out_dim % 16 == 0 && out_dim <= 4096, "out_dim must be a multiple of 16, at most 4096");
+    if (num_rows == 0) return GG_OK;
+    GG_REQUIRE(x && w1 && b1 && w2 && b2 && y, "null pointer");
+    GG_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "x and y must be 16-byte aligned");
+    if (ws == nullptr || ws_bytes < gg_mlp_fwd_fast_workspace(in_dim, hidden_dim, out_dim) || ((uintptr_t)ws & 15)) {
+        gg_set_error("gg_mlp_fwd_fast: workspace of gg_mlp_fwd_fast_workspace() bytes, 16-byte aligned, expected");
+        return GG_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nsl = ((size_t)out_dim + 127) / 128;
+    uint4 *packed = reinterpret_cast<uint4 *>(ws);
+    float *inv_s = reinterpret_cast<float *>(packed + (size_t)8 * (in_dim / 32) * 2 * 64 + nsl * MLPF_SLICE_Q);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const long nblocks = (num_rows + 255) / 256;
+    const int grid = (int)(nblocks < cus ? nblocks : cus);
+    const size_t lds_bytes = sizeof(uint4) * 2 * MLPF_SLICE_Q + sizeof(float) * (size_t)(2 * MLP_HID + 2 * out_dim);
+    hipError_t e = hipSuccess;
+#define MLPF_LAUNCH(IN_)                                                                                              \
+    do {                                                                                                             \
+        hipLaunchKernelGGL((mlpf_pack_kernel<IN_>), dim3(MLP_HID + out_dim), dim3(64), 0, s, out_dim, w1, w2, packed, \
+                           inv_s);                                                                                   \
+        e = hipFuncSetAttribute((const void *)mlp_fwd_f16_kernel<IN_>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                (int)lds_bytes);                                                                     \
+        if (e == hipSuccess)                                                                                         \
+            hipLaunchKernelGGL((mlp_fwd_f16_kernel<IN_>), dim3(grid), dim3(MLPF_THREADS), lds_bytes, s,              \
+                               (long)num_rows, out_dim, x, packed, inv_s, b1, b2, y);                                \
+    } while (0)
+    gg_prof_begin(GG_K_MLP_FWD, s);
+    if (in_dim == 32) MLPF_LAUNCH(32);
+    else if (in_dim == 64) MLPF_LAUNCH(64);
+    else MLPF_LAUNCH(128);
+    gg_prof_end(GG_K_MLP_FWD, s);
+    if (e != hipSuccess) {
+        gg_set_error("gg_mlp_fwd_fast: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
+        return GG_ERR_LAUNCH;
+    }
+    GG_CHECK_LAUNCH();
+    return GG_OK;
 }
 
 extern "C" int gg_mlp_fwd(int64_t num_rows, int in_dim, int hidden_dim, int out_dim, const float *x,

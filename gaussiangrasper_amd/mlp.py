@@ -25,6 +25,9 @@ HIDDEN = 128
 SUPPORTED_IN = (8, 16, 32, 64, 128)     # fused forward kernels (W1 in registers; 128: W1 in LDS, W2 slices streamed)
 SUPPORTED_IN_BWD = (8, 16, 32, 64, 128)
 NATIVE_BWD_MAX_ROWS = 1 << 16
+FAST_IN = (32, 64, 128)     # gg_mlp_fwd_fast: fp16 two-piece operands on the 16x-rate matrix instruction (fp32-grade)
+# True: always the exact-order kernels (bit-identical to oracle.mlp_fwd's summation order; 4x the matrix cycles)
+EXACT_ORDER = False
 
 
 class _MLPForward(Function):
@@ -39,7 +42,14 @@ class _MLPForward(Function):
             raise ValueError(f"x has {x.shape[-1]} features, the first layer takes {in_dim}")
         x2 = _f32(x).reshape(-1, in_dim)
         w1c, b1c, w2c, b2c = _f32(w1), _f32(b1), _f32(w2), _f32(b2)
-        if in_dim in SUPPORTED_IN and out_dim % 32 == 0:
+        if in_dim in FAST_IN and out_dim % 16 == 0 and out_dim <= 4096 and not EXACT_ORDER:
+            lib = _lib.load()
+            y = torch.empty(x2.shape[0], out_dim, dtype=torch.float32, device=dev)
+            ws = torch.empty(lib.gg_mlp_fwd_fast_workspace(in_dim, HIDDEN, out_dim), dtype=torch.uint8, device=dev)
+            _lib.check(lib.gg_mlp_fwd_fast(x2.shape[0], in_dim, HIDDEN, out_dim, _ptr(x2), _ptr(w1c), _ptr(b1c),
+                                           _ptr(w2c), _ptr(b2c), _ptr(y), _ptr(ws), ws.numel(), _stream(dev)),
+                       "gg_mlp_fwd_fast")
+        elif in_dim in SUPPORTED_IN and out_dim % 32 == 0:
             y = torch.empty(x2.shape[0], out_dim, dtype=torch.float32, device=dev)
             _lib.check(_lib.load().gg_mlp_fwd(x2.shape[0], in_dim, HIDDEN, out_dim, _ptr(x2), _ptr(w1c),
                                               _ptr(b1c), _ptr(w2c), _ptr(b2c), _ptr(y), _stream(dev)),

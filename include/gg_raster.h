@@ -314,6 +314,18 @@ int gg_mlp_fwd(int64_t num_rows, int in_dim, int hidden_dim, int out_dim, const 
                const float *w1, const float *b1, const float *w2, const float *b2, float *y,
                gg_stream_t stream);
 
+/* The same forward four times faster (round 3): both layers as products of fp16 two-piece operands scaled by powers of
+ * two on v_mfma_f32_16x16x32_f16 — as accurate against a double-precision sum as the fp32 matrix instruction
+ * (tools/check_f16split.hip), but not gg_mlp_fwd's summation order: the two agree to ~1e-6 of the largest output
+ * (tests/test_gpu_parity.py), not bit for bit.  in_dim 32 / 64 / 128, out_dim a multiple of 16 (<= 4096); `ws`:
+ * gg_mlp_fwd_fast_workspace(in_dim, 128, out_dim) bytes, 16-byte aligned, rewritten by every call (the packed
+ * weights: 0.3 MB at out_dim 512).  What the reference runs here is cuBLAS behind nn.Linear
+ * (gaussian_splatting.py:198-213): no summation order to match on that side. */
+size_t gg_mlp_fwd_fast_workspace(int in_dim, int hidden_dim, int out_dim);
+int gg_mlp_fwd_fast(int64_t num_rows, int in_dim, int hidden_dim, int out_dim, const float *x,
+                    const float *w1, const float *b1, const float *w2, const float *b2, float *y,
+                    void *ws, size_t ws_bytes, gg_stream_t stream);
+
 /* Backward of the same module (the reference evaluates fea_up on 1000 sampled pixels per training
  * step, gaussian_splatting.py:917): g = dL/dy (num_rows, out_dim) -> v_x (num_rows, in_dim), v_w1 (128,
  * in_dim), v_b1 (128), v_w2 (out_dim, 128), v_b2 (out_dim), all fully written.  in_dim 8..128, out_dim

@@ -616,10 +616,12 @@ def test_quat_to_rotmat_hip_vs_oracle_and_torch(oracle):
                                                  (5000, 32, 512), (1000, 8, 64), (1000, 16, 288),
                                                  (777, 64, 32), (1, 128, 512), (300, 128, 512), (5000, 128, 512),
                                                  (1000, 128, 96)])
-def test_mlp_fwd_bitexact_vs_oracle(oracle, rows, in_dim, out_dim):
-    """gg_mlp_fwd (fp32 MFMA) against the oracle, which sums in the kernel's order: bit-exact; and
+def test_mlp_fwd_bitexact_vs_oracle(oracle, rows, in_dim, out_dim, monkeypatch):
+    """gg_mlp_fwd (fp32 MFMA, `mlp.EXACT_ORDER`) against the oracle, which sums in the kernel's order: bit-exact; and
     against torch's Linear/ReLU/Linear on the GPU within 1e-5 of the output scale."""
+    from gaussiangrasper_amd import mlp as mlp_mod
     from gaussiangrasper_amd.mlp import mlp_forward
+    monkeypatch.setattr(mlp_mod, "EXACT_ORDER", True)
     g = torch.Generator().manual_seed(rows + in_dim)
     x = torch.randn(rows, in_dim, generator=g)
     w1, b1 = torch.randn(128, in_dim, generator=g) * 0.3, torch.randn(128, generator=g)
@@ -631,11 +633,81 @@ def test_mlp_fwd_bitexact_vs_oracle(oracle, rows, in_dim, out_dim):
     assert float((y - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
 
 
-def test_mlp_module_is_a_drop_in(oracle):
+def _mlp_ref64(x, w1, b1, w2, b2):
+    x, w1, b1, w2, b2 = (np.asarray(a, np.float64) for a in (x, w1, b1, w2, b2))
+    return np.maximum(x @ w1.T + b1, 0.0) @ w2.T + b2
+
+
+@pytest.mark.parametrize("rows,in_dim,out_dim", [(1, 32, 512), (63, 32, 512), (257, 32, 512), (5000, 32, 512),
+                                                 (777, 64, 32), (1000, 64, 272), (1, 128, 512), (300, 128, 512),
+                                                 (5000, 128, 512), (1000, 128, 96), (4099, 128, 1040)])
+def test_mlp_fwd_fast_is_fp32_grade(oracle, rows, in_dim, out_dim, monkeypatch):
+    """gg_mlp_fwd_fast (the default behind mlp_forward: fp16 two-piece operands on the 16x-rate matrix instruction)
+    against a float64 evaluation: max |err| <= 1e-6 of the largest output, and no worse than 1.5x the error of the
+    exact-order fp32 kernel (gg_mlp_fwd) where that one takes the shape; ragged row counts, partial last slices of
+    W2 (out_dim 96, 272, 1040)."""
+    from gaussiangrasper_amd import mlp as mlp_mod
+    from gaussiangrasper_amd.mlp import mlp_forward
+    g = torch.Generator().manual_seed(3 * rows + in_dim + out_dim)
+    x = torch.randn(rows, in_dim, generator=g)
+    w1, b1 = torch.randn(128, in_dim, generator=g) * 0.3, torch.randn(128, generator=g)
+    w2, b2 = torch.randn(out_dim, 128, generator=g) * 0.2, torch.randn(out_dim, generator=g)
+    args = [t.to(DEV) for t in (x, w1, b1, w2, b2)]
+    y = mlp_forward(*args)
+    assert y.shape == (rows, out_dim)
+    ref = _mlp_ref64(*(t.numpy() for t in (x, w1, b1, w2, b2)))
+    scale = np.abs(ref).max()
+    err_fast = np.abs(_np(y) - ref).max() / scale
+    assert err_fast <= 1e-6, err_fast
+    if out_dim % 32 == 0:
+        monkeypatch.setattr(mlp_mod, "EXACT_ORDER", True)
+        y_exact = mlp_forward(*args)
+        err_exact = np.abs(_np(y_exact) - ref).max() / scale
+        assert err_fast <= 1.5 * err_exact + 1e-8, (err_fast, err_exact)
+        ERROR_STATS.append({"what": f"mlp_fwd_fast in={in_dim}", "n": int(ref.size), "max_abs_over_scale": float(err_fast),
+                            "rel_p999": float(err_exact), "rel_max": float(err_exact), "rtol": 0.0, "atol_frac": 1e-6})
+
+
+@pytest.mark.parametrize("case", ["pixel rows 1e-6..1e6", "weight rows 1e-4..1e4", "inputs spread 1e-5..1 in a row",
+                                  "all 1e-25", "all 1e12"])
+def test_mlp_fwd_fast_over_a_wide_dynamic_range(case):
+    """The fast forward scales every pixel row of x, every hidden row and every weight row by its own power of two:
+    rows of very different magnitude, values spread inside a row and arrays far from 1 stay at fp32-grade error,
+    measured per output row against float64 (|err| <= 2e-6 of the row's largest |output| + |bias| magnitude)."""
+    from gaussiangrasper_amd.mlp import mlp_forward
+    g = torch.Generator().manual_seed(11)
+    rows, in_dim, out_dim = 3000, 128, 512
+    x = torch.randn(rows, in_dim, generator=g)
+    w1, b1 = torch.randn(128, in_dim, generator=g) * 0.3, torch.randn(128, generator=g) * 0.1
+    w2, b2 = torch.randn(out_dim, 128, generator=g) * 0.2, torch.randn(out_dim, generator=g) * 0.1
+    u = lambda lo, hi, shape: 10.0 ** (torch.rand(shape, generator=g) * (hi - lo) + lo)
+    if case.startswith("pixel rows"):
+        x = x * u(-6, 6, (rows, 1))
+        b1 = b1 * 0
+    elif case.startswith("weight rows"):
+        w1, w2 = w1 * u(-4, 4, (128, 1)), w2 * u(-4, 4, (out_dim, 1))
+    elif case.startswith("inputs spread"):
+        x = x * u(-5, 0, (rows, in_dim))
+    elif case.startswith("all 1e-25"):
+        x, b1, b2 = x * 1e-25, b1 * 0, b2 * 0
+    else:
+        x, b1 = x * 1e12, b1 * 1e12
+    y = _np(mlp_forward(*[t.to(DEV) for t in (x, w1, b1, w2, b2)]))
+    ref = _mlp_ref64(*(t.numpy() for t in (x, w1, b1, w2, b2)))
+    # per pixel row, against the magnitude its terms reach (the sum of |terms| bounds what fp32 can resolve)
+    hid = np.maximum(np.asarray(x, np.float64) @ np.asarray(w1, np.float64).T + np.asarray(b1, np.float64), 0.0)
+    mag = hid @ np.abs(np.asarray(w2, np.float64)).T + np.abs(np.asarray(b2, np.float64))
+    bad = np.abs(y - ref) > 2e-6 * mag.max(axis=1, keepdims=True) + 1e-37
+    assert not bad.any(), (case, float((np.abs(y - ref) / (mag.max(axis=1, keepdims=True) + 1e-300)).max()))
+
+
+def test_mlp_module_is_a_drop_in(oracle, monkeypatch):
     """Same sub-module names as the reference's MLP (checkpoint keys), same call on an (H, W, 32)
     feature image, gradients of the 1000-point training use equal to torch autograd through the plain
     Sequential within 1e-5, loud errors for CPU tensors and unsupported shapes."""
+    from gaussiangrasper_amd import mlp as mlp_mod
     from gaussiangrasper_amd.mlp import MLP
+    monkeypatch.setattr(mlp_mod, "EXACT_ORDER", True)      # (the bit-for-bit comparison below)
     torch.manual_seed(0)
     m = MLP(32, 512, hidden_list=[128]).to(DEV)
     assert sorted(m.state_dict()) == ["layers.0.bias", "layers.0.weight", "layers.2.bias", "layers.2.weight"]
@@ -664,11 +736,14 @@ def test_mlp_module_is_a_drop_in(oracle):
         m(torch.randn(4, 16, device=DEV))
 
 
-def test_mlp_full_image_rows_sampled_against_oracle(oracle):
+@pytest.mark.parametrize("exact", [True, False])
+def test_mlp_full_image_rows_sampled_against_oracle(oracle, exact, monkeypatch):
     """The render.sh size: every pixel of a 1600x1200x32 feature image -> 512 channels (3.9 GB of
-    output).  20 000 sampled rows bit-exact against the oracle; the untouched tail of a ragged row
-    count is covered by the small cases above."""
+    output).  20 000 sampled rows bit-exact against the oracle (exact-order kernel) / within 1e-6 of the output
+    scale (fast kernel, the default); the untouched tail of a ragged row count is covered by the small cases above."""
+    from gaussiangrasper_amd import mlp as mlp_mod
     from gaussiangrasper_amd.mlp import mlp_forward
+    monkeypatch.setattr(mlp_mod, "EXACT_ORDER", exact)
     g = torch.Generator().manual_seed(9)
     rows = 1200 * 1600
     x = torch.randn(rows, 32, generator=g)
@@ -678,7 +753,10 @@ def test_mlp_full_image_rows_sampled_against_oracle(oracle):
     idx = torch.randint(0, rows, (20000,), generator=g)
     idx[:4] = torch.tensor([0, 1, rows - 2, rows - 1])
     want = oracle.mlp_fwd(x[idx].numpy(), w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy())
-    assert_bitexact(_np(y[idx.to(DEV)]), want, "mlp.full")
+    if exact:
+        assert_bitexact(_np(y[idx.to(DEV)]), want, "mlp.full")
+    else:
+        assert np.abs(_np(y[idx.to(DEV)]) - want).max() <= 1e-6 * np.abs(want).max()
 
 
 @pytest.mark.parametrize("ch", [3, 32, 35])

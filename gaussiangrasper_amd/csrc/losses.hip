@@ -8,15 +8,27 @@
 //
 // Design point: 10^3-10^5 rows per call — a training step, not the 1.9 M-pixel render.sh pass (whose
 // forward is csrc/mlp.hip).  One launch each instead of torch's ~10 GEMM / elementwise launches with
-// their intermediates in HBM.  Row tiles of 16 through LDS, fp32 FMA on the VALU (the matrix pipe
-// would not be filled by 16-row tiles and the whole problem is 0.3 GFLOP), weight gradients summed
+// their intermediates in HBM.  Row tiles of 8 x hidden quarters through LDS, fp32 FMA on the VALU (the matrix pipe
+// would not be filled by such tiles and the whole problem is 0.3 GFLOP), weight and input gradients summed
 // across tiles with float atomics (the entry point clears them first).
 #include "gg_common.h"
 
 #define MB_HID 128
-#define MB_ROWS 16
+#ifndef MB_ROWS
+#define MB_ROWS 16     // rows per tile: 1000 rows x 4 hidden quarters = 252 workgroups, one round on 256 CUs
+#endif
+#define MB_JQ 32       // hidden units per workgroup: blockIdx.y = which quarter of the hidden layer
+#define MB_RT (MB_ROWS / 8)   // rows per thread in the hidden-layer phase (32 units x 8 row groups)
 #define MB_THREADS 256
+#ifndef MB_ABL
+#define MB_ABL 0   // measurement builds: 1 no v_w2, 2 also no dL/dh product, 3 also no v_x / v_w1
+#endif
 
+// r03: grid (row tiles, 4 hidden quarters).  The first form — one workgroup per 16-row tile doing everything — put 63
+// workgroups of ~190 us of serial work on 256 CUs for the reference's 1000 sampled points (the call took 0.19 ms, 7 % of
+// a training iteration); most of that work does not depend on the tile's row count (512 dependent w2 loads per thread,
+// 256 weight-gradient elements with an atomic each).  A workgroup now owns 32 hidden units: dL/dh of ITS units over all
+// outputs, v_w1 / v_w2 rows of its units, and its share of v_x (added with float atomics: four partial sums per element).
 template <int IN>
 __global__ __launch_bounds__(MB_THREADS) void mlp_bwd_kernel(long P, int out_dim, const float *__restrict__ x,
                                                              const float *__restrict__ w1,
@@ -27,11 +39,13 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_bwd_kernel(long P, int out_dim
                                                              float *__restrict__ v_b1, float *__restrict__ v_w2,
                                                              float *__restrict__ v_b2) {
     extern __shared__ float lds[];
-    float *xs = lds;                          // [16][IN]
-    float *hs = xs + MB_ROWS * IN;            // [16][128]   relu(h)
-    float *ghs = hs + MB_ROWS * MB_HID;       // [16][128]   dL/dh_pre
-    float *gs = ghs + MB_ROWS * MB_HID;       // [16][out]
+    float *xs = lds;                          // [rows][IN]
+    float *hs = xs + MB_ROWS * IN;            // [rows][32]   relu(h) of this quarter
+    float *ghs = hs + MB_ROWS * MB_JQ;        // [rows][32]   dL/dh_pre
+    float *part = ghs + MB_ROWS * MB_JQ;      // [8 output eighths][rows][32]   partial dL/dh
+    float *gs = part + 8 * MB_ROWS * MB_JQ;   // [out][rows]  (transposed: 16-byte aligned rows of four)
     const int t = threadIdx.x;
+    const int j0 = MB_JQ * blockIdx.y;
     const long ntiles = (P + MB_ROWS - 1) / MB_ROWS;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long row0 = tile * MB_ROWS;
@@ -39,69 +53,112 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_bwd_kernel(long P, int out_dim
         __syncthreads();
         for (int e = t; e < MB_ROWS * IN; e += MB_THREADS)
             xs[e] = (e / IN < rows) ? x[(size_t)row0 * IN + e] : 0.0f;
-        for (int e = t; e < MB_ROWS * out_dim; e += MB_THREADS)
-            gs[e] = (e / out_dim < rows) ? g[(size_t)row0 * out_dim + e] : 0.0f;
+        for (int e = t; e < MB_ROWS * out_dim; e += MB_THREADS) {   // g tile TRANSPOSED: gs[o][r], one float4 = four rows
+            const int r = e / out_dim, o = e - r * out_dim;
+            gs[o * MB_ROWS + r] = (r < rows) ? g[(size_t)row0 * out_dim + e] : 0.0f;
+        }
         __syncthreads();
         // v_b2[o] += sum_r g[r][o]
-        for (int o = t; o < out_dim; o += MB_THREADS) {
-            float s = 0.0f;
+        if (blockIdx.y == 0) {
+            for (int o = t; o < out_dim; o += MB_THREADS) {
+                float s = 0.0f;
 #pragma unroll
-            for (int r = 0; r < MB_ROWS; ++r) s += gs[r * out_dim + o];
-            if (s != 0.0f) atomicAdd(v_b2 + o, s);
+                for (int r = 0; r < MB_ROWS; ++r) s += gs[o * MB_ROWS + r];
+                if (s != 0.0f) atomicAdd(v_b2 + o, s);
+            }
         }
-        // hidden layer and dL/dh: thread -> hidden unit j, 8 of the 16 rows
-        const int j = t & (MB_HID - 1), rb = (t >> 7) * 8;
-        float hp[8], gh[8];
+        // hidden layer: thread -> hidden unit j0 + (t & 31), rows rb .. rb + MB_RT - 1
+        const int jl = t & (MB_JQ - 1), j = j0 + jl, rb = (t >> 5) * MB_RT;
+        float hp[MB_RT];
         {
             const float bias = b1[j];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) hp[r] = bias;
+            for (int r = 0; r < MB_RT; ++r) hp[r] = bias;
+#pragma unroll
             for (int k = 0; k < IN; ++k) {
                 const float w = w1[(size_t)j * IN + k];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) hp[r] = __builtin_fmaf(w, xs[(rb + r) * IN + k], hp[r]);
+                for (int r = 0; r < MB_RT; ++r) hp[r] = __builtin_fmaf(w, xs[(rb + r) * IN + k], hp[r]);
             }
 #pragma unroll
-            for (int r = 0; r < 8; ++r) gh[r] = 0.0f;
-            for (int o = 0; o < out_dim; ++o) {
-                const float w = w2[(size_t)o * MB_HID + j];            // coalesced over j
+            for (int r = 0; r < MB_RT; ++r) hs[(rb + r) * MB_JQ + jl] = fmaxf(hp[r], 0.0f);
+        }
+        // dL/dh of this quarter: thread -> (unit, one eighth of the outputs), ALL rows of the tile — every w2 value is
+        // loaded once per workgroup, at most 64 + 64 loads per thread in two batches (the first form had every thread
+        // walk all 512 outputs with eight loads in flight: a chain of L2 latencies, most of the call's time)
+        {
+            const int og = t >> 5, ob = (out_dim + 7) / 8, o_lo = og * ob, o_hi = min(out_dim, o_lo + ob);
+            float gp[MB_ROWS];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) gh[r] = __builtin_fmaf(gs[(rb + r) * out_dim + o], w, gh[r]);
+            for (int r = 0; r < MB_ROWS; ++r) gp[r] = 0.0f;
+            for (int o0 = o_lo; o0 < (MB_ABL >= 2 ? o_lo : o_hi); o0 += 32) {
+                float wv[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u)                            // 32 consecutive j: one 128-byte segment
+                    wv[u] = (o0 + u < o_hi) ? w2[(size_t)(o0 + u) * MB_HID + j] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < 32; ++u) {
+                    const int o = min(o0 + u, out_dim - 1);
+#pragma unroll
+                    for (int r4 = 0; r4 < MB_ROWS; r4 += 4) {
+                        const float4 g4 = *reinterpret_cast<const float4 *>(gs + o * MB_ROWS + r4);
+                        gp[r4] = __builtin_fmaf(g4.x, wv[u], gp[r4]);
+                        gp[r4 + 1] = __builtin_fmaf(g4.y, wv[u], gp[r4 + 1]);
+                        gp[r4 + 2] = __builtin_fmaf(g4.z, wv[u], gp[r4 + 2]);
+                        gp[r4 + 3] = __builtin_fmaf(g4.w, wv[u], gp[r4 + 3]);
+                    }
+                }
             }
+#pragma unroll
+            for (int r = 0; r < MB_ROWS; ++r) part[(og * MB_ROWS + r) * MB_JQ + jl] = gp[r];
+        }
+        __syncthreads();
+        {
             float sb = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const bool on = hp[r] > 0.0f;
-                gh[r] = on ? gh[r] : 0.0f;
-                hs[(rb + r) * MB_HID + j] = on ? hp[r] : 0.0f;
-                ghs[(rb + r) * MB_HID + j] = gh[r];
-                sb += gh[r];
+            for (int r = 0; r < MB_RT; ++r) {
+                float gh = 0.0f;
+#pragma unroll
+                for (int og = 0; og < 8; ++og) gh += part[(og * MB_ROWS + rb + r) * MB_JQ + jl];
+                gh = hp[r] > 0.0f ? gh : 0.0f;
+                ghs[(rb + r) * MB_JQ + jl] = gh;
+                sb += gh;
             }
             if (sb != 0.0f) atomicAdd(v_b1 + j, sb);
         }
         __syncthreads();
-        // v_x[r][k] = sum_j gh[r][j] w1[j][k]
-        for (int e = t; e < rows * IN; e += MB_THREADS) {
+        // v_x[r][k] += sum_{j in quarter} gh[r][j] w1[j][k]
+        for (int e = t; e < (MB_ABL >= 3 ? 0 : rows * IN); e += MB_THREADS) {
             const int r = e / IN, k = e - r * IN;
             float s = 0.0f;
-            for (int jj = 0; jj < MB_HID; ++jj) s = __builtin_fmaf(ghs[r * MB_HID + jj], w1[(size_t)jj * IN + k], s);
-            v_x[(size_t)row0 * IN + e] = s;
+#pragma unroll
+            for (int jj = 0; jj < MB_JQ; ++jj) s = __builtin_fmaf(ghs[r * MB_JQ + jj], w1[(size_t)(j0 + jj) * IN + k], s);
+            if (s != 0.0f) atomicAdd(v_x + (size_t)row0 * IN + e, s);
         }
         // v_w1[j][k] += sum_r gh[r][j] x[r][k]
-        for (int e = t; e < MB_HID * IN; e += MB_THREADS) {
+        for (int e = t; e < (MB_ABL >= 3 ? 0 : MB_JQ * IN); e += MB_THREADS) {
             const int jj = e / IN, k = e - jj * IN;
             float s = 0.0f;
 #pragma unroll
-            for (int r = 0; r < MB_ROWS; ++r) s = __builtin_fmaf(ghs[r * MB_HID + jj], xs[r * IN + k], s);
-            if (s != 0.0f) atomicAdd(v_w1 + e, s);
+            for (int r = 0; r < MB_ROWS; ++r) s = __builtin_fmaf(ghs[r * MB_JQ + jj], xs[r * IN + k], s);
+            if (s != 0.0f) atomicAdd(v_w1 + (size_t)j0 * IN + e, s);
         }
-        // v_w2[o][j] += sum_r g[r][o] relu(h)[r][j]   (consecutive threads: consecutive j -> full rows)
-        for (int e = t; e < out_dim * MB_HID; e += MB_THREADS) {
-            const int o = e >> 7, jj = e & (MB_HID - 1);
+        // v_w2[o][j] += sum_r g[r][o] relu(h)[r][j]   (consecutive threads: consecutive j -> 128-byte segments)
+        float hcol[MB_ROWS];      // relu(h)[:, jj] of this thread's unit: the same for every output it takes
+#pragma unroll
+        for (int r = 0; r < MB_ROWS; ++r) hcol[r] = hs[r * MB_JQ + (t & (MB_JQ - 1))];
+        for (int e = t; e < (MB_ABL >= 1 ? 0 : out_dim * MB_JQ); e += MB_THREADS) {
+            const int o = e >> 5, jj = e & (MB_JQ - 1);
             float s = 0.0f;
 #pragma unroll
-            for (int r = 0; r < MB_ROWS; ++r) s = __builtin_fmaf(gs[r * out_dim + o], hs[r * MB_HID + jj], s);
-            if (s != 0.0f) atomicAdd(v_w2 + e, s);
+            for (int r4 = 0; r4 < MB_ROWS; r4 += 4) {
+                const float4 g4 = *reinterpret_cast<const float4 *>(gs + o * MB_ROWS + r4);
+                s = __builtin_fmaf(g4.x, hcol[r4], s);
+                s = __builtin_fmaf(g4.y, hcol[r4 + 1], s);
+                s = __builtin_fmaf(g4.z, hcol[r4 + 2], s);
+                s = __builtin_fmaf(g4.w, hcol[r4 + 3], s);
+            }
+            if (s != 0.0f) atomicAdd(v_w2 + (size_t)o * MB_HID + j0 + jj, s);
         }
     }
 }
@@ -120,22 +177,23 @@ extern "C" int gg_mlp_bwd(int64_t num_rows, int in_dim, int hidden_dim, int out_
     fail |= hipMemsetAsync(v_b1, 0, sizeof(float) * MB_HID, s) != hipSuccess;
     fail |= hipMemsetAsync(v_w2, 0, sizeof(float) * (size_t)out_dim * MB_HID, s) != hipSuccess;
     fail |= hipMemsetAsync(v_b2, 0, sizeof(float) * out_dim, s) != hipSuccess;
+    if (num_rows > 0 && v_x) fail |= gg_fill_async(v_x, 0, sizeof(float) * (size_t)num_rows * in_dim, s) != hipSuccess;
     if (fail) {
         gg_set_error("gg_mlp_bwd: memset failed");
         return GG_ERR_LAUNCH;
     }
     if (num_rows == 0) return GG_OK;
     GG_REQUIRE(x && w1 && b1 && w2 && g && v_x, "null pointer");
-    const size_t lds_bytes = sizeof(float) * (size_t)MB_ROWS * (in_dim + 2 * MB_HID + out_dim);
+    const size_t lds_bytes = sizeof(float) * (size_t)MB_ROWS * (in_dim + 10 * MB_JQ + out_dim);
     const long ntiles = (num_rows + MB_ROWS - 1) / MB_ROWS;
-    const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
+    const dim3 grid((unsigned)(ntiles < 2048 ? ntiles : 2048), MB_HID / MB_JQ);
     hipError_t e = hipSuccess;
 #define MB_LAUNCH(IN_)                                                                                     \
     do {                                                                                                   \
         e = hipFuncSetAttribute((const void *)mlp_bwd_kernel<IN_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds_bytes);                                                           \
         if (e == hipSuccess)                                                                               \
-            hipLaunchKernelGGL((mlp_bwd_kernel<IN_>), dim3(grid), dim3(MB_THREADS), lds_bytes, s,           \
+            hipLaunchKernelGGL((mlp_bwd_kernel<IN_>), grid, dim3(MB_THREADS), lds_bytes, s,           \
                                (long)num_rows, out_dim, x, w1, b1, w2, g, v_x, v_w1, v_b1, v_w2, v_b2);     \
     } while (0)
     gg_prof_begin(GG_K_MLP_BWD, s);

@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--skip-torch", action="store_true", help="only the fused variant (clean kernel profiles)")
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--height", type=int, default=1200)
     ap.add_argument("--width", type=int, default=1600)
@@ -135,7 +136,7 @@ def main():
         return (time.perf_counter() - t0) / a.steps
 
     t_fused = timed(True, optimizers(FusedAdam))
-    t_torch = timed(False, optimizers(torch.optim.Adam))
+    t_torch = timed(False, optimizers(torch.optim.Adam)) if not a.skip_torch else float("nan")
     print(json.dumps({
         "workload": "%d Gaussians, %dx%d, %d views per optimizer step: plugin-route render + main / depth / normal / "
                     "feature / up losses + backward, one Adam step over 6 Gaussian groups + fea_up" % (a.points, w, h, a.views),

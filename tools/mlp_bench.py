@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
-"""MFMA roofline of the feature up-projection MLP at the render.sh size: 1600x1200
-pixels, 32 -> 128 -> 512, fp32.  Times gg_mlp_fwd with the in-library hipEvents, torch's
+"""Roofline of the feature up-projection MLP at the render.sh size: 1600x1200
+pixels, 32 -> 128 -> 512, fp32 results.  Since r03 the default forward (gg_mlp_fwd_fast: fp16 two-piece operands on
+the 16x-rate matrix instruction) needs a quarter of the matrix cycles of the fp32 kernel and is bound by its 3.9 GB of
+OUTPUT: `roofline` is the HBM one (bytes read + written over time against 8 TB/s; a plain fill of the same size runs
+at ~2.9 TB/s on this chip), `mfma_fp32_equivalent` what the old bound would have said; `--exact` times the
+exact-order fp32 kernel (gg_mlp_fwd).  Times with the in-library hipEvents, torch's
 Linear/ReLU/Linear (the reference's implementation, on the same GPU) with torch events, and the CPU
 oracle on a bounded sample.  Prints one JSON line."""
 import ctypes, json, os, sys, time
@@ -10,7 +14,10 @@ import torch
 from gaussiangrasper_amd import _lib
 from gaussiangrasper_amd.mlp import MLP
 
+from gaussiangrasper_amd import mlp as mlp_mod
 PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA, dense
+HBM_PEAK_GBS = 8000.0
+mlp_mod.EXACT_ORDER = "--exact" in sys.argv
 dev = "cuda:0"
 lib = _lib.load()
 h, w, cin, cout = 1200, 1600, 32, 512
@@ -48,10 +55,15 @@ O.mlp_fwd(img.reshape(-1, cin)[:sample].cpu().numpy(), *[p.detach().cpu().numpy(
           (m.layers[0].weight, m.layers[0].bias, m.layers[2].weight, m.layers[2].bias)])
 cpu_s = time.perf_counter() - t0
 print(json.dumps({
-    "kernel": "mlp_fwd_kernel<32>", "workload": f"{w}x{h} pixels, 32->128->512 fp32, {flops / 1e9:.1f} GFLOP, "
+    "kernel": "mlp_fwd_kernel<32>" if mlp_mod.EXACT_ORDER else "mlp_fwd_f16_kernel<32>",
+    "workload": f"{w}x{h} pixels, 32->128->512 fp32, {flops / 1e9:.1f} GFLOP, "
     f"{rows * cout * 4 / 1e9:.2f} GB written",
-    "ms": ours_ms, "roofline": {"bound": "mfma", "achieved": flops / ours_ms / 1e9, "peak": PEAK_TFLOPS,
-                                "unit": "TFLOP/s", "frac": flops / ours_ms / 1e9 / PEAK_TFLOPS},
+    "ms": ours_ms,
+    "roofline": ({"bound": "mfma", "achieved": flops / ours_ms / 1e9, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                  "frac": flops / ours_ms / 1e9 / PEAK_TFLOPS} if mlp_mod.EXACT_ORDER else
+                 {"bound": "hbm", "achieved": rows * (cin + cout) * 4 / ours_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": rows * (cin + cout) * 4 / ours_ms / 1e6 / HBM_PEAK_GBS}),
+    "mfma_fp32_equivalent": {"achieved": flops / ours_ms / 1e9, "peak": PEAK_TFLOPS, "unit": "TFLOP/s"},
     "torch_linear_relu_linear_ms": torch_ms, "max_rel_diff_vs_torch": err,
     "cpu_baseline": {"value": sample / cpu_s, "unit": "pixels/s", "cores": O.num_threads(), "kind": "port",
                      "sample": f"{sample} pixels"}, "gpu_pixels_per_s": rows / (ours_ms * 1e-3)}))

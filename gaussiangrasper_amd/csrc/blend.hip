@@ -71,7 +71,11 @@ void gg_launch_blend2_bwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
 void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int ntiles, const int32_t *ids,
                                const int2 *bins, const GRec *rec, const float *colors, const float *background,
                                float *out_img, float *final_Ts, int32_t *final_idx, const float *colors2, int C2,
-                               const float *background2, float *out_img2, QList ql, hipStream_t s);
+                               const float *background2, float *out_img2, QList ql, hipStream_t s, int ncb);
+void gg_launch_blend2_fwd_blocks(int ncb, int C, int off, int img_h, int img_w, int tiles_x, int ntiles,
+                                 const int32_t *ids, const int2 *bins, const GRec *rec, const float *colors,
+                                 const float *background, float *out_img, float *final_Ts, int32_t *final_idx,
+                                 int write_final, hipStream_t s);
 
 // Channel chunking: calls with <= 3 channels (rgb / depth / normal) use the narrow kernels with
 // the colours inside the LDS record; anything wider is processed in chunks of 32 channels on the
@@ -82,6 +86,54 @@ void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
 // 4..8 remaining channels (the rgb | depth | normal tail of a fused call) go to the 8-wide narrow
 // kernels: on the wide kernels such a tail cost as much as a full 32-channel chunk.
 static int chunk_width(int remaining) { return remaining <= 3 ? remaining : remaining <= 8 ? 8 : 32; }
+// Defaults (tools/fwdblocks_bench.py, 5 M Gaussians, 1920x1080, 128 + 7 channels, forward kernels per view): pair walk of
+// one block + one walk of the other three 1.51 ms (three waves per SIMD, 147 registers); all four blocks in the pair walk
+// 1.50 (two waves, 201 registers); 2 + 2 1.74; one block per walk 2.0-2.2.  The headline's 32-channel array is one block.
+#ifndef GG_FWD_BLOCKS_PAIR
+#define GG_FWD_BLOCKS_PAIR 1
+#endif
+#ifndef GG_FWD_BLOCKS_CHUNK
+#define GG_FWD_BLOCKS_CHUNK 3
+#endif
+
+// Forward walks over several 32-channel blocks at once (csrc/blend2.hip, NCB; r03): how many blocks the pair walk and
+// the walks of the remaining chunks of a wide first array take.  Tuning entry (tools/): returns the previous pair value.
+static int g_fwd_blocks_pair = GG_FWD_BLOCKS_PAIR, g_fwd_blocks_chunk = GG_FWD_BLOCKS_CHUNK;
+extern "C" int gg_debug_set_fwd_blocks(int pair_blocks, int chunk_blocks) {
+    const int prev = g_fwd_blocks_pair;
+    g_fwd_blocks_pair = pair_blocks == 4 ? 4 : (pair_blocks == 2 ? 2 : 1);
+    g_fwd_blocks_chunk = chunk_blocks >= 2 && chunk_blocks <= 4 ? chunk_blocks : 1;
+    return prev;
+}
+// the forward walks of channels [off, C) of a wide array beyond its first walk: as many 32-channel blocks per walk as
+// the policy allows (16-byte aligned rows), then the usual chunks
+static void fwd_remaining_chunks(int C, int off, int img_h, int img_w, int tiles_x, int ntiles, const int32_t *ids,
+                                 const int32_t *tile_bins, const GRec *rec, const float *colors, const float *background,
+                                 float *out_img, float *final_Ts, int32_t *final_idx, bool first_writes_final,
+                                 hipStream_t s) {
+    const bool aligned = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_img) & 15) == 0);
+    bool first = first_writes_final;
+    while (off < C) {
+        const int blocks = (C - off) / 32;
+        const int ncb = aligned && (off % 4 == 0) ? min(blocks, g_fwd_blocks_chunk) : 1;
+        if (ncb >= 2) {
+            gg_prof_begin(GG_K_BLEND_FWD + gg_width_index(32), s);
+            gg_launch_blend2_fwd_blocks(ncb, C, off, img_h, img_w, tiles_x, ntiles, ids, (const int2 *)tile_bins, rec,
+                                        colors, background, out_img, final_Ts, final_idx, first, s);
+            gg_prof_end(GG_K_BLEND_FWD + gg_width_index(32), s);
+            off += 32 * ncb;
+        } else {
+            const int w = chunk_width(C - off);
+            const int n = min(w, C - off);
+            gg_prof_begin(GG_K_BLEND_FWD + gg_width_index(w), s);
+            gg_launch_blend2_fwd(w, C, off, n, img_h, img_w, tiles_x, ntiles, ids, (const int2 *)tile_bins, rec, colors,
+                                 background, out_img, final_Ts, final_idx, first, s);
+            gg_prof_end(GG_K_BLEND_FWD + gg_width_index(w), s);
+            off += n;
+        }
+        first = false;
+    }
+}
 
 #ifdef GG_ABLATION
 // Measurement build only (libgg_raster_abl.so, tools/kbench.py): level > 0 makes the backward run an
@@ -119,15 +171,8 @@ extern "C" int gg_blend_fwd(int C, int N, int img_h, int img_w, const int32_t *i
     }
     const int tiles_x = (img_w + GG_BLOCK - 1) / GG_BLOCK, tiles_y = (img_h + GG_BLOCK - 1) / GG_BLOCK;
     const int ntiles = tiles_x * tiles_y;
-    for (int off = 0; off < C;) {
-        const int w = chunk_width(C - off);
-        const int n = min(w, C - off);
-        gg_prof_begin(GG_K_BLEND_FWD + gg_width_index(w), s);
-        gg_launch_blend2_fwd(w, C, off, n, img_h, img_w, tiles_x, ntiles, ids, (const int2 *)tile_bins,
-                             rec, colors, background, out_img, final_Ts, final_idx, off == 0, s);
-        gg_prof_end(GG_K_BLEND_FWD + gg_width_index(w), s);
-        off += n;
-    }
+    fwd_remaining_chunks(C, 0, img_h, img_w, tiles_x, ntiles, ids, tile_bins, rec, colors, background, out_img, final_Ts,
+                         final_idx, true, s);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
@@ -181,19 +226,19 @@ static int blend_fwd_pair_impl(int C, int C2, int N, int img_h, int img_w, const
                    "quad_lists: gg_quad_lists_workspace(num_intersects, H, W) bytes, 16-byte aligned, expected");
         ql = quad_lists_at(quad_lists, ntiles, N);
     }
+    // the pair walk takes 1, 2 or 4 blocks of the first array (aligned rows; not with quad lists)
+    int pair_blocks = 1;
+    if (!quad_lists && (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_img) & 15) == 0)) {
+        if (g_fwd_blocks_pair >= 4 && C >= 128) pair_blocks = 4;
+        else if (g_fwd_blocks_pair >= 2 && C >= 64) pair_blocks = 2;
+    }
     gg_prof_begin(GG_K_BLEND_FWD_PAIR, s);
     gg_launch_blend2_fwd_pair(C, img_h, img_w, tiles_x, ntiles, ids, (const int2 *)tile_bins, rec, colors,
-                              background, out_img, final_Ts, final_idx, colors2, C2, background2, out_img2, ql, s);
+                              background, out_img, final_Ts, final_idx, colors2, C2, background2, out_img2, ql, s,
+                              pair_blocks);
     gg_prof_end(GG_K_BLEND_FWD_PAIR, s);
-    for (int off = 32; off < C;) {
-        const int w = chunk_width(C - off);
-        const int n = min(w, C - off);
-        gg_prof_begin(GG_K_BLEND_FWD + gg_width_index(w), s);
-        gg_launch_blend2_fwd(w, C, off, n, img_h, img_w, tiles_x, ntiles, ids, (const int2 *)tile_bins,
-                             rec, colors, background, out_img, final_Ts, final_idx, 0, s);
-        gg_prof_end(GG_K_BLEND_FWD + gg_width_index(w), s);
-        off += n;
-    }
+    fwd_remaining_chunks(C, 32 * pair_blocks, img_h, img_w, tiles_x, ntiles, ids, tile_bins, rec, colors, background,
+                         out_img, final_Ts, final_idx, false, s);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }

@@ -223,8 +223,13 @@ __device__ __forceinline__ int stage_chunk(LIST &L, int lane, int e, bool valid,
 #define GG_FWD_WAVES 5
 #endif
 // QW: the wave persists the survivors of its quadrant cull (quad lists, blend_common.h) for the backward walk
-template <int CH, bool WIDE, bool FULL, bool EX = false, int FABL = 0, bool QW = false>
-__global__ __launch_bounds__(64 * GG_WPB_OTHER) __attribute__((amdgpu_waves_per_eu((WIDE && EX) ? GG_FWD_WAVES : 1)))
+// NCB (r03): 32-channel blocks per walk of a wide build — one cull, one sigma / exp / alpha / T per (pixel, Gaussian)
+// for 32 NCB channels: NCB more colour dwords per lane and pair, 2 NCB MFMAs, 32 NCB accumulator registers.  What
+// a 128-channel feature image (BASELINE config 5) is rendered with: per channel the same fma / MFMA sequence, so
+// the images are bit-identical to the one-block walks'.
+template <int CH, bool WIDE, bool FULL, bool EX = false, int FABL = 0, bool QW = false, int NCB = 1>
+__global__ __launch_bounds__(64 * GG_WPB_OTHER)
+__attribute__((amdgpu_waves_per_eu((WIDE && EX && NCB == 1) ? GG_FWD_WAVES : (NCB == 2 ? (EX ? 4 : 3) : (NCB > 2 ? 2 : 1)))))
 void blend2_fwd_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
@@ -234,6 +239,7 @@ void blend2_fwd_kernel(
     constexpr bool N8 = !WIDE && CH > 3;          // 8-channel narrow record layout
     static_assert(!EX || WIDE, "the second array rides on the wide kernel");
     static_assert(!QW || WIDE, "quad lists are written by the wide builds (their list record keeps position + 1 in c.w)");
+    static_assert(NCB == 1 || (WIDE && FULL), "several channel blocks: the full wide builds");
     typedef WaveListT<EX ? 3 : (N8 ? 2 : 1)> LIST;
     __shared__ LIST lists[GG_WPB_OTHER];
     int wave;
@@ -261,11 +267,13 @@ void blend2_fwd_kernel(
     float acc2[EX ? 8 : 1];
 #pragma unroll
     for (int c = 0; c < (EX ? 8 : 1); ++c) acc2[c] = 0.0f;
-    f32x16 acc0, acc1;  // WIDE: pixels 0-31 / 32-63 of the quadrant x 32 channels
+    f32x16 acc0[NCB], acc1[NCB];  // WIDE: pixels 0-31 / 32-63 of the quadrant x 32 channels (per channel block)
 #pragma unroll
     for (int c = 0; c < (WIDE ? 1 : CH); ++c) acc[c] = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[cb][r] = acc1[cb][r] = 0.0f;
     const int wch = lane & 31, half = lane >> 5;
     const bool wch_ok = FULL || wch < nch;
 
@@ -293,7 +301,7 @@ void blend2_fwd_kernel(
             // LEANF (pair build): the records of a group are not all requested up front
             // (12 ds_read_b128 = 48 registers in flight) but two Gaussians at a time, and the list position is read
             // again where it is needed: a fifth wave per SIMD needs <= 96 registers.
-            constexpr bool LEANF = WIDE && EX;
+            constexpr bool LEANF = WIDE && (EX || NCB > 1);
             float4 A[GRP], B[GRP], Cc[GRP], Cd[GRP];
 #pragma unroll
             for (int q = 0; q < GRP; ++q) {
@@ -303,13 +311,15 @@ void blend2_fwd_kernel(
                 Cc[q] = L.c[GRP + k + q];
                 if (N8) Cd[q] = L.d[GRP + k + q];
             }
-            float colB[GRP / 2];
+            float colB[GRP / 2][NCB];
             if (WIDE) {
 #pragma unroll
                 for (int pr = 0; pr < GRP / 2; ++pr) {
                     // lanes 0-31 fetch the colour row of the even Gaussian, 32-63 of the odd one
                     const int gid = __builtin_bit_cast(int, L.c[GRP + k + 2 * pr + half].x);
-                    colB[pr] = (wch_ok && fabl < 2) ? colors[(size_t)gid * C + ch_off + wch] : 0.0f;
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+                        colB[pr][cb] = (wch_ok && fabl < 2) ? colors[(size_t)gid * C + ch_off + 32 * cb + wch] : 0.0f;
                 }
             }
             float alpha[GRP];
@@ -375,7 +385,7 @@ void blend2_fwd_kernel(
 #pragma unroll
                 for (int q = 0; q < GRP; ++q) KEEP(vis[q]);
 #pragma unroll
-                for (int pr = 0; pr < GRP / 2; ++pr) KEEP(colB[pr]);
+                for (int pr = 0; pr < GRP / 2; ++pr) KEEP(colB[pr][0]);
             } else if (WIDE) {
                 // (handing these four dependent MFMAs to the pipe at the top of the NEXT iteration, in front of that
                 // group's arithmetic, measures the same for the pair kernel and +8 % for the plain one: 20 more VGPRs)
@@ -385,10 +395,13 @@ void blend2_fwd_kernel(
                         __builtin_bit_cast(unsigned, vis[2 * pr]),
                         __builtin_bit_cast(unsigned, vis[2 * pr + 1]), false, false);
                     // r[0]: pixels 0-31 x {even, odd} Gaussian ; r[1]: pixels 32-63 x {even, odd}
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, (unsigned)r[0]),
-                                                                colB[pr], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, (unsigned)r[1]),
-                                                                colB[pr], acc1, 0, 0, 0);
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) {
+                        acc0[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, (unsigned)r[0]),
+                                                                        colB[pr][cb], acc0[cb], 0, 0, 0);
+                        acc1[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, (unsigned)r[1]),
+                                                                        colB[pr][cb], acc1[cb], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -446,15 +459,18 @@ void blend2_fwd_kernel(
         // (dead) list memory and leave as float4: 8 store instructions of 1 KB each (one image row of the quadrant).
         float *buf = reinterpret_cast<float *>(&L);   // 2 KB of the wave's list
         const int chunk = lane & 7;
-        const float4 bg4 = *reinterpret_cast<const float4 *>(background + ch_off + 4 * chunk);
         __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+        const int ch_cb = ch_off + 32 * cb;
+        const float4 bg4 = *reinterpret_cast<const float4 *>(background + ch_cb + 4 * chunk);
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {   // pixels 16 q4 .. 16 q4 + 15: registers 8 (q4 & 1) .. + 7 of acc0 / acc1
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
                 const int r = 8 * (q4 & 1) + rr;
                 const int pl = (rr & 3) + 8 * (rr >> 2) + 4 * half;   // pixel inside the 16
-                buf[pl * 32 + wch] = (q4 >> 1) ? acc1[r] : acc0[r];
+                buf[pl * 32 + wch] = (q4 >> 1) ? acc1[cb][r] : acc0[cb][r];
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -469,11 +485,12 @@ void blend2_fwd_kernel(
                     typedef float f4v __attribute__((ext_vector_type(4)));
                     const f4v o = {__builtin_fmaf(Tp, bg4.x, v.x), __builtin_fmaf(Tp, bg4.y, v.y),
                                    __builtin_fmaf(Tp, bg4.z, v.z), __builtin_fmaf(Tp, bg4.w, v.w)};
-                    f4v *dst = reinterpret_cast<f4v *>(out_img + ((size_t)pi * img_w + pj) * C + ch_off + 4 * chunk);
+                    f4v *dst = reinterpret_cast<f4v *>(out_img + ((size_t)pi * img_w + pj) * C + ch_cb + 4 * chunk);
                     *dst = o;   // (a non-temporal store measures the same: 0.483 against 0.490 ms)
                 }
             }
             __builtin_amdgcn_wave_barrier();
+        }
         }
     } else {
         const float bgc = wch_ok ? background[ch_off + wch] : 0.0f;
@@ -486,7 +503,7 @@ void blend2_fwd_kernel(
                 const int pj = qx0 + (pq & 7), pi = qy0 + (pq >> 3);
                 if (pi < img_h && pj < img_w && wch_ok)
                     out_img[((size_t)pi * img_w + pj) * C + ch_off + wch] =
-                        __builtin_fmaf(Tp, bgc, blk ? acc1[r] : acc0[r]);
+                        __builtin_fmaf(Tp, bgc, blk ? acc1[0][r] : acc0[0][r]);
             }
     }
     STAMP(7);
@@ -1635,10 +1652,27 @@ void gg_launch_blend2_fwd(int width, int C, int off, int n, int img_h, int img_w
         hipLaunchKernelGGL((blend2_fwd_kernel<32, true, false>), grid, block, 0, s, B2_FWD_ARGS);
 }
 
+// several 32-channel blocks in one walk (channels [off, off + 32 ncb)); 16-byte aligned rows (the launcher's caller
+// checks), ncb = 2, 3 or 4
+void gg_launch_blend2_fwd_blocks(int ncb, int C, int off, int img_h, int img_w, int tiles_x, int ntiles,
+                                 const int32_t *ids, const int2 *bins, const GRec *rec, const float *colors,
+                                 const float *background, float *out_img, float *final_Ts, int32_t *final_idx,
+                                 int write_final, hipStream_t s) {
+    dim3 grid(gg_blend_grid(ntiles, GG_WPB_OTHER)), block(64 * GG_WPB_OTHER);
+    const int n = 32;
+    if (ncb == 2)
+        hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, false, 0, false, 2>), grid, block, 0, s, B2_FWD_ARGS);
+    else if (ncb == 3)
+        hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, false, 0, false, 3>), grid, block, 0, s, B2_FWD_ARGS);
+    else
+        hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, false, 0, false, 4>), grid, block, 0, s, B2_FWD_ARGS);
+}
+
+// ncb: 32-channel blocks of the first array in this walk (1, 2 or 4; channels [0, 32 ncb))
 void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int ntiles, const int32_t *ids,
                                const int2 *bins, const GRec *rec, const float *colors, const float *background,
                                float *out_img, float *final_Ts, int32_t *final_idx, const float *colors2, int C2,
-                               const float *background2, float *out_img2, QList ql, hipStream_t s) {
+                               const float *background2, float *out_img2, QList ql, hipStream_t s, int ncb) {
     dim3 grid(gg_blend_grid(ntiles, GG_WPB_OTHER)), block(64 * GG_WPB_OTHER);
     Seg2 seg2;
     seg2.colors = colors2;
@@ -1657,6 +1691,16 @@ void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
         default: break;
     }
 #endif
+    if (ncb == 2 && !ql.recs) {
+        hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, true, 0, false, 2>), grid, block, 0, s, C, 0, 32, img_h,
+                           img_w, tiles_x, ntiles, ids, bins, rec, colors, background, out_img, final_Ts, final_idx, 1, seg2);
+        return;
+    }
+    if (ncb == 4 && !ql.recs) {
+        hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, true, 0, false, 4>), grid, block, 0, s, C, 0, 32, img_h,
+                           img_w, tiles_x, ntiles, ids, bins, rec, colors, background, out_img, final_Ts, final_idx, 1, seg2);
+        return;
+    }
     if (ql.recs) {   // the survivors of the quadrant cull are persisted for the backward walk
         hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, true, 0, true>), grid, block, 0, s, C, 0, 32, img_h, img_w,
                            tiles_x, ntiles, ids, bins, rec, colors, background, out_img, final_Ts, final_idx, 1, seg2, ql);

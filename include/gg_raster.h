@@ -314,6 +314,11 @@ int gg_mlp_fwd(int64_t num_rows, int in_dim, int hidden_dim, int out_dim, const 
                const float *w1, const float *b1, const float *w2, const float *b2, float *y,
                gg_stream_t stream);
 
+/* Tuning entry (round 3): how many 32-channel blocks of a wide colour array one forward walk takes — in the pair walk
+ * of gg_blend_fwd_pair (1, 2 or 4) and in the walks of the remaining chunks / of gg_blend_fwd (1..4).  Images are
+ * bit-identical for every setting; returns the previous pair value.  Defaults: see csrc/blend.hip. */
+int gg_debug_set_fwd_blocks(int pair_blocks, int chunk_blocks);
+
 /* The same forward four times faster (round 3): both layers as products of fp16 two-piece operands scaled by powers of
  * two on v_mfma_f32_16x16x32_f16 — as accurate against a double-precision sum as the fp32 matrix instruction
  * (tools/check_f16split.hip), but not gg_mlp_fwd's summation order: the two agree to ~1e-6 of the largest output

@@ -1223,6 +1223,42 @@ def test_split_segment_returns_channel_slices_and_takes_separate_cotangents(orac
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("c", [64, 96, 128, 160, 100])
+def test_forward_walks_over_several_channel_blocks_are_bit_identical(oracle, c):
+    """A forward walk can take 2, 3 or 4 blocks of 32 channels at once (csrc/blend2.hip NCB, gg_debug_set_fwd_blocks;
+    BASELINE config 5's 128-channel feature image): every setting gives the images of the one-block walks bit for bit,
+    through gg_blend_fwd (NDRasterizeGaussians) and through the pair operator; the default is checked against the
+    oracle as well.  Ragged image, channel counts with a partial last chunk (100) and a fifth block (160)."""
+    from gaussiangrasper_amd import _lib
+    lib = _lib.load()
+    n, h, w = 4000, 83, 101
+    xys, depths, radii, conics, nth, colors, opac, bg = _blend_inputs(oracle, n, h, w, c + 7, seed=3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    args = (t(xys), t(depths), t(radii), t(conics), t(nth))
+    cols, tail = t(colors[:, :c]), t(colors[:, c:])
+
+    def render():
+        P.clear_bin_cache()
+        single = P.NDRasterizeGaussians.apply(*args, cols, t(opac), h, w, t(bg[:c]))
+        P.clear_bin_cache()
+        pair = P.rasterize_segments(*args, t(opac), h, w, [(cols, t(bg[:c])), (tail, t(bg[c:]))])
+        return [single.clone(), pair[0].clone(), pair[1].clone()]
+
+    try:
+        lib.gg_debug_set_fwd_blocks(1, 1)
+        ref = render()
+        for pb, cb in ((1, 2), (1, 3), (1, 4), (2, 1), (2, 2), (4, 1), (4, 4)):
+            lib.gg_debug_set_fwd_blocks(pb, cb)
+            for name, a, b in zip(("gg_blend_fwd", "pair first array", "pair second array"), render(), ref):
+                assert torch.equal(a, b), f"{name}: blocks ({pb}, {cb}) differ from (1, 1) at C = {c}"
+    finally:
+        lib.gg_debug_set_fwd_blocks(1, 3)      # the library's defaults (csrc/blend.hip)
+    want, _ = oracle.rasterize_fwd(xys, depths, radii, conics, nth, colors[:, :c], opac, h, w, bg[:c])
+    assert_bitexact(_np(ref[0]), want, f"one-block walks vs oracle, C = {c}")
+    assert_bitexact(_np(render()[0]), want, f"default blocks vs oracle, C = {c}")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("spread", ["channels 1e-4..1e4", "pixels 1e-3..1", "colour rows 1e-3..1e3", "all tiny 1e-20",
                                     "all huge 1e15"])
 def test_pair_backward_fp16_piece_products_over_a_wide_dynamic_range(oracle, spread):

@@ -717,6 +717,9 @@ __global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_bwd_narrow_kernel(
 #ifndef GG_F16_NLL
 #define GG_F16_NLL 0       // 1: without the lo x lo piece products (2^-24 each; measured -1.5 % of the kernel: not taken)
 #endif
+#ifndef GG_MG_MOMENTS
+#define GG_MG_MOMENTS 1   // merged-flush builds: geometry sums as moments about the Gaussian's centre (0: the per-pixel form)
+#endif
 #ifndef GG_S16_F16
 #define GG_S16_F16 1    // 0: the 16-slot backward's products on v_mfma_f32_16x16x4_f32 (the build before)
 #endif
@@ -1336,8 +1339,22 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                 const float v_alpha = pass[q] ? (Tn * D - ra_ * W) : 0.0f;
                 W = pass[q] ? __builtin_fmaf(D, fac, W) : W;
                 T = pass[q] ? Tn : T;
-                const float v_sigma = pass[q] ? (-A.z * vis[q]) * v_alpha : 0.0f;
                 const float dx = A.x - px, dy = A.y - py;
+                if (MG && GG_MG_MOMENTS) {
+                    // moments about the Gaussian's own centre: sum v_sigma {dx, dy, dx^2, dx dy, dy^2}; the conic enters
+                    // AFTER the reduction, in the flush (v_x = a M0 + b M1, v_y = b M0 + c M1, conic gradients M2..4 / 2):
+                    // 5 multiplies per pair instead of 14 operations.  (Not the experiment of 3.5c: no expansion about a
+                    // distant centre, nothing cancels that did not cancel before.)
+                    const float vis_s = pass[q] ? vis[q] : 0.0f;     // (vis may be inf where the pair does not pass)
+                    const float v_sigma = (-A.z * vis_s) * v_alpha;
+                    pg[0] = v_sigma * dx;
+                    pg[1] = v_sigma * dy;
+                    pg[2] = pg[0] * dx;
+                    pg[3] = pg[0] * dy;
+                    pg[4] = pg[1] * dy;
+                    pg[5] = vis_s * v_alpha;
+                } else {
+                const float v_sigma = pass[q] ? (-A.z * vis[q]) * v_alpha : 0.0f;
                 pg[0] = v_sigma * (B.x * dx + B.y * dy);
                 pg[1] = v_sigma * (B.y * dx + B.z * dy);
                 const float hs = 0.5f * v_sigma;
@@ -1345,6 +1362,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                 pg[3] = (hs * dx) * dy;
                 pg[4] = (hs * dy) * dy;
                 pg[5] = pass[q] ? vis[q] * v_alpha : 0.0f;
+                }
                 fac_w[FIDX(g + q, lane)] = fac;   // over D: the flush reads fac from here
                 slotmask |= 1u << (g + q);
             }
@@ -1489,10 +1507,15 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                     // lanes 8..13 the geometry sum n16 - 8 (column n16 - 8): 14 floats of one 64-byte row per request
                     const int col = n16 < 8 ? 6 + n16 : n16 - 8;
                     const bool lane_on = n16 < 8 ? n16 < seg2.nch2 : n16 < 14;
+                    const int gcol = n16 & 7;   // geometry column of lanes 8..13: 0, 1 mix moments 0 and 1 with the conic
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int slot = 4 * k4 + r;
-                        const float gv = geo_w[slot * 8 + (n16 & 7)];
+                        const float4 cq = Q.b[base + slot];     // conic a, b, c
+                        const float ga = geo_w[slot * 8 + (gcol < 2 ? 0 : gcol)], gb = geo_w[slot * 8 + 1];
+                        const float ca = gcol == 0 ? cq.x : (gcol == 1 ? cq.y : (gcol == 5 ? 1.0f : 0.5f));
+                        const float cb = gcol == 0 ? cq.y : cq.z;
+                        const float gv = !GG_MG_MOMENTS ? geo_w[slot * 8 + gcol] : (gcol < 2 ? ca * ga + cb * gb : ca * ga);
                         const float val = n16 < 8 ? (F16 ? a4[r] * inv_sw : a4[r]) : gv;
                         const bool on = ((slotmask >> slot) & 1u) != 0u && lane_on;
                         if (on && val != 0.0f) {

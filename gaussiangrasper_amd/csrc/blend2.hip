@@ -1333,12 +1333,16 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                 }
                 const float4 A = REREAD ? Q.a[gi + q] : Ah[REREAD ? 0 : q], B = REREAD ? Q.b[gi + q] : Bh[REREAD ? 0 : q];
                 const float D = fac_w[FIDX(g + q, lane)];
-                const float ra_ = __builtin_amdgcn_rcpf(1.0f - alpha[q]);
+                // MG: a pair that does not pass takes alpha = 0 and exp = 0 through the SAME arithmetic instead of five
+                // selects: 1 / (1 - 0) = 1, so T and (D finite) W stay as they are and fac, v_sigma and the moments are zeros
+                constexpr bool SEL2 = MG && GG_MG_MOMENTS;
+                const float al = SEL2 ? (pass[q] ? alpha[q] : 0.0f) : alpha[q];
+                const float ra_ = __builtin_amdgcn_rcpf(1.0f - al);
                 const float Tn = T * ra_;
-                const float fac = pass[q] ? alpha[q] * Tn : 0.0f;
-                const float v_alpha = pass[q] ? (Tn * D - ra_ * W) : 0.0f;
-                W = pass[q] ? __builtin_fmaf(D, fac, W) : W;
-                T = pass[q] ? Tn : T;
+                const float fac = SEL2 ? al * Tn : (pass[q] ? alpha[q] * Tn : 0.0f);
+                const float v_alpha = SEL2 ? __builtin_fmaf(Tn, D, -(ra_ * W)) : (pass[q] ? (Tn * D - ra_ * W) : 0.0f);
+                W = SEL2 ? __builtin_fmaf(D, fac, W) : (pass[q] ? __builtin_fmaf(D, fac, W) : W);
+                T = SEL2 ? Tn : (pass[q] ? Tn : T);
                 const float dx = A.x - px, dy = A.y - py;
                 if (MG && GG_MG_MOMENTS) {
                     // moments about the Gaussian's own centre: sum v_sigma {dx, dy, dx^2, dx dy, dy^2}; the conic enters
@@ -1346,13 +1350,13 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                     // 5 multiplies per pair instead of 14 operations.  (Not the experiment of 3.5c: no expansion about a
                     // distant centre, nothing cancels that did not cancel before.)
                     const float vis_s = pass[q] ? vis[q] : 0.0f;     // (vis may be inf where the pair does not pass)
-                    const float v_sigma = (-A.z * vis_s) * v_alpha;
+                    pg[5] = vis_s * v_alpha;                          // d/d opacity
+                    const float v_sigma = -A.z * pg[5];               // (= -opacity exp v_alpha: one multiply less)
                     pg[0] = v_sigma * dx;
                     pg[1] = v_sigma * dy;
                     pg[2] = pg[0] * dx;
                     pg[3] = pg[0] * dy;
                     pg[4] = pg[1] * dy;
-                    pg[5] = vis_s * v_alpha;
                 } else {
                 const float v_sigma = pass[q] ? (-A.z * vis[q]) * v_alpha : 0.0f;
                 pg[0] = v_sigma * (B.x * dx + B.y * dy);

@@ -1350,13 +1350,13 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                     // 5 multiplies per pair instead of 14 operations.  (Not the experiment of 3.5c: no expansion about a
                     // distant centre, nothing cancels that did not cancel before.)
                     const float vis_s = pass[q] ? vis[q] : 0.0f;     // (vis may be inf where the pair does not pass)
-                    pg[5] = vis_s * v_alpha;                          // d/d opacity
-                    const float v_sigma = -A.z * pg[5];               // (= -opacity exp v_alpha: one multiply less)
+                    const float v_sigma = (-A.z * vis_s) * v_alpha;
                     pg[0] = v_sigma * dx;
                     pg[1] = v_sigma * dy;
                     pg[2] = pg[0] * dx;
                     pg[3] = pg[0] * dy;
                     pg[4] = pg[1] * dy;
+                    pg[5] = vis_s * v_alpha;
                 } else {
                 const float v_sigma = pass[q] ? (-A.z * vis[q]) * v_alpha : 0.0f;
                 pg[0] = v_sigma * (B.x * dx + B.y * dy);

@@ -717,9 +717,6 @@ __global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_bwd_narrow_kernel(
 #ifndef GG_F16_NLL
 #define GG_F16_NLL 0       // 1: without the lo x lo piece products (2^-24 each; measured -1.5 % of the kernel: not taken)
 #endif
-#ifndef GG_BWD_VOUT_NT
-#define GG_BWD_VOUT_NT 0
-#endif
 #ifndef GG_MG_MOMENTS
 #define GG_MG_MOMENTS 1   // merged-flush builds: geometry sums as moments about the Gaussian's centre (0: the per-pixel form)
 #endif
@@ -912,13 +909,6 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int pi = qy0 + 4 * hh + rr, pj = qx0 + (lane >> 3);
-                if (GG_BWD_VOUT_NT) {   // the cotangent image is read once: non-temporal
-                    typedef float f4v __attribute__((ext_vector_type(4)));
-                    const bool okp = pi < img_h && pj < img_w;
-                    const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(
-                        v_out + ((size_t)(okp ? pi : 0) * img_w + (okp ? pj : 0)) * C + ch_off + 4 * (lane & 7)));
-                    rowv[rr] = okp ? make_float4(t.x, t.y, t.z, t.w) : make_float4(0.f, 0.f, 0.f, 0.f);
-                } else
                 rowv[rr] = (pi < img_h && pj < img_w)
                                ? *reinterpret_cast<const float4 *>(v_out + ((size_t)pi * img_w + pj) * C + ch_off + 4 * (lane & 7))
                                : make_float4(0.f, 0.f, 0.f, 0.f);

@@ -51,6 +51,7 @@ SIGNATURES = {
     "gg_activate_bwd_ex": (_I, [_I] + [_P] * 7 + [_I] + [_P] * 4 + [_I, _P]),
     "gg_mlp_fwd": (_I, [_I64, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "gg_debug_set_fwd_blocks": (_I, [_I, _I]),
+    "gg_debug_set_depth_onesweep": (_I, [_I]),
     "gg_mlp_fwd_fast_workspace": (_SZ, [_I, _I, _I]),
     "gg_mlp_fwd_fast": (_I, [_I64, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gg_mlp_bwd": (_I, [_I64, _I, _I, _I] + [_P] * 11),

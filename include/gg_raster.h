@@ -314,6 +314,12 @@ int gg_mlp_fwd(int64_t num_rows, int in_dim, int hidden_dim, int out_dim, const 
                const float *w1, const float *b1, const float *w2, const float *b2, float *y,
                gg_stream_t stream);
 
+/* Tuning / test entry (round 3): 1 = the depth sort's four radix passes as one launch each (decoupled look-back over
+ * per-digit counts, csrc/binning.hip radix_os_kernel: measured slower, 0.32 against 0.28 ms for the whole binning at 1 M
+ * Gaussians), 0 = three launches per pass (the default).  Same order either way
+ * (stable LSD passes); returns the previous value. */
+int gg_debug_set_depth_onesweep(int on);
+
 /* Tuning entry (round 3): how many 32-channel blocks of a wide colour array one forward walk takes — in the pair walk
  * of gg_blend_fwd_pair (1, 2 or 4) and in the walks of the remaining chunks / of gg_blend_fwd (1..4).  Images are
  * bit-identical for every setting; returns the previous pair value.  Defaults: see csrc/blend.hip. */

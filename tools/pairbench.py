@@ -39,10 +39,13 @@ def main():
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--label", default="")
     ap.add_argument("--view", type=int, default=0)
+    ap.add_argument("--onesweep", type=int, default=None, help="gg_debug_set_depth_onesweep(0 / 1) before the runs")
     args = ap.parse_args()
     if args.lib:
         _lib.LIB_PATH = os.path.abspath(args.lib)
     lib = _lib.load(build_if_missing=False)
+    if args.onesweep is not None:
+        lib.gg_debug_set_depth_onesweep(args.onesweep)
     dev = "cuda:0"
     h, w = 1200, 1600
     sc = make_scene(args.points, config_index=3).to(dev)

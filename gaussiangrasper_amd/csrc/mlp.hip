@@ -357,6 +357,9 @@ __global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(long P, int out_dim, 
 //     after them — one barrier per slice.
 // ---------------------------------------------------------------------------------------------
 #define MLPF_THREADS 512
+#ifndef MLPF_ABL
+#define MLPF_ABL 0   // measurement builds: 1 no output stores, 2 no layer-2 MFMAs, 3 no stores and layer 2's A operands read once
+#endif
 #define MLPF_SLICE_Q 4096                        // uint4 per 64 KB slice: 8 tiles x 4 k-steps x 2 pieces x 64 lanes
 __host__ __device__ __forceinline__ int mlpf_hidden_of(int ks, int q, int j) { return 16 * (2 * ks + (j >> 2)) + 4 * q + (j & 3); }
 
@@ -421,145 +424,173 @@ __global__ __launch_bounds__(MLPF_THREADS) void mlp_fwd_f16_kernel(long P, int o
     for (int i = threadIdx.x; i < W1_Q; i += MLPF_THREADS) buf0[i] = packed[i];
     __syncthreads();
     int g = 0;   // stages done: the current stage's weights are in buffer g & 1
-    uint4 pf[PF];
-    // request a slice (W2's slice sl, or W1 for sl < 0) into registers / put it into the buffer the NEXT stage reads
+    // request a slice (W2's slice sl, or W1 for sl < 0): global_load_lds_dwordx4 copies it straight into the buffer the
+    // NEXT stage reads — 1 KB per wave and instruction (lane l: 16 bytes at base + 16 l), no registers in between (with
+    // the slice held in 32 registers per thread across a stage's MFMAs the four-block build spilled 26-57 of them).
+    // The other buffer is free: every wave passed the barrier that ended the stage which read it.
     auto request = [&](int sl) {
         const uint4 *src = sl < 0 ? packed : w2p + (size_t)sl * MLPF_SLICE_Q;
         const int n = sl < 0 ? W1_Q : min(MLPF_SLICE_Q, (out_dim - 128 * sl) / 16 * 4 * 2 * 64);
+        uint4 *dst = (g & 1) ? buf0 : buf1;
+        const int wbase = wave * 64;
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            const int i = threadIdx.x + u * MLPF_THREADS;
-            pf[u] = i < n ? src[i] : make_uint4(0u, 0u, 0u, 0u);
+            const int i0 = wbase + u * MLPF_THREADS;          // first uint4 of this wave's 1 KB (wave-uniform)
+            if (i0 < n)
+                __builtin_amdgcn_global_load_lds(src + i0 + lane, (__attribute__((address_space(3))) void *)(dst + i0), 16, 0, 0);
         }
     };
     auto deliver = [&]() {
-        uint4 *dst = (g & 1) ? buf0 : buf1;
-#pragma unroll
-        for (int u = 0; u < PF; ++u) dst[threadIdx.x + u * MLPF_THREADS] = pf[u];
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0);     // (vmcnt, lgkmcnt, expcnt = 0: the copies have landed)
+        if (MLPF_ABL != 4) __syncthreads();
         ++g;
     };
-    const long nblocks = (P + 255) / 256;
+    // NPB pixel blocks of 16 per wave and iteration: every A operand read (1 KB per piece and wave) feeds 2 NPB MFMAs.
+    // With two blocks the LDS ran at its 128 B/clk: 0.91 ms of compute against 0.60 with the A operands read once
+    // (output stores off, 32 -> 128 -> 512 at 1600x1200); four blocks halve that traffic.  Layer 1 runs on two blocks
+    // at a time (its B operands: 64 registers at 128 inputs).
+    constexpr int NPB = 4;
+    constexpr int PIX_PER_WG = (MLPF_THREADS / 64) * 16 * NPB;      // 512
+    const long nblocks = (P + PIX_PER_WG - 1) / PIX_PER_WG;
     for (long blkid = blockIdx.x; blkid < nblocks; blkid += gridDim.x) {   // (every wave runs every barrier)
-        long pix[2];
-        bool ok[2];
+        long pix[NPB];
+        bool ok[NPB];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            pix[b] = blkid * 256 + wave * 32 + 16 * b + l16;
+        for (int b = 0; b < NPB; ++b) {
+            pix[b] = blkid * PIX_PER_WG + wave * (16 * NPB) + 16 * b + l16;
             ok[b] = pix[b] < P;
         }
-        request(0);
-        // ---------------- x: scale per pixel, two fp16 pieces ---------------------------------------
-        unsigned xh[2][KS1][4], xl[2][KS1][4];
-        float inv_sx[2];
+        unsigned hh[NPB][4][4], hl[NPB][4][4];
+        float inv_sh[NPB];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            float xv[KS1][8];
-            const float *xp = x + (size_t)(ok[b] ? pix[b] : 0) * IN + 8 * q4;
-            float m = 0.0f;
+        for (int half = 0; half < NPB / 2; ++half) {
+            if (half == NPB / 2 - 1) request(0);       // (in flight during the last pair's layer 1)
+            // ---------------- x: scale per pixel, two fp16 pieces ---------------------------------------
+            unsigned xh[2][KS1][4], xl[2][KS1][4];
+            float inv_sx[2];
 #pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) {
-                const float4 v0 = *reinterpret_cast<const float4 *>(xp + 32 * ks), v1 = *reinterpret_cast<const float4 *>(xp + 32 * ks + 4);
-                const float t[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    xv[ks][j] = ok[b] ? t[j] : 0.0f;
-                    m = fmaxf(m, fabsf(xv[ks][j]));
-                }
-            }
-            const float sx = pow2_scale(mlpf_max_over_q(m));
-            inv_sx[b] = pow2_inv(sx);
-#pragma unroll
-            for (int ks = 0; ks < KS1; ++ks)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) split2h(xv[ks][2 * t] * sx, xv[ks][2 * t + 1] * sx, xh[b][ks][t], xl[b][ks][t]);
-        }
-        // ---------------- layer 1: H^T = relu(W1 X^T + b1) -------------------------------------------
-        float h[2][32];
-        {
-            const uint4 *wb = (g & 1) ? buf1 : buf0;
-#pragma unroll
-            for (int tp = 0; tp < 4; ++tp) {
-                f32x4 acc[2][2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) acc[u][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int b = 0; b < 2; ++b) {
+                const int pb = 2 * half + b;
+                float xv[KS1][8];
+                const float *xp = x + (size_t)(ok[pb] ? pix[pb] : 0) * IN + 8 * q4;
+                float m = 0.0f;
 #pragma unroll
                 for (int ks = 0; ks < KS1; ++ks) {
+                    const float4 v0 = *reinterpret_cast<const float4 *>(xp + 32 * ks), v1 = *reinterpret_cast<const float4 *>(xp + 32 * ks + 4);
+                    const float t[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const uint4 ah = wb[(((2 * tp + u) * KS1 + ks) * 2) * 64 + lane], al = wb[(((2 * tp + u) * KS1 + ks) * 2 + 1) * 64 + lane];
-                        const h16x8 Ah = H8(ah.x, ah.y, ah.z, ah.w), Al = H8(al.x, al.y, al.z, al.w);
-#pragma unroll
-                        for (int b = 0; b < 2; ++b) {
-                            const h16x8 Bh = H8(xh[b][ks][0], xh[b][ks][1], xh[b][ks][2], xh[b][ks][3]);
-                            const h16x8 Bl = H8(xl[b][ks][0], xl[b][ks][1], xl[b][ks][2], xl[b][ks][3]);
-                            acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bl, acc[u][b], 0, 0, 0);
-                            acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh, acc[u][b], 0, 0, 0);
-                            acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl, acc[u][b], 0, 0, 0);
-                            acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh, acc[u][b], 0, 0, 0);
-                        }
+                    for (int j = 0; j < 8; ++j) {
+                        xv[ks][j] = ok[pb] ? t[j] : 0.0f;
+                        m = fmaxf(m, fabsf(xv[ks][j]));
                     }
                 }
+                const float sx = pow2_scale(mlpf_max_over_q(m));
+                inv_sx[b] = pow2_inv(sx);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int m0 = 16 * (2 * tp + u) + 4 * q4;       // hidden units m0 .. m0 + 3
-                    const float4 bi = *reinterpret_cast<const float4 *>(b1s + m0), iv = *reinterpret_cast<const float4 *>(i1s + m0);
-                    const float bb[4] = {bi.x, bi.y, bi.z, bi.w}, ii[4] = {iv.x, iv.y, iv.z, iv.w};
+                for (int ks = 0; ks < KS1; ++ks)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b)
+                    for (int t = 0; t < 4; ++t) split2h(xv[ks][2 * t] * sx, xv[ks][2 * t + 1] * sx, xh[b][ks][t], xl[b][ks][t]);
+            }
+            // ---------------- layer 1: H^T = relu(W1 X^T + b1) -------------------------------------------
+            float h[2][32];
+            {
+                const uint4 *wb = (g & 1) ? buf1 : buf0;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            h[b][4 * (2 * tp + u) + r] = fmaxf(__builtin_fmaf(acc[u][b][r], ii[r] * inv_sx[b], bb[r]), 0.0f);
+                for (int tp = 0; tp < 4; ++tp) {
+                    f32x4 acc[2][2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) acc[u][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int ks = 0; ks < KS1; ++ks) {
+                        h16x8 Ah[2], Al[2], Bh[2], Bl[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const uint4 ah = wb[(((2 * tp + u) * KS1 + ks) * 2) * 64 + lane], al = wb[(((2 * tp + u) * KS1 + ks) * 2 + 1) * 64 + lane];
+                            Ah[u] = H8(ah.x, ah.y, ah.z, ah.w);
+                            Al[u] = H8(al.x, al.y, al.z, al.w);
+                            Bh[u] = H8(xh[u][ks][0], xh[u][ks][1], xh[u][ks][2], xh[u][ks][3]);      // (u doubles as the pixel block)
+                            Bl[u] = H8(xl[u][ks][0], xl[u][ks][1], xl[u][ks][2], xl[u][ks][3]);
+                        }
+#pragma unroll
+                        for (int pr = 0; pr < 4; ++pr)
+#pragma unroll
+                            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                                for (int b = 0; b < 2; ++b)
+                                    acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16((pr >> 1) ? Ah[u] : Al[u], (pr & 1) ? Bh[b] : Bl[b],
+                                                                                       acc[u][b], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int m0 = 16 * (2 * tp + u) + 4 * q4;       // hidden units m0 .. m0 + 3
+                        const float4 bi = *reinterpret_cast<const float4 *>(b1s + m0), iv = *reinterpret_cast<const float4 *>(i1s + m0);
+                        const float bb[4] = {bi.x, bi.y, bi.z, bi.w}, ii[4] = {iv.x, iv.y, iv.z, iv.w};
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                h[b][4 * (2 * tp + u) + r] = fmaxf(__builtin_fmaf(acc[u][b][r], ii[r] * inv_sx[b], bb[r]), 0.0f);
+                    }
                 }
+            }
+            // ---------------- hidden: second scale per pixel, two fp16 pieces ----------------------------
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int pb = 2 * half + b;
+                float m = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) m = fmaxf(m, h[b][i]);
+                const float sh = pow2_scale(mlpf_max_over_q(m));
+                inv_sh[pb] = pow2_inv(sh);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        split2h(h[b][8 * ks + 2 * t] * sh, h[b][8 * ks + 2 * t + 1] * sh, hh[pb][ks][t], hl[pb][ks][t]);
             }
         }
         deliver();
-        // ---------------- hidden: second scale per pixel, two fp16 pieces ----------------------------
-        unsigned hh[2][4][4], hl[2][4][4];
-        float inv_sh[2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            float m = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 32; ++i) m = fmaxf(m, h[b][i]);
-            const float sh = pow2_scale(mlpf_max_over_q(m));
-            inv_sh[b] = pow2_inv(sh);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    split2h(h[b][8 * ks + 2 * t] * sh, h[b][8 * ks + 2 * t + 1] * sh, hh[b][ks][t], hl[b][ks][t]);
-        }
         // ---------------- layer 2, slice by slice ------------------------------------------------------
         for (int sl = 0; sl < nsl; ++sl) {
             request(sl + 1 < nsl ? sl + 1 : -1);       // (after the last slice: W1 for the next iteration)
             const uint4 *wb = (g & 1) ? buf1 : buf0;
             const int nt = min(8, (out_dim - 128 * sl) >> 4);
             for (int tp = 0; 2 * tp < nt; ++tp) {
-                f32x4 acc[2][2];
+                f32x4 acc[2][NPB];
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) acc[u][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    for (int b = 0; b < NPB; ++b) acc[u][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
+                    h16x8 Ah[2], Al[2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int tile = min(2 * tp + u, nt - 1);
-                        const uint4 ah = wb[((tile * 4 + ks) * 2) * 64 + lane], al = wb[((tile * 4 + ks) * 2 + 1) * 64 + lane];
-                        const h16x8 Ah = H8(ah.x, ah.y, ah.z, ah.w), Al = H8(al.x, al.y, al.z, al.w);
-#pragma unroll
-                        for (int b = 0; b < 2; ++b) {
-                            const h16x8 Bh = H8(hh[b][ks][0], hh[b][ks][1], hh[b][ks][2], hh[b][ks][3]);
-                            const h16x8 Bl = H8(hl[b][ks][0], hl[b][ks][1], hl[b][ks][2], hl[b][ks][3]);
-                            acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bl, acc[u][b], 0, 0, 0);
-                            acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh, acc[u][b], 0, 0, 0);
-                            acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl, acc[u][b], 0, 0, 0);
-                            acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh, acc[u][b], 0, 0, 0);
-                        }
+                        const int aidx = MLPF_ABL == 3 ? 0 : ((tile * 4 + ks) * 2) * 64;     // (3: the A operands read once)
+                        const uint4 ah = wb[aidx + lane], al = wb[aidx + 64 + lane];
+                        Ah[u] = H8(ah.x, ah.y, ah.z, ah.w);
+                        Al[u] = H8(al.x, al.y, al.z, al.w);
                     }
+                    if (MLPF_ABL == 2) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int b = 0; b < NPB; ++b) acc[u][b][0] += (float)Ah[u][0] + (float)Al[u][1] + __builtin_bit_cast(float, hh[b][ks][0]);
+                        continue;
+                    }
+#pragma unroll
+                    for (int pr = 0; pr < 4; ++pr)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int b = 0; b < NPB; ++b) {
+                                const h16x8 Bp = (pr & 1) ? H8(hh[b][ks][0], hh[b][ks][1], hh[b][ks][2], hh[b][ks][3])
+                                                          : H8(hl[b][ks][0], hl[b][ks][1], hl[b][ks][2], hl[b][ks][3]);
+                                acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16((pr >> 1) ? Ah[u] : Al[u], Bp, acc[u][b], 0, 0, 0);
+                            }
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -567,13 +598,14 @@ __global__ __launch_bounds__(MLPF_THREADS) void mlp_fwd_f16_kernel(long P, int o
                     const int m0 = 128 * sl + 16 * (2 * tp + u) + 4 * q4;   // outputs m0 .. m0 + 3
                     const float4 bi = *reinterpret_cast<const float4 *>(b2s + m0), iv = *reinterpret_cast<const float4 *>(i2s + m0);
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) {
+                    for (int b = 0; b < NPB; ++b) {
                         if (!ok[b]) continue;
                         float4 o;
                         o.x = __builtin_fmaf(acc[u][b][0], iv.x * inv_sh[b], bi.x);
                         o.y = __builtin_fmaf(acc[u][b][1], iv.y * inv_sh[b], bi.y);
                         o.z = __builtin_fmaf(acc[u][b][2], iv.z * inv_sh[b], bi.z);
                         o.w = __builtin_fmaf(acc[u][b][3], iv.w * inv_sh[b], bi.w);
+                        if (MLPF_ABL == 1 || MLPF_ABL == 3 || MLPF_ABL == 4) { asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w)); continue; }
                         *reinterpret_cast<float4 *>(y + (size_t)pix[b] * out_dim + m0) = o;
                     }
                 }
@@ -612,7 +644,7 @@ extern "C" int gg_mlp_fwd_fast(int64_t num_rows, int in_dim, int hidden_dim, int
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
-    const long nblocks = (num_rows + 255) / 256;
+    const long nblocks = (num_rows + 511) / 512;      // 512 pixels per workgroup iteration (mlp_fwd_f16_kernel: NPB)
     const int grid = (int)(nblocks < cus ? nblocks : cus);
     const size_t lds_bytes = sizeof(uint4) * 2 * MLPF_SLICE_Q + sizeof(float) * (size_t)(2 * MLP_HID + 2 * out_dim);
     hipError_t e = hipSuccess;

@@ -3,7 +3,7 @@
 pixels, 32 -> 128 -> 512, fp32 results.  Since r03 the default forward (gg_mlp_fwd_fast: fp16 two-piece operands on
 the 16x-rate matrix instruction) needs a quarter of the matrix cycles of the fp32 kernel and is bound by its 3.9 GB of
 OUTPUT: `roofline` is the HBM one (bytes read + written over time against 8 TB/s; a plain fill of the same size runs
-at ~2.9 TB/s on this chip), `mfma_fp32_equivalent` what the old bound would have said; `--exact` times the
+at 6.8 TB/s on this chip: DESIGN 3.7 has the ablations), `mfma_fp32_equivalent` what the old bound would have said; `--exact` times the
 exact-order fp32 kernel (gg_mlp_fwd).  Times with the in-library hipEvents, torch's
 Linear/ReLU/Linear (the reference's implementation, on the same GPU) with torch events, and the CPU
 oracle on a bounded sample.  Prints one JSON line."""

@@ -1334,6 +1334,69 @@ def test_pair_backward_fp16_piece_products_over_a_wide_dynamic_range(oracle, spr
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_pair_backward_degenerate_operands(oracle, seed):
+    """Operands the scaled fp16 pieces must not stumble over: Gaussians whose whole colour row is zero, quadrants (and
+    whole tiles) with zero cotangents, one channel that is zero everywhere, a ragged image — gradients within the blend
+    tolerance of the oracle; then one NaN cotangent pixel: the call completes, the NaN stays with the Gaussians that reach
+    that pixel's tile, every other Gaussian's gradients equal the clean run's bit for bit (deterministic mode off: within
+    the atomics' reordering noise)."""
+    n, h, w, c, c2 = 3000, 67, 93, 32, 7
+    xys, depths, radii, conics, nth, colors, opac, bg = _blend_inputs(oracle, n, h, w, c + c2, seed=100 + seed)
+    rng = np.random.default_rng(seed)
+    colors = colors.copy()
+    colors[rng.random(n) < 0.2] = 0.0                      # zero colour rows (both arrays)
+    colors[:, 5] = 0.0                                     # a dead channel
+    v = rng.standard_normal((h, w, c + c2)).astype(np.float32)
+    v[:, :, 9] = 0.0
+    for _ in range(12):                                    # zero 8x8 quadrants / 16x16 tiles
+        y0, x0, sz = int(rng.integers(0, h)), int(rng.integers(0, w)), int(rng.choice([8, 16]))
+        v[(y0 // sz) * sz:(y0 // sz + 1) * sz, (x0 // sz) * sz:(x0 // sz + 1) * sz, :] = 0.0
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    segs = [(colors[:, :c], bg[:c]), (colors[:, c:], bg[c:])]
+
+    def run(vv):
+        xt, ct, ot = t(xys).requires_grad_(True), t(conics).requires_grad_(True), t(opac).requires_grad_(True)
+        cts = [t(col).requires_grad_(True) for col, _ in segs]
+        P.clear_bin_cache()
+        imgs = P.rasterize_segments(xt, t(depths), t(radii), ct, t(nth), ot, h, w,
+                                    [(cts[i], t(segs[i][1])) for i in range(2)])
+        torch.autograd.backward(imgs, [t(vv[..., :c]), t(vv[..., c:])])
+        return [_np(g.grad) for g in (xt, ct, ot, cts[0], cts[1])]
+
+    got = run(v)
+    ref = None
+    for (col, b), vv in zip(segs, (v[..., :c], v[..., c:])):
+        out, saved = oracle.rasterize_fwd(xys, depths, radii, conics, nth, col, opac, h, w, b)
+        bb = saved["bins"]
+        g = oracle.blend_bwd(bb["gaussian_ids_sorted"], bb["tile_bins"], xys, conics, col, opac, h, w, b,
+                             saved["final_Ts"], saved["final_idx"], np.ascontiguousarray(vv))
+        ref = [g[0].astype(np.float64), g[1].astype(np.float64), [g[2]], g[3].astype(np.float64)] if ref is None \
+            else [ref[0] + g[0], ref[1] + g[1], ref[2] + [g[2]], ref[3] + g[3]]
+    assert_close(got[0], ref[0], "degenerate.v_xy", rtol=5e-5, atol_frac=1e-6)
+    assert_close(got[1], ref[1], "degenerate.v_conic", rtol=5e-5, atol_frac=1e-6)
+    assert_close(got[2], ref[3].reshape(got[2].shape), "degenerate.v_opacity", rtol=5e-5, atol_frac=1e-6)
+    assert_close(got[3], ref[2][0], "degenerate.v_colors[0]", rtol=5e-5, atol_frac=1e-6)
+    assert_close(got[4], ref[2][1], "degenerate.v_colors[1]", rtol=5e-5, atol_frac=1e-6)
+    assert np.all(got[3][:, 9] == 0.0)          # (the channel whose cotangent is zero everywhere)
+    # one NaN cotangent: stays local
+    v2 = v.copy()
+    py, px = h // 2, w // 2
+    v2[py, px, 3] = np.nan
+    bad = run(v2)
+    bins = saved["bins"]
+    tile = (py // 16) * ((w + 15) // 16) + px // 16
+    lo, hi = np.asarray(bins["tile_bins"]).reshape(-1, 2)[tile]
+    touched = np.zeros(n, bool)
+    touched[np.asarray(bins["gaussian_ids_sorted"])[lo:hi]] = True
+    for a, b_ in zip(bad, got):
+        a2, b2 = a.reshape(n, -1), b_.reshape(n, -1)
+        assert np.isfinite(a2[~touched]).all()
+        assert np.allclose(a2[~touched], b2[~touched], rtol=1e-4, atol=2e-6 * np.abs(b2).max())
+    assert not np.isfinite(bad[3].reshape(n, -1)[touched]).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("c,c2", [(32, 1), (32, 8), (35, 4), (64, 7), (33, 2)])
 def test_pair_kernels_channel_counts(oracle, c, c2):
     """gg_blend_fwd_pair / gg_blend_bwd_pair for 1..8 rider channels and first arrays of 32, 33, 35 and 64 channels

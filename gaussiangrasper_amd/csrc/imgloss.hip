@@ -56,19 +56,33 @@ __global__ __launch_bounds__(256) void image_loss_fwd_kernel(int H, int W, const
     const int Ho = H - IL_WIN + 1, Wo = W - IL_WIN + 1;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int x0 = blockIdx.x * IL_T, y0 = blockIdx.y * IL_T;
-    for (int idx = tid; idx < IL_IN * IL_IN; idx += 256) {
-        const int r = idx / IL_IN, c = idx - r * IL_IN;
-        const int y = y0 + r, x = x0 + c;
-        float vx[3] = {0.f, 0.f, 0.f}, vy[3] = {0.f, 0.f, 0.f};
-        if (y < H && x < W) {
-            const size_t p = (size_t)y * W + x;
-            if (!valid || valid[p]) {
+    {   // the six loads of each of a thread's three window points requested together (the validity byte first: it is
+        // NOT a condition of the loads, only of what is kept)
+        constexpr int NPT = (IL_IN * IL_IN + 255) / 256;
+        float vx[NPT][3], vy[NPT][3];
+        bool keep[NPT];
+        int rr[NPT], cc[NPT];
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) { vx[ch] = gt[3 * p + ch]; vy[ch] = rgb[(size_t)rs * p + ch]; }
-            }
+        for (int k = 0; k < NPT; ++k) {
+            const int idx = tid + 256 * k;
+            const int r = idx / IL_IN, c = idx - r * IL_IN;
+            rr[k] = r; cc[k] = c;
+            const int y = y0 + r, x = x0 + c;
+            const bool in = idx < IL_IN * IL_IN && y < H && x < W;
+            const size_t p = in ? (size_t)y * W + x : 0;
+            keep[k] = in && (!valid || valid[p]);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { vx[k][ch] = gt[3 * p + ch]; vy[k][ch] = rgb[(size_t)rs * p + ch]; }
         }
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) { sx[ch][r][c] = vx[ch]; sy[ch][r][c] = vy[ch]; }
+        for (int k = 0; k < NPT; ++k)
+            if (tid + 256 * k < IL_IN * IL_IN) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    sx[ch][rr[k]][cc[k]] = keep[k] ? vx[k][ch] : 0.0f;
+                    sy[ch][rr[k]][cc[k]] = keep[k] ? vy[k][ch] : 0.0f;
+                }
+            }
     }
     // L1 over this tile's own 16 x 16 input pixels (the masked images are zero where invalid, but so is the
     // difference only if both are masked: count validity explicitly)
@@ -174,24 +188,41 @@ __global__ __launch_bounds__(256) void image_loss_bwd_kernel(int H, int W, const
                                                              const double *__restrict__ header,
                                                              const float *__restrict__ maps,
                                                              float *__restrict__ v_rgb) {
-    __shared__ float sg[9][IL_IN][IL_IN + 1];          // the maps around the tile (zero outside their domain)
-    __shared__ float hb[9][IL_IN][IL_T + 1];
+    // one workgroup per (tile, colour channel) — blockIdx.z: its three maps are 13.7 KB of LDS instead of 41 KB for all
+    // nine, so eight workgroups fit a CU instead of three (r03: occupancy 33 %, VALUBusy 41 % with the nine together)
+    __shared__ float sg[3][IL_IN][IL_IN + 1];          // the channel's maps around the tile (zero outside their domain)
+    __shared__ float hb[3][IL_IN][IL_T + 1];
     const int Ho = H - IL_WIN + 1, Wo = W - IL_WIN + 1;
     const size_t plane = (size_t)Ho * Wo;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int x0 = blockIdx.x * IL_T, y0 = blockIdx.y * IL_T;
+    const int x0 = blockIdx.x * IL_T, y0 = blockIdx.y * IL_T, ch = blockIdx.z;
     // pixel (y, x) gathers the outputs (y - a, x - b), a, b in 0..10: window origin (y0 - 10, x0 - 10)
-    for (int idx = tid; idx < IL_IN * IL_IN; idx += 256) {
-        const int r = idx / IL_IN, c = idx - r * IL_IN;
-        const int i = y0 - (IL_WIN - 1) + r, j = x0 - (IL_WIN - 1) + c;
-        const bool in = i >= 0 && i < Ho && j >= 0 && j < Wo;
-        const size_t o = in ? (size_t)i * Wo + j : 0;
+    {   // all loads of a thread's three window points in flight before the first is used (r03: one point at a time
+        // was three L2 round trips per workgroup)
+        constexpr int NPT = (IL_IN * IL_IN + 255) / 256;
+        float tv[NPT][3];
+        int rr[NPT], cc[NPT];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) sg[q][r][c] = in ? maps[q * plane + o] : 0.0f;
+        for (int k = 0; k < NPT; ++k) {
+            const int idx = tid + 256 * k;
+            const int r = idx / IL_IN, c = idx - r * IL_IN;
+            rr[k] = r; cc[k] = c;
+            const int i = y0 - (IL_WIN - 1) + r, j = x0 - (IL_WIN - 1) + c;
+            const bool in = idx < IL_IN * IL_IN && i >= 0 && i < Ho && j >= 0 && j < Wo;
+            const size_t o = in ? (size_t)i * Wo + j : 0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) tv[k][q] = in ? maps[(3 * ch + q) * plane + o] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < NPT; ++k)
+            if (tid + 256 * k < IL_IN * IL_IN) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) sg[q][rr[k]][cc[k]] = tv[k][q];
+            }
     }
     __syncthreads();
     // rows: h[r][tx] = sum_b w[b] g[r][x - b]  (window column of x - b: tx + 10 - b)
-    for (int idx = tid; idx < 9 * IL_IN * IL_T; idx += 256) {
+    for (int idx = tid; idx < 3 * IL_IN * IL_T; idx += 256) {
         const int q = idx / (IL_IN * IL_T), rem = idx - q * (IL_IN * IL_T);
         const int r = rem / IL_T, c = rem - r * IL_T;
         float acc = 0.f;
@@ -210,23 +241,20 @@ __global__ __launch_bounds__(256) void image_loss_bwd_kernel(int H, int W, const
     const float vm = v_main[0];
     const float ks = -ssim_lambda * vm / (float)(3.0 * Ho * Wo);
     const float kl = (1 - ssim_lambda) * vm / (float)header[2];
+    if (!ok) { v_rgb[3 * p + ch] = 0.0f; return; }
+    float G[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        if (!ok) { v_rgb[3 * p + ch] = 0.0f; continue; }
-        float G[3] = {0.f, 0.f, 0.f};
+    for (int a = 0; a < IL_WIN; ++a) {
+        const int i = y - a;
+        if (i < 0 || i >= Ho) continue;
+        const float w = win.w[a];
 #pragma unroll
-        for (int a = 0; a < IL_WIN; ++a) {
-            const int i = y - a;
-            if (i < 0 || i >= Ho) continue;
-            const float w = win.w[a];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) G[k] += w * hb[3 * ch + k][ty + (IL_WIN - 1) - a][tx];
-        }
-        const float Y = rgb[(size_t)rs * p + ch], X = gt[3 * p + ch];
-        const float d = Y - X;
-        const float sgn = d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.0f);
-        v_rgb[3 * p + ch] = ks * (G[0] + 2 * Y * G[1] + X * G[2]) + kl * sgn;
+        for (int k = 0; k < 3; ++k) G[k] += w * hb[k][ty + (IL_WIN - 1) - a][tx];
     }
+    const float Y = rgb[(size_t)rs * p + ch], X = gt[3 * p + ch];
+    const float d = Y - X;
+    const float sgn = d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.0f);
+    v_rgb[3 * p + ch] = ks * (G[0] + 2 * Y * G[1] + X * G[2]) + kl * sgn;
 }
 
 static IlWindow il_window() {
@@ -288,7 +316,7 @@ extern "C" int gg_image_loss_bwd(int H, int W, const float *rgb, int rgb_pixel_s
     const double *header = (const double *)ws;
     const size_t nblk = il_blocks(H, W);
     const float *maps = (const float *)((const char *)ws + gg_align_up(sizeof(double) * (IL_HEADER + 3 * nblk), 256));
-    const dim3 grid((W + IL_T - 1) / IL_T, (H + IL_T - 1) / IL_T);
+    const dim3 grid((W + IL_T - 1) / IL_T, (H + IL_T - 1) / IL_T, 3);
     hipLaunchKernelGGL(image_loss_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, rgb, rgb_pixel_stride,
                        gt, valid, il_window(), ssim_lambda, v_main, header, maps, v_rgb);
     GG_CHECK_LAUNCH();

@@ -26,9 +26,14 @@ def timed(fn, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--lib", default=None, help="A/B: another build of the library")
     ap.add_argument("--height", type=int, default=1200)
     ap.add_argument("--width", type=int, default=1600)
     a = ap.parse_args()
+    if a.lib:
+        from gaussiangrasper_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(a.lib)
+        _lib.load(build_if_missing=False)
     dev = torch.device("cuda:0")
     h, w = a.height, a.width
     g = torch.Generator(device="cpu").manual_seed(0)

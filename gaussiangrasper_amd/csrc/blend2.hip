@@ -717,6 +717,15 @@ __global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_bwd_narrow_kernel(
 #ifndef GG_F16_NLL
 #define GG_F16_NLL 0       // 1: without the lo x lo piece products (2^-24 each; measured -1.5 % of the kernel: not taken)
 #endif
+// quadrants without any cotangent of the first array (feat_any, below): skip its flush (measured: training iteration
+// -1.6 %, dense bench view +-0) / also its colour rows and D k-steps (dense bench view +4 %, training iteration +-0: the
+// branches keep the compiler from running the two arrays' D k-steps together) — the second is off
+#ifndef GG_FEATANY_D
+#define GG_FEATANY_D 0
+#endif
+#ifndef GG_FEATANY_FLUSH
+#define GG_FEATANY_FLUSH 1
+#endif
 #ifndef GG_MG_MOMENTS
 #define GG_MG_MOMENTS 1   // merged-flush builds: geometry sums as moments about the Gaussian's centre (0: the per-pixel form)
 #endif
@@ -1013,11 +1022,22 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     // F16: s_w from the largest |cotangent| of the quadrant — every element of the first array's tile is in exactly one
     // lane's va16, every element of the second array's in one lane's t8
     float mloc = 0.0f;
+    // feat_any (wave-uniform): does the quadrant's cotangent of THIS array have a non-zero (or NaN) element at all?  The
+    // reference's training loss reaches the feature image at <= 2 600 sampled pixels of 1.9 M (gaussian_splatting.py:
+    // 909-918): nine quadrants in ten have none, and for them a batch's flush of this array is skipped (its colour
+    // gradients are exactly zero; GG_FEATANY_* above)
+    bool feat_any = true;
     if (F16) {
+        bool nz = false;
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk)
 #pragma unroll
-            for (int t = 0; t < 8; ++t) mloc = fmaxf(mloc, fabsf(va16[F16 ? blk : 0][F16 ? t : 0]));
+            for (int t = 0; t < 8; ++t) {
+                const float v = va16[F16 ? blk : 0][F16 ? t : 0];
+                mloc = fmaxf(mloc, fabsf(v));
+                nz = nz || (v != 0.0f);
+            }
+        feat_any = __ballot(nz) != 0ull;
     }
     auto tile_scale = [&]() {
         for (int off = 32; off > 0; off >>= 1) mloc = fmaxf(mloc, __shfl_xor(mloc, off, 64));
@@ -1140,7 +1160,11 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         if (S16) {   // D[64 pixels x 16 slots] as 4 x 10 v_mfma_f32_16x16x4_f32
             const int q4 = lane >> 4;
             const float *row = colors + (size_t)(cgid < 0 ? 0 : cgid) * C + ch_off + 8 * q4;
-            const float4 c0 = *reinterpret_cast<const float4 *>(row), c1 = *reinterpret_cast<const float4 *>(row + 4);
+            float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
+            if (feat_any || !GG_FEATANY_D) {
+                c0 = *reinterpret_cast<const float4 *>(row);
+                c1 = *reinterpret_cast<const float4 *>(row + 4);
+            }
             const float colb[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
             float colb2[2] = {0.0f, 0.0f};
             float va2[4][2];
@@ -1176,9 +1200,11 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
 #endif
                 const float sg = cgid < 0 ? 0.0f : pow2_scale(m);   // (null slot: every operand 0)
                 const float unscale = pow2_inv(cgid < 0 ? 1.0f : sg) * inv_sw;
-                unsigned ch_[4], cl_[4];
+                unsigned ch_[4] = {0u, 0u, 0u, 0u}, cl_[4] = {0u, 0u, 0u, 0u};
+                if (feat_any || !GG_FEATANY_D) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) split2h(colb[2 * t] * sg, colb[2 * t + 1] * sg, ch_[t], cl_[t]);
+                    for (int t = 0; t < 4; ++t) split2h(colb[2 * t] * sg, colb[2 * t + 1] * sg, ch_[t], cl_[t]);
+                }
                 const h16x8 Bh = H8(ch_[0], ch_[1], ch_[2], ch_[3]), Bl = H8(cl_[0], cl_[1], cl_[2], cl_[3]);
                 const float b2[2] = {colb2[0] * sg, colb2[1] * sg};   // (zeros without a second array)
 #pragma unroll
@@ -1187,12 +1213,14 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                     const h16x8 Ah = H8(vah[bb][0], vah[bb][F16 ? 1 : 0], vah[bb][F16 ? 2 : 0], vah[bb][F16 ? 3 : 0]);
                     const h16x8 Al = H8(val[bb][0], val[bb][F16 ? 1 : 0], val[bb][F16 ? 2 : 0], val[bb][F16 ? 3 : 0]);
                     d[blk] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    if (feat_any || !GG_FEATANY_D) {
 #if !GG_F16_NLL
-                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bl, d[blk], 0, 0, 0);
+                        d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bl, d[blk], 0, 0, 0);
 #endif
-                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh, d[blk], 0, 0, 0);
-                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl, d[blk], 0, 0, 0);
-                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh, d[blk], 0, 0, 0);
+                        d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh, d[blk], 0, 0, 0);
+                        d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl, d[blk], 0, 0, 0);
+                        d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh, d[blk], 0, 0, 0);
+                    }
                     if (EX) {
 #pragma unroll
                         for (int t = 0; t < 2; ++t)   // the second array's channels: fp32 k-steps on operands carrying s_w, s_g
@@ -1405,7 +1433,9 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
             int sl = lane & 15, q4 = lane >> 4;
             asm volatile("" : "+v"(sl), "+v"(q4));
             f32x4 acc2[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
-            if (F16) {   // A: FAC[slot sl][pixel 32 ks + 8 q4 + 0..7] x 2^15 in two pieces; 2 x 2 x 4 v_mfma_f32_16x16x32_f16
+            if (F16 && !feat_any && GG_FEATANY_FLUSH) {
+                // (no cotangent of this array in the quadrant: its colour gradients are zeros — nothing to add)
+            } else if (F16) {   // A: FAC[slot sl][pixel 32 ks + 8 q4 + 0..7] x 2^15 in two pieces; 2 x 2 x 4 v_mfma_f32_16x16x32_f16
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     unsigned fh[4], fl[4];
@@ -1440,6 +1470,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
             }
             }
             // lane holds channel 16 nb + sl of slots 4 q4 + r
+            if (!F16 || feat_any || !GG_FEATANY_FLUSH)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll

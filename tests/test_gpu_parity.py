@@ -1334,6 +1334,47 @@ def test_pair_backward_fp16_piece_products_over_a_wide_dynamic_range(oracle, spr
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("c2", [7, 3])
+def test_pair_backward_with_the_training_loss_sparse_feature_cotangent(oracle, c2):
+    """In training the feature image's cotangent is non-zero at a few thousand sampled pixels (reference
+    gaussian_splatting.py:909-918) while rgb / depth / normal cotangents are dense: the 16-slot pair backward skips the
+    first array's flush in quadrants without any (csrc/blend2.hip feat_any).  Feature cotangent at 60 random
+    pixels of a 96 x 120 image (most quadrants empty), one of them NaN-free but tiny: all gradients within the blend
+    tolerance of the oracle, feature-colour gradients of Gaussians that reach no sampled pixel exactly zero."""
+    n, h, w, c = 4000, 96, 120, 32
+    xys, depths, radii, conics, nth, colors, opac, bg = _blend_inputs(oracle, n, h, w, c + c2, seed=41)
+    rng = np.random.default_rng(c2)
+    v = rng.standard_normal((h, w, c + c2)).astype(np.float32)
+    keep = np.zeros((h, w), bool)
+    keep[rng.integers(0, h, 60), rng.integers(0, w, 60)] = True
+    v[..., :c] *= keep[..., None]
+    v[np.nonzero(keep)[0][0], np.nonzero(keep)[1][0], :c] *= 1e-12
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    segs = [(colors[:, :c], bg[:c]), (colors[:, c:], bg[c:])]
+    ref = None
+    for (col, b), vv in zip(segs, (v[..., :c], v[..., c:])):
+        out, saved = oracle.rasterize_fwd(xys, depths, radii, conics, nth, col, opac, h, w, b)
+        bb = saved["bins"]
+        g = oracle.blend_bwd(bb["gaussian_ids_sorted"], bb["tile_bins"], xys, conics, col, opac, h, w, b,
+                             saved["final_Ts"], saved["final_idx"], np.ascontiguousarray(vv))
+        ref = [g[0].astype(np.float64), g[1].astype(np.float64), [g[2]], g[3].astype(np.float64)] if ref is None \
+            else [ref[0] + g[0], ref[1] + g[1], ref[2] + [g[2]], ref[3] + g[3]]
+    xt, ct, ot = t(xys).requires_grad_(True), t(conics).requires_grad_(True), t(opac).requires_grad_(True)
+    cts = [t(col).requires_grad_(True) for col, _ in segs]
+    P.clear_bin_cache()
+    imgs = P.rasterize_segments(xt, t(depths), t(radii), ct, t(nth), ot, h, w,
+                                [(cts[i], t(segs[i][1])) for i in range(2)])
+    torch.autograd.backward(imgs, [t(v[..., :c]), t(v[..., c:])])
+    assert_close(_np(xt.grad), ref[0], "sparse feature cotangent.v_xy", rtol=5e-5, atol_frac=1e-6)
+    assert_close(_np(ct.grad), ref[1], "sparse feature cotangent.v_conic", rtol=5e-5, atol_frac=1e-6)
+    assert_close(_np(ot.grad), ref[3].reshape(_np(ot.grad).shape), "sparse feature cotangent.v_opacity", rtol=5e-5, atol_frac=1e-6)
+    for i in range(2):
+        assert_close(_np(cts[i].grad), ref[2][i], f"sparse feature cotangent.v_colors[{i}]", rtol=5e-5, atol_frac=1e-6)
+    untouched = np.all(ref[2][0] == 0.0, axis=1)
+    assert untouched.sum() > n // 4 and np.all(_np(cts[0].grad)[untouched] == 0.0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_pair_backward_degenerate_operands(oracle, seed):
     """Operands the scaled fp16 pieces must not stumble over: Gaussians whose whole colour row is zero, quadrants (and

@@ -49,10 +49,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--skip-torch", action="store_true", help="only the fused variant (clean kernel profiles)")
+    ap.add_argument("--lib", default=None, help="A/B: another build of the library")
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--height", type=int, default=1200)
     ap.add_argument("--width", type=int, default=1600)
     a = ap.parse_args()
+    if a.lib:
+        from gaussiangrasper_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(a.lib)
+        _lib.load(build_if_missing=False)
     dev = torch.device("cuda:0")
     h, w = a.height, a.width
     scene = make_scene(a.points, config_index=3).to(dev)

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgg_raster.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _P, _I, _F, _I64, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 
@@ -51,7 +51,6 @@ SIGNATURES = {
     "gg_activate_bwd_ex": (_I, [_I] + [_P] * 7 + [_I] + [_P] * 4 + [_I, _P]),
     "gg_mlp_fwd": (_I, [_I64, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "gg_debug_set_fwd_blocks": (_I, [_I, _I]),
-    "gg_debug_set_depth_onesweep": (_I, [_I]),
     "gg_mlp_fwd_fast_workspace": (_SZ, [_I, _I, _I]),
     "gg_mlp_fwd_fast": (_I, [_I64, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gg_mlp_bwd": (_I, [_I64, _I, _I, _I] + [_P] * 11),
@@ -79,10 +78,6 @@ SIGNATURES = {
     "gg_shade_tail_bwd": (_I, [_I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P]),
     "gg_blend_bwd_pair": (_I, [_I, _I, _I, _I, _I] + [_P] * 12 + [C.POINTER(_P), C.POINTER(_I), _I] + [_P] * 5
                           + [_I, _I, _I, _P, _SZ, _I, _P]),
-    "gg_quad_lists_workspace": (_SZ, [_I64, _I, _I]),
-    "gg_blend_fwd_pair_lists": (_I, [_I, _I, _I, _I, _I] + [_P] * 14 + [_SZ, _I64, _P, _SZ, _P]),
-    "gg_blend_bwd_pair_lists": (_I, [_I, _I, _I, _I, _I] + [_P] * 12 + [C.POINTER(_P), C.POINTER(_I), _I] + [_P] * 5
-                                + [_I, _I, _I, _P, _SZ, _I, _I64, _P, _SZ, _P]),
     "gg_blend_bwd_deterministic_workspace": (_SZ, [_I, _I, _I64]),
     "gg_blend_bwd_deterministic": (_I, [_I, _I, _I, _I] + [_P] * 14 + [_I, _I, _P, _SZ, _I, _I64, _P, _SZ, _P]),
     "gg_expf_array": (_I, [_I, _P, _P, _P]),

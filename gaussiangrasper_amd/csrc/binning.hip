@@ -251,214 +251,6 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// One-launch radix pass for the depth sort (r03): histogram, cross-workgroup prefix and scatter in ONE kernel.
-// At N = 1 M the three-launch pass above is latency, not bandwidth (8 MB in, 8 MB out in 25.7 us: 6.9 + 6.4 + 12.4).
-// Here a workgroup of 512 threads takes 8 192 keys (123 workgroups at 1 M), ranks them as the scatter kernel does, and
-// gets its start inside every digit's run by a decoupled look-back over its predecessors' PER-DIGIT counts — thread d
-// reads word d of up to eight predecessors at a time and stops at the first one that already carries an inclusive
-// prefix.  (With 256-thread workgroups of 4 096 keys the chain is 244 long and as slow as the launches it replaces —
-// that was the onesweep priced and not built in r02; twice the tile halves it, and the words of a workgroup arrive
-// together.)  The digit totals of all four passes come from one histogram launch over the keys (they do not depend on
-// the order).  Protocol as in scan.h: one relaxed agent-scope atomic word {count:30 | flag:2} per (workgroup, digit),
-// logical workgroup index from an atomic ticket, bounded spins — a wait that gives up raises the state's error word
-// (gg_bin_sort_status) and the scatter holds its addresses inside the array.
-// ---------------------------------------------------------------------------------------------
-#define OS_THREADS 512
-#define OS_WAVES (OS_THREADS / GG_WAVE)
-#define OS_ITEMS 16
-#define OS_TILE (OS_THREADS * OS_ITEMS)
-#define OS_AGG 1u
-#define OS_INCL 2u
-#define OS_SPIN_LIMIT (1u << 22)
-#ifndef OS_LB
-#define OS_LB 32      // predecessors' words requested at once by a digit's thread
-#endif
-struct OsState {
-    unsigned int ticket[4];     // per pass
-    unsigned int error;
-    unsigned int pad[3];
-    // followed by 4 x 256 digit totals, then per pass nblocks x 256 words
-};
-static inline size_t os_state_bytes(int nblocks) {
-    return gg_align_up(sizeof(OsState) + 4 * (4 * 256 + (size_t)4 * (nblocks > 0 ? nblocks : 1) * 256), 256);
-}
-__device__ __forceinline__ unsigned int *os_totals(OsState *st) { return reinterpret_cast<unsigned int *>(st + 1); }
-__device__ __forceinline__ unsigned int *os_words(OsState *st, int pass, int nblocks) {
-    return os_totals(st) + 4 * 256 + (size_t)pass * nblocks * 256;
-}
-
-// digit counts of all four bytes of the depth keys
-__global__ __launch_bounds__(256) void os_hist4_kernel(int n, DepthSrc dsrc, OsState *st) {
-    __shared__ unsigned int h[4][256];
-    for (int i = threadIdx.x; i < 1024; i += 256) (&h[0][0])[i] = 0u;
-    __syncthreads();
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
-        const uint32_t k = depth_key(dsrc, idx);
-        atomicAdd(&h[0][k & 255u], 1u);
-        atomicAdd(&h[1][(k >> 8) & 255u], 1u);
-        atomicAdd(&h[2][(k >> 16) & 255u], 1u);
-        atomicAdd(&h[3][k >> 24], 1u);
-    }
-    __syncthreads();
-    unsigned int *tot = os_totals(st);
-    for (int i = threadIdx.x; i < 1024; i += 256) {
-        const unsigned int v = (&h[0][0])[i];
-        if (v) atomicAdd(&tot[i], v);
-    }
-}
-
-// exclusive scan over 256 values held by threads 0..255 of a 512-thread workgroup (all threads call)
-__device__ __forceinline__ unsigned int os_scan256(unsigned int v, unsigned int *wsum /*[4]*/) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned int incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned int t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
-    if (tid < 256 && lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    unsigned int wpre = 0;
-    for (int w = 0; w < 4; ++w) wpre += (w < wave) ? wsum[w] : 0u;
-    __syncthreads();
-    return wpre + incl - v;
-}
-
-__global__ __launch_bounds__(OS_THREADS) void radix_os_kernel(
-    int n, const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int pass, int nblocks, OsState *st,
-    DepthSrc dsrc) {
-    __shared__ uint32_t whist[OS_WAVES][256];
-    __shared__ uint32_t digit_base[256], lstart[256];
-    __shared__ uint32_t wsum[4];
-    __shared__ unsigned int s_slot;
-    extern __shared__ uint32_t os_stage[];          // 2 x OS_TILE words (64 KB: dynamic, above the static limit)
-    uint32_t *skey = os_stage, *sval = os_stage + OS_TILE;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int shift = 8 * pass;
-    if (tid == 0) s_slot = atomicAdd(&st->ticket[pass], 1u);
-    for (int w = 0; w < OS_WAVES; ++w)
-        if (tid < 256) whist[w][tid] = 0;
-    __syncthreads();
-    const int bid = (int)s_slot;
-    unsigned int *words = os_words(st, pass, nblocks);
-
-    const int64_t wbase = (int64_t)bid * OS_TILE + (int64_t)wave * (GG_WAVE * OS_ITEMS);
-    uint32_t key[OS_ITEMS], val[OS_ITEMS], rank[OS_ITEMS];
-    volatile uint32_t *wh = whist[wave];
-    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll
-    for (int it = 0; it < OS_ITEMS; ++it) {
-        const int64_t idx = wbase + (int64_t)it * GG_WAVE + lane;
-        const bool valid = idx < n;
-        key[it] = valid ? (dsrc.depths ? depth_key(dsrc, idx) : keys_in[idx]) : 0u;
-        val[it] = valid ? (dsrc.depths ? (uint32_t)idx : vals_in[idx]) : 0u;
-    }
-#pragma unroll
-    for (int it = 0; it < OS_ITEMS; ++it) {
-        const int64_t idx = wbase + (int64_t)it * GG_WAVE + lane;
-        const bool valid = idx < n;
-        const uint32_t d = (key[it] >> shift) & 255u;
-        uint64_t peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        const uint32_t cnt = (uint32_t)__popcll(peers);
-        const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
-        if (valid && before == 0) wh[d] = wh[d] + cnt;   // group leader (lowest lane)
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t after = valid ? wh[d] : 0u;
-        rank[it] = after - cnt + before;
-        __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    // threads 0..255: digit tid — the waves' offsets inside the workgroup's run of the digit, the workgroup's count
-    uint32_t run = 0;
-    if (tid < 256) {
-        for (int w = 0; w < OS_WAVES; ++w) {
-            const uint32_t c = whist[w][tid];
-            whist[w][tid] = run;
-            run += c;
-        }
-        // publish the count at once: successors can add it without waiting for this workgroup's own look-back
-        __hip_atomic_store(&words[(size_t)bid * 256 + tid], (run << 2) | (bid == 0 ? OS_INCL : OS_AGG), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const uint32_t ls = os_scan256(tid < 256 ? run : 0u, wsum);                       // start of the digit's run in the tile
-    const uint32_t gs = os_scan256(tid < 256 ? os_totals(st)[256 * pass + tid] : 0u, wsum);   // ... in the whole array
-    if (tid < 256) {
-        uint32_t excl = 0;
-        bool failed = false;
-        int top = bid - 1;
-        while (top >= 0) {
-            // up to OS_LB predecessors' words of this digit, nearest first: all requested before the first is looked at
-            // (eight at a time made a chain of 15 L2 round trips for the last workgroup at 1 M keys: 31 us per pass)
-            uint32_t wq[OS_LB];
-            bool done = false;
-            unsigned int spins = 0;
-            while (true) {
-#pragma unroll
-                for (int u = 0; u < OS_LB; ++u) {
-                    const int pb = top - u;
-                    wq[u] = pb >= 0 ? __hip_atomic_load(&words[(size_t)pb * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                    : OS_INCL;
-                }
-                // usable as soon as every word in front of the first inclusive one is there
-                bool usable = true, seen_incl = false;
-#pragma unroll
-                for (int u = 0; u < OS_LB; ++u) {
-                    const unsigned f = wq[u] & 3u;
-                    usable = usable && (seen_incl || f != 0u);
-                    seen_incl = seen_incl || f == OS_INCL;
-                }
-                if (usable) break;
-                if (++spins > OS_SPIN_LIMIT) { failed = true; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (failed) break;
-#pragma unroll
-            for (int u = 0; u < OS_LB; ++u) {
-                excl += done ? 0u : (wq[u] >> 2);
-                done = done || (wq[u] & 3u) == OS_INCL;
-            }
-            if (done) break;
-            top -= OS_LB;
-        }
-        if (failed) atomicExch(&st->error, 1u);
-        if (bid > 0)
-            __hip_atomic_store(&words[(size_t)bid * 256 + tid], ((excl + run) << 2) | OS_INCL, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        digit_base[tid] = gs + excl;
-        lstart[tid] = ls;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < OS_ITEMS; ++it) {
-        const int64_t idx = wbase + (int64_t)it * GG_WAVE + lane;
-        if (idx < n) {
-            const uint32_t d = (key[it] >> shift) & 255u;
-            const uint32_t lp = lstart[d] + whist[wave][d] + rank[it];
-            skey[lp] = key[it];
-            sval[lp] = val[it];
-        }
-    }
-    __syncthreads();
-    const int64_t left = (int64_t)n - (int64_t)bid * OS_TILE;
-    const int count = (int)(left < OS_TILE ? left : OS_TILE);
-    for (int jj = tid; jj < count; jj += OS_THREADS) {
-        const uint32_t k = skey[jj];
-        const uint32_t d = (k >> shift) & 255u;
-        uint32_t dst = digit_base[d] + ((uint32_t)jj - lstart[d]);
-        dst = dst < (uint32_t)n ? dst : (uint32_t)n - 1u;      // (only after a failed look-back)
-        keys_out[dst] = k;
-        vals_out[dst] = sval[jj];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // exclusive scan of num_tiles_hit[order[r]]: ONE launch (decoupled look-back across workgroups, scan.h)
 // (r03: the same look-back moved INTO the emission kernel — 3 907 workgroups of 256 Gaussians instead of 489 of 2 048,
 //  no offsets array — measured 0.312 ms for the whole binning against 0.282: the chain of 3 907 published prefixes is
@@ -601,7 +393,6 @@ struct BinWs {
     uint32_t *G;                              // 256 * max nblocks
     uint32_t *totals;                         // 256
     uint32_t *tkeyA, *tkeyB, *tvalTmp;        // I each
-    uint32_t *os_state;
     size_t bytes;
 };
 static BinWs bin_ws_layout(void *ws, int N, int64_t I) {
@@ -619,7 +410,6 @@ static BinWs bin_ws_layout(void *ws, int N, int64_t I) {
     w.dvalB = take(4 * n);
     w.offsets = take(4 * n);
     w.block_sums = take(gg_scan_state_bytes((int)((n + SC_TILE - 1) / SC_TILE)));   // look-back state of the offsets scan
-    w.os_state = take(os_state_bytes((int)((n + OS_TILE - 1) / OS_TILE)));           // ... of the one-launch depth-sort passes
     int nb = max(radix_nblocks(N), radix_nblocks(I));
     w.G = take(4 * 256 * (size_t)(nb + 1));
     w.totals = take(4 * 256);
@@ -652,22 +442,6 @@ static void radix_pass(int64_t n, const int64_t *n_dev, const uint32_t *kin, con
                            kout, vout, shift, mask, nb, w.G, w.totals, dsrc);
 }
 
-// MEASURED (r03, 1 M Gaussians, rocprofv3): radix_os_kernel 27.4 us per pass (eight or 32 look-back words in flight: the
-// same) against 6.9 + 6.4 + 12.4 = 25.7 for the three launches, plus 33 us for os_hist4_kernel (four LDS atomics per key,
-// the upper bytes of depth keys take few values) and the state's fill: all binning launches 0.317-0.336 ms against 0.282.
-// Half the CUs idle (123 workgroups) and the chain of published counts cost what the two saved launches did.  Kept as a
-// tested option (bit-identical lists), default OFF.
-#ifndef GG_DEPTH_ONESWEEP
-#define GG_DEPTH_ONESWEEP 0
-#endif
-// 1: the depth sort's four passes as one launch each (radix_os_kernel); 0: three launches per pass.  Tuning / test entry.
-static int g_depth_onesweep = GG_DEPTH_ONESWEEP;
-extern "C" int gg_debug_set_depth_onesweep(int on) {
-    const int prev = g_depth_onesweep;
-    g_depth_onesweep = on ? 1 : 0;
-    return prev;
-}
-
 static int bin_sort_impl(int N, int64_t I, const int64_t *I_dev, const float *xys, const float *depths,
                          const int32_t *radii, const int32_t *num_tiles_hit, int tiles_x, int tiles_y,
                          int32_t *gaussian_ids_sorted, int32_t *tile_bins, int32_t *isect_tile_sorted,
@@ -692,39 +466,11 @@ static int bin_sort_impl(int N, int64_t I, const int64_t *I_dev, const float *xy
     gg_prof_begin(GG_K_BIN_SORT, s);
     // 1. depth order of the Gaussians
     uint32_t *ka = w.dkeyA, *kb = w.dkeyB, *va = w.dvalA, *vb = w.dvalB;
-    const int osb = (N + OS_TILE - 1) / OS_TILE;
-    bool onesweep = g_depth_onesweep != 0;
-    if (onesweep) {
-        const size_t lds = sizeof(uint32_t) * 2 * OS_TILE;
-        static bool attr_set = false;
-        if (!attr_set) {
-            onesweep = hipFuncSetAttribute((const void *)radix_os_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds) == hipSuccess;
-            attr_set = onesweep;
-        }
-        if (onesweep && gg_fill_async(w.os_state, 0, os_state_bytes(osb), s) != hipSuccess) {
-            gg_set_error("gg_bin_sort: memset failed");
-            return GG_ERR_LAUNCH;
-        }
-        if (onesweep) {
-            OsState *ost = (OsState *)w.os_state;
-            const DepthSrc src{depths, radii};
-            hipLaunchKernelGGL(os_hist4_kernel, dim3(min((N + 1023) / 1024, 1024)), dim3(256), 0, s, N, src, ost);
-            for (int pass = 0; pass < 4; ++pass) {
-                hipLaunchKernelGGL(radix_os_kernel, dim3(osb), dim3(OS_THREADS), lds, s, N, ka, va, kb, vb, pass, osb, ost,
-                                   pass == 0 ? src : DepthSrc{nullptr, nullptr});
-                uint32_t *t = ka; ka = kb; kb = t;
-                t = va; va = vb; vb = t;
-            }
-        }
-    }
-    if (!onesweep) {
     for (int pass = 0; pass < 4; ++pass) {
         radix_pass(N, nullptr, ka, va, kb, vb, 8 * pass, 0xFFu, w, s,
                    pass == 0 ? DepthSrc{depths, radii} : DepthSrc{nullptr, nullptr});
         uint32_t *t = ka; ka = kb; kb = t;
         t = va; va = vb; vb = t;
-    }
     }
     const uint32_t *order = va;
     // 2. offsets in depth order
@@ -781,18 +527,6 @@ extern "C" int gg_bin_sort_status(int N, int64_t I, const void *ws, size_t ws_by
     if (st.error != 0u) {
         gg_set_error("gg_bin_sort: the offsets scan's look-back timed out; the tile lists of this view were left empty");
         return GG_ERR_LAUNCH;
-    }
-    if (g_depth_onesweep) {
-        OsState ost;
-        if (hipMemcpyAsync(&ost, w.os_state, sizeof(OsState), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
-            hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
-            gg_set_error("gg_bin_sort_status: read-back failed");
-            return GG_ERR_LAUNCH;
-        }
-        if (ost.error != 0u) {
-            gg_set_error("gg_bin_sort: a depth-sort pass's look-back timed out; the depth order of this view is not to be trusted");
-            return GG_ERR_LAUNCH;
-        }
     }
     return GG_OK;
 }

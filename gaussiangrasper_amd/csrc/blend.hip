@@ -67,11 +67,11 @@ void gg_launch_blend2_bwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
                                float *v_conic, float *v_colors, float *v_opacity, int gstride, int cstride,
                                const float *colors2, int C2, const float *background2,
                                const float *const *v_out2_parts, const int *v_out2_channels, int num_parts,
-                               float *v_colors2, int cstride2, QList ql, hipStream_t s);
+                               float *v_colors2, int cstride2, hipStream_t s);
 void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int ntiles, const int32_t *ids,
                                const int2 *bins, const GRec *rec, const float *colors, const float *background,
                                float *out_img, float *final_Ts, int32_t *final_idx, const float *colors2, int C2,
-                               const float *background2, float *out_img2, QList ql, hipStream_t s, int ncb);
+                               const float *background2, float *out_img2, hipStream_t s, int ncb);
 void gg_launch_blend2_fwd_blocks(int ncb, int C, int off, int img_h, int img_w, int tiles_x, int ntiles,
                                  const int32_t *ids, const int2 *bins, const GRec *rec, const float *colors,
                                  const float *background, float *out_img, float *final_Ts, int32_t *final_idx,
@@ -177,27 +177,12 @@ extern "C" int gg_blend_fwd(int C, int N, int img_h, int img_w, const int32_t *i
     return GG_OK;
 }
 
-// quad lists (blend_common.h): (ntiles, 4) counts, then 4 records of 32 bytes per list entry
-extern "C" size_t gg_quad_lists_workspace(int64_t num_intersects, int img_h, int img_w) {
-    if (num_intersects < 0 || img_h <= 0 || img_w <= 0) return 0;
-    const int tiles_x = (img_w + GG_BLOCK - 1) / GG_BLOCK, tiles_y = (img_h + GG_BLOCK - 1) / GG_BLOCK;
-    return gg_quad_lists_cnt_bytes(tiles_x * tiles_y) + (size_t)(num_intersects > 0 ? num_intersects : 1) * 4 * 32;
-}
-static QList quad_lists_at(void *buf, int ntiles, int npoints) {
-    QList ql;
-    ql.npoints = npoints;
-    ql.cnt = (int32_t *)buf;
-    ql.recs = (float4 *)((char *)buf + gg_quad_lists_cnt_bytes(ntiles));
-    return ql;
-}
-
 static int blend_fwd_pair_impl(int C, int C2, int N, int img_h, int img_w, const int32_t *ids,
                                  const int32_t *tile_bins, const float *xys, const float *conics,
                                  const float *colors, const float *colors2, const float *opacity,
                                  const float *background, const float *background2, float *out_img,
                                  float *out_img2, float *final_Ts, int32_t *final_idx, void *ws,
-                                 size_t ws_bytes, int64_t num_intersects, void *quad_lists, size_t quad_lists_bytes,
-                                 gg_stream_t stream) {
+                                 size_t ws_bytes, gg_stream_t stream) {
     GG_REQUIRE(C >= 32, "the first colour array needs >= 32 channels (its first chunk carries the second array)");
     GG_REQUIRE(C2 >= 1 && C2 <= 8, "the second colour array has 1..8 channels");
     GG_REQUIRE(N >= 0, "num_points < 0");
@@ -219,22 +204,15 @@ static int blend_fwd_pair_impl(int C, int C2, int N, int img_h, int img_w, const
     }
     const int tiles_x = (img_w + GG_BLOCK - 1) / GG_BLOCK, tiles_y = (img_h + GG_BLOCK - 1) / GG_BLOCK;
     const int ntiles = tiles_x * tiles_y;
-    QList ql = QList();
-    if (quad_lists) {
-        GG_REQUIRE(num_intersects >= 0 && (reinterpret_cast<uintptr_t>(quad_lists) & 15) == 0 &&
-                       quad_lists_bytes >= gg_quad_lists_workspace(num_intersects, img_h, img_w),
-                   "quad_lists: gg_quad_lists_workspace(num_intersects, H, W) bytes, 16-byte aligned, expected");
-        ql = quad_lists_at(quad_lists, ntiles, N);
-    }
-    // the pair walk takes 1, 2 or 4 blocks of the first array (aligned rows; not with quad lists)
+    // the pair walk takes 1, 2 or 4 blocks of the first array (aligned rows)
     int pair_blocks = 1;
-    if (!quad_lists && (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_img) & 15) == 0)) {
+    if ((C % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_img) & 15) == 0)) {
         if (g_fwd_blocks_pair >= 4 && C >= 128) pair_blocks = 4;
         else if (g_fwd_blocks_pair >= 2 && C >= 64) pair_blocks = 2;
     }
     gg_prof_begin(GG_K_BLEND_FWD_PAIR, s);
     gg_launch_blend2_fwd_pair(C, img_h, img_w, tiles_x, ntiles, ids, (const int2 *)tile_bins, rec, colors,
-                              background, out_img, final_Ts, final_idx, colors2, C2, background2, out_img2, ql, s,
+                              background, out_img, final_Ts, final_idx, colors2, C2, background2, out_img2, s,
                               pair_blocks);
     gg_prof_end(GG_K_BLEND_FWD_PAIR, s);
     fwd_remaining_chunks(C, 32 * pair_blocks, img_h, img_w, tiles_x, ntiles, ids, tile_bins, rec, colors, background,
@@ -250,20 +228,7 @@ extern "C" int gg_blend_fwd_pair(int C, int C2, int N, int img_h, int img_w, con
                                  float *out_img2, float *final_Ts, int32_t *final_idx, void *ws,
                                  size_t ws_bytes, gg_stream_t stream) {
     return blend_fwd_pair_impl(C, C2, N, img_h, img_w, ids, tile_bins, xys, conics, colors, colors2, opacity, background,
-                               background2, out_img, out_img2, final_Ts, final_idx, ws, ws_bytes, 0, nullptr, 0, stream);
-}
-
-extern "C" int gg_blend_fwd_pair_lists(int C, int C2, int N, int img_h, int img_w, const int32_t *ids,
-                                       const int32_t *tile_bins, const float *xys, const float *conics,
-                                       const float *colors, const float *colors2, const float *opacity,
-                                       const float *background, const float *background2, float *out_img,
-                                       float *out_img2, float *final_Ts, int32_t *final_idx, void *ws,
-                                       size_t ws_bytes, int64_t num_intersects, void *quad_lists,
-                                       size_t quad_lists_bytes, gg_stream_t stream) {
-    GG_REQUIRE(quad_lists != nullptr, "quad_lists is null (gg_blend_fwd_pair is the call without them)");
-    return blend_fwd_pair_impl(C, C2, N, img_h, img_w, ids, tile_bins, xys, conics, colors, colors2, opacity, background,
-                               background2, out_img, out_img2, final_Ts, final_idx, ws, ws_bytes, num_intersects,
-                               quad_lists, quad_lists_bytes, stream);
+                               background2, out_img, out_img2, final_Ts, final_idx, ws, ws_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -505,8 +470,7 @@ static int blend_bwd_pair_impl(int C, int C2, int N, int img_h, int img_w, const
                                  const int *v_out2_channels, int num_parts, float *v_xy,
                                  float *v_conic, float *v_colors, float *v_colors2, float *v_opacity,
                                  int geom_stride, int color_stride, int color_stride2, void *ws, size_t ws_bytes,
-                                 int flags, int64_t num_intersects, const void *quad_lists, size_t quad_lists_bytes,
-                                 gg_stream_t stream) {
+                                 int flags, gg_stream_t stream) {
     const bool ws_from_forward = (flags & GG_BWD_WS_FROM_FORWARD) != 0;
     const bool acc_colors = (flags & GG_BWD_ACCUMULATE_COLORS) != 0;
     GG_REQUIRE((flags & GG_BWD_ACCUMULATE_GEOM) == 0, "gg_blend_bwd_pair writes the geometry gradients itself");
@@ -565,18 +529,11 @@ static int blend_bwd_pair_impl(int C, int C2, int N, int img_h, int img_w, const
     }
     const int tiles_x = (img_w + GG_BLOCK - 1) / GG_BLOCK, tiles_y = (img_h + GG_BLOCK - 1) / GG_BLOCK;
     const int ntiles = tiles_x * tiles_y;
-    QList ql = QList();
-    if (quad_lists) {
-        GG_REQUIRE(num_intersects >= 0 && (reinterpret_cast<uintptr_t>(quad_lists) & 15) == 0 &&
-                       quad_lists_bytes >= gg_quad_lists_workspace(num_intersects, img_h, img_w),
-                   "quad_lists: gg_quad_lists_workspace(num_intersects, H, W) bytes, 16-byte aligned, expected");
-        ql = quad_lists_at(const_cast<void *>(quad_lists), ntiles, N);
-    }
     gg_prof_begin(GG_K_BLEND_BWD_PAIR, s);
     gg_launch_blend2_bwd_pair(C, img_h, img_w, tiles_x, ntiles, ids, (const int2 *)tile_bins, rec, colors, background,
                               final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, geom_stride,
                               color_stride, colors2, C2, background2, v_out2_parts, v_out2_channels, num_parts,
-                              v_colors2, color_stride2, ql, s);
+                              v_colors2, color_stride2, s);
     gg_prof_end(GG_K_BLEND_BWD_PAIR, s);
     for (int off = 32; off < C;) {   // further chunks of the first array: their own walks, adding to the same arrays
         const int w = chunk_width(C - off);
@@ -604,24 +561,7 @@ extern "C" int gg_blend_bwd_pair(int C, int C2, int N, int img_h, int img_w, con
     return blend_bwd_pair_impl(C, C2, N, img_h, img_w, ids, tile_bins, xys, conics, colors, colors2, opacity, background,
                                background2, final_Ts, final_idx, v_out, v_out2_parts, v_out2_channels, num_parts, v_xy,
                                v_conic, v_colors, v_colors2, v_opacity, geom_stride, color_stride, color_stride2, ws,
-                               ws_bytes, flags, 0, nullptr, 0, stream);
-}
-
-extern "C" int gg_blend_bwd_pair_lists(int C, int C2, int N, int img_h, int img_w, const int32_t *ids,
-                                       const int32_t *tile_bins, const float *xys, const float *conics,
-                                       const float *colors, const float *colors2, const float *opacity,
-                                       const float *background, const float *background2, const float *final_Ts,
-                                       const int32_t *final_idx, const float *v_out,
-                                       const float *const *v_out2_parts, const int *v_out2_channels, int num_parts,
-                                       float *v_xy, float *v_conic, float *v_colors, float *v_colors2,
-                                       float *v_opacity, int geom_stride, int color_stride, int color_stride2,
-                                       void *ws, size_t ws_bytes, int flags, int64_t num_intersects,
-                                       const void *quad_lists, size_t quad_lists_bytes, gg_stream_t stream) {
-    GG_REQUIRE(quad_lists != nullptr, "quad_lists is null (gg_blend_bwd_pair is the call without them)");
-    return blend_bwd_pair_impl(C, C2, N, img_h, img_w, ids, tile_bins, xys, conics, colors, colors2, opacity, background,
-                               background2, final_Ts, final_idx, v_out, v_out2_parts, v_out2_channels, num_parts, v_xy,
-                               v_conic, v_colors, v_colors2, v_opacity, geom_stride, color_stride, color_stride2, ws,
-                               ws_bytes, flags, num_intersects, quad_lists, quad_lists_bytes, stream);
+                               ws_bytes, flags, stream);
 }
 
 extern "C" int gg_blend_bwd_deterministic(int C, int N, int img_h, int img_w, const int32_t *ids,

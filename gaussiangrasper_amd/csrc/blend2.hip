@@ -27,84 +27,9 @@
 #include "blend_common.h"
 
 #define GRP 4          // survivors per loop iteration
-// quad-list backward: 0 = a chunk's 64 records are requested when the queue is free for them (the wave waits for one
-// load per 64 survivors), 1 = requested between the previous chunk's last walk and its flush.  Measured (r03, bench
-// view): 1.000 / 1.014 ms, and a whole chunk ahead (8 registers across four batches: 16 spilled) 1.019.
-#ifndef GG_QR_PREFETCH
-#define GG_QR_PREFETCH 0
-#endif
 #define KEEP(x) asm volatile("" ::"v"(x))   // measurement builds: keep a value alive
 
-#ifdef GG_ABLATION
-// measurement twin only: walk statistics of the forward kernel (tools/walkstats.py)
-//   0 list entries staged   1 survivors of the quadrant cull that were walked   2 of those, with >= 1
-//   blending pixel   3 (pixel, Gaussian) pairs evaluated   4 pairs passing the alpha test   5 pairs blended
-__device__ unsigned long long g_walk_stats[8];
-extern "C" int gg_debug_walk_stats(unsigned long long *out8, int reset) {
-    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_walk_stats), sizeof(g_walk_stats)) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[8] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_walk_stats), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#ifdef GG_WALK_STATS   // the counters cost 100x the kernel: only tools/walkstats.py builds with them
-#define WALK_STAT(i, v) do { if (lane == 0) atomicAdd(&g_walk_stats[i], (unsigned long long)(v)); } while (0)
-#else
-#define WALK_STAT(i, v) do { } while (0)
-#endif
-// forward ablation of the pair kernel (tools/kbench.py; template parameter FABL): 1 no MFMAs, 2 also no
-// colour-row loads, 3 also no second-array fma, 4 staging only
-static int g_fwd_abl = 0;
-extern "C" int gg_debug_set_fwd_ablation(int level) {
-    const int prev = g_fwd_abl;
-    g_fwd_abl = level;
-    return prev;
-}
-#else
-#define WALK_STAT(i, v) do { } while (0)
-#endif
-// GG_STAMPS (tools/stamps.py; a diagnostic build of its own, never timed as a whole): s_memtime stamps around the
-// phases of the wide backward.  Every wave adds the cycles it spent per phase into g_stamp_sums:
-//   0 prologue  1 staging (list ids, records, cull, queue)  2 batch start: colour-row loads issued and waited for
-//   3 D product (MFMAs + slab stores)  4 walk  5 flush MFMAs  6 32-channel colour atomics  7 second-array flush
-//   8 queue compaction  9 wave lifetime  10 batches  11 waves
-#ifdef GG_STAMPS
-__device__ unsigned long long g_stamp_sums[16];
-extern "C" int gg_debug_stamps(unsigned long long *out16, int reset) {
-    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamp_sums), sizeof(g_stamp_sums)) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[16] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sums), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-__device__ __forceinline__ unsigned long long gg_stamp() {
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-#define STAMP_DECL unsigned long long st_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned st_batches = 0; \
-                   const unsigned long long st_t0 = gg_stamp(); unsigned long long st_prev = st_t0
-#define STAMP(i) do { const unsigned long long st_now = gg_stamp(); st_sum[i] += st_now - st_prev; st_prev = st_now; } while (0)
-#define STAMP_BATCH() (++st_batches)
-#define STAMP_END() do { st_sum[9] = gg_stamp() - st_t0; if (lane == 0) { \
-        for (int q_ = 0; q_ < 10; ++q_) atomicAdd(&g_stamp_sums[q_], st_sum[q_]); \
-        atomicAdd(&g_stamp_sums[10], (unsigned long long)st_batches); atomicAdd(&g_stamp_sums[11], 1ull); } } while (0)
-#else
-#define STAMP_DECL do { } while (0)
-#define STAMP(i) do { } while (0)
-#define STAMP_BATCH() do { } while (0)
-#define STAMP_END() do { } while (0)
-#endif
-#ifdef GG_STAMPS
-#ifndef GG_EPI_SKIP
-#define GG_EPI_SKIP 0
-#endif
-extern "C" int gg_debug_epi_skip() { return GG_EPI_SKIP; }
-#endif
+#include "blend_measure.h"   // GG_ABLATION / GG_STAMPS / GG_WALK_STATS hooks: empty macros in the product build
 #define LIST_CAP 72    // 4 leading pads + 64 + 4 trailing pads
 
 // NC: colour float4s per record.  <= 3 channels: c = colours 0..2 and .w = list position; 8-channel
@@ -134,33 +59,15 @@ __device__ __forceinline__ int lane_prefix(uint64_t m) {
 
 // Stage one chunk: returns the survivor count; list[OFF + k] = k-th survivor in list order,
 // GRP null records (opacity 0 -> never pass) on both sides.
-template <int CH, bool WIDE, bool REL = false, typename LIST = WaveList, bool QWT = false>
+template <int CH, bool WIDE, bool REL = false, typename LIST = WaveList>
 __device__ __forceinline__ int stage_chunk(LIST &L, int lane, int e, bool valid,
                                            const int g /* ids[e], loaded by the caller one chunk ahead */,
                                            const GRec *__restrict__ rec,
                                            const float *__restrict__ colors, int C, int ch_off, int nch,
                                            float xlo, float xhi, float ylo, float yhi,
-                                           const Seg2 *seg2 = nullptr,
-                                           float4 *qdst = nullptr /* quad list: next free record of this quadrant */,
-                                           int qprev_cnt = 0 /* quad list: survivors of the previous chunk (still in L) */) {
+                                           const Seg2 *seg2 = nullptr) {
     const float4 ra = reinterpret_cast<const float4 *>(rec + g)[0];
     const float4 rb = reinterpret_cast<const float4 *>(rec + g)[1];
-    if (QWT) {
-        // quad list, late form: the PREVIOUS chunk's survivors leave from the list (still intact: compacted, in list
-        // order) behind this chunk's record request.  The vector memory counter is in order: stores issued in front
-        // of a load are waited for with it, stores behind it are not — and the compiler's wait for the records is
-        // vmcnt(2) only if no branch surrounds the stores: they are unconditional.  Lanes past the last survivor
-        // repeat its record (same address, same data); with no survivor at all every lane writes a dead record to
-        // the next free slot, which the next chunk's survivors (or nobody: it lies behind the count) overwrite.
-        __builtin_amdgcn_sched_barrier(0);
-        const int sl = max(min(lane, qprev_cnt - 1), 0);
-        const float4 pa = L.a[GRP + sl], pb = L.b[GRP + sl];
-        const int ppos = __builtin_bit_cast(int, L.c[GRP + sl].w) - 1;
-        float4 *q = qdst - 2 * (size_t)qprev_cnt + 2 * sl;
-        q[0] = make_float4(pa.x, pa.y, pa.z, __builtin_bit_cast(float, ppos));
-        q[1] = pb;
-        __builtin_amdgcn_sched_barrier(0);
-    }
     const bool hit = valid && rec_hits_rect(ra, rb, xlo, xhi, ylo, yhi);
     const uint64_t m = __ballot(hit);
     const int cnt = __builtin_popcountll(m);
@@ -222,12 +129,11 @@ __device__ __forceinline__ int stage_chunk(LIST &L, int lane, int e, bool valid,
 #ifndef GG_FWD_WAVES
 #define GG_FWD_WAVES 5
 #endif
-// QW: the wave persists the survivors of its quadrant cull (quad lists, blend_common.h) for the backward walk
 // NCB (r03): 32-channel blocks per walk of a wide build — one cull, one sigma / exp / alpha / T per (pixel, Gaussian)
 // for 32 NCB channels: NCB more colour dwords per lane and pair, 2 NCB MFMAs, 32 NCB accumulator registers.  What
 // a 128-channel feature image (BASELINE config 5) is rendered with: per channel the same fma / MFMA sequence, so
 // the images are bit-identical to the one-block walks'.
-template <int CH, bool WIDE, bool FULL, bool EX = false, int FABL = 0, bool QW = false, int NCB = 1>
+template <int CH, bool WIDE, bool FULL, bool EX = false, int FABL = 0, int NCB = 1>
 __global__ __launch_bounds__(64 * GG_WPB_OTHER)
 __attribute__((amdgpu_waves_per_eu((WIDE && EX && NCB == 1) ? GG_FWD_WAVES : (NCB == 2 ? (EX ? 4 : 3) : (NCB > 2 ? 2 : 1)))))
 void blend2_fwd_kernel(
@@ -235,10 +141,9 @@ void blend2_fwd_kernel(
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
     const float *__restrict__ colors, const float *__restrict__ background,
     float *__restrict__ out_img, float *__restrict__ final_T, int32_t *__restrict__ final_idx,
-    int write_final, Seg2 seg2 = Seg2(), QList ql = QList()) {
+    int write_final, Seg2 seg2 = Seg2()) {
     constexpr bool N8 = !WIDE && CH > 3;          // 8-channel narrow record layout
     static_assert(!EX || WIDE, "the second array rides on the wide kernel");
-    static_assert(!QW || WIDE, "quad lists are written by the wide builds (their list record keeps position + 1 in c.w)");
     static_assert(NCB == 1 || (WIDE && FULL), "several channel blocks: the full wide builds");
     typedef WaveListT<EX ? 3 : (N8 ? 2 : 1)> LIST;
     __shared__ LIST lists[GG_WPB_OTHER];
@@ -260,9 +165,6 @@ void blend2_fwd_kernel(
     float T = 1.0f;
     int last = range.x;
     bool done = !inside;
-    // quad list of this quadrant: qn_prev survivors before the chunk staged last, cnt_last in it (wave-uniform)
-    float4 *qseg = QW ? ql.recs + 2 * ((size_t)4 * range.x + (size_t)wave * (range.y - range.x)) : nullptr;
-    int qn_prev = 0, cnt_last = 0;
     float acc[WIDE ? 1 : CH];
     float acc2[EX ? 8 : 1];
 #pragma unroll
@@ -285,11 +187,8 @@ void blend2_fwd_kernel(
         if (__ballot(!done) == 0ull) break;
         const int e = base + lane;
         const int g_cur = e < range.y ? ids[e] : 0;
-        if (QW) qn_prev += cnt_last;
-        const int cnt = stage_chunk<CH, WIDE, false, LIST, QW>(L, lane, e, e < range.y, g_cur, rec, colors, C,
-                                                           ch_off, nch, xlo, xhi, ylo, yhi, EX ? &seg2 : nullptr,
-                                                           QW ? qseg + 2 * (size_t)qn_prev : nullptr, QW ? cnt_last : 0);
-        if (QW) cnt_last = cnt;
+        const int cnt = stage_chunk<CH, WIDE, false, LIST>(L, lane, e, e < range.y, g_cur, rec, colors, C,
+                                                           ch_off, nch, xlo, xhi, ylo, yhi, EX ? &seg2 : nullptr);
         WALK_STAT(0, min(64, range.y - base));
         STAMP(1);
         STAMP_BATCH();
@@ -409,24 +308,6 @@ void blend2_fwd_kernel(
         STAMP(4);
     }
     STAMP(8);
-    if (QW) {
-        // how many of the persisted survivors can still pass the backward's `position < final_idx` test of some pixel:
-        // those of the earlier chunks and, of the chunk staged last (its records are still in the list: c.w =
-        // position + 1), the ones at or below the quadrant's largest final_idx.  (If that maximum lies in an earlier
-        // chunk the count keeps a few entries too many: they fail the per-pixel test, nothing else.)
-        int hi_q = last;
-        for (int off = 32; off > 0; off >>= 1) hi_q = max(hi_q, __shfl_xor(hi_q, off, 64));
-        const bool keep = lane < cnt_last && __builtin_bit_cast(int, L.c[GRP + lane].w) <= hi_q;
-        const int n_eff = qn_prev + __builtin_popcountll(__ballot(keep));
-        if (lane == 0) ql.cnt[tile * 4 + wave] = n_eff;
-        if (keep) {   // the last chunk's survivors (the counted ones: a prefix)
-            const float4 pa = L.a[GRP + lane], pb = L.b[GRP + lane];
-            const int ppos = __builtin_bit_cast(int, L.c[GRP + lane].w) - 1;
-            float4 *q = qseg + 2 * ((size_t)qn_prev + lane);
-            q[0] = make_float4(pa.x, pa.y, pa.z, __builtin_bit_cast(float, ppos));
-            q[1] = pb;
-        }
-    }
 #ifndef GG_EPI_SKIP
 #define GG_EPI_SKIP 0   // diagnostic builds only (with GG_STAMPS): 1 no final_T / final_idx stores, 2 no image stores.
                         // A backward after a GG_EPI_SKIP=1 forward reads an uninitialised final_idx image: it faulted
@@ -717,12 +598,9 @@ __global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_bwd_narrow_kernel(
 #ifndef GG_F16_NLL
 #define GG_F16_NLL 0       // 1: without the lo x lo piece products (2^-24 each; measured -1.5 % of the kernel: not taken)
 #endif
-// quadrants without any cotangent of the first array (feat_any, below): skip its flush (measured: training iteration
-// -1.6 %, dense bench view +-0) / also its colour rows and D k-steps (dense bench view +4 %, training iteration +-0: the
-// branches keep the compiler from running the two arrays' D k-steps together) — the second is off
-#ifndef GG_FEATANY_D
-#define GG_FEATANY_D 0
-#endif
+// quadrants without any cotangent of the first array (feat_any, below): its flush is skipped (measured: training
+// iteration -1.6 %, dense bench view +-0; skipping its colour rows and D k-steps as well measured +4 % on the dense
+// view: profiles/r03_featany_d_experiment.patch)
 #ifndef GG_FEATANY_FLUSH
 #define GG_FEATANY_FLUSH 1
 #endif
@@ -763,7 +641,6 @@ struct __attribute__((aligned(16))) WaveQueueT {
     float4 b[CAP];   // conic a, b, c, Gaussian id (int bits; -1 = null record)
 };
 typedef WaveQueueT<BQ_CAP> WaveQueue;
-#define BQ_CAP_QR 64   // quad-list builds: the queue is one chunk of the persisted survivors (nulls behind the last one)
 
 // second colour array (<= 8 channels) whose backward rides on the walk of a 32-channel chunk (gg_blend_bwd_pair)
 struct Seg2B {
@@ -788,17 +665,13 @@ struct Seg2B {
 // re-reading its records.  k-step s of lane group q = lane >> 4 is channel 8 q + s, so a lane's B operand is still two
 // float4 loads of its Gaussian's colour row.  Needs 16-byte aligned colour rows and cotangent rows (the launcher
 // checks) and the full 32-channel chunk.
-// QR (round 3): the walk streams the quadrant's survivors from the forward's quad list (blend_common.h) instead of
-// staging the tile list again: no list ids, no record gather, no cull, no queue compaction — the queue is 64
-// consecutive records of a contiguous array, the next 64 requested while the current ones are walked.
 // MG (round 3, the pair build with a 16-float gradient record per Gaussian — geometry 0..5 | second array 6..6 + C2 — on
 // a 64-byte boundary): the geometry sums of a batch are parked in LDS by the walk and leave together with the second
 // array's colour gradients, ONE atomic request per Gaussian and batch instead of three to four.  Float atomics execute
 // at the L2 at ~20 G 64-byte requests/s chip-wide whatever the lanes of an instruction cover (tools/ubench_atomics.hip),
 // and the pair backward ran at 17 G/s (TCC_EA0_ATOMIC 16.7 M per launch): per batch of 16 Gaussians 32 requests for the
 // feature rows, ~22 for the 7 floats at offset 24 of 52-byte rows, ~21 for the 6 geometry floats.
-template <bool FULL, int ABL = 0, int CHD = 32, bool DET = false, bool EX = false, bool S16 = false, bool QR = false,
-          bool MG = false>
+template <bool FULL, int ABL = 0, int CHD = 32, bool DET = false, bool EX = false, bool S16 = false, bool MG = false>
 __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_per_eu(S16 ? GG_S16_WAVES : 3))) void blend2_bwd_wide_kernel(
     int C, int ch_off, int nch, int img_h, int img_w, int tiles_x, int ntiles,
     const int32_t *__restrict__ ids, const int2 *__restrict__ bins, const GRec *__restrict__ rec,
@@ -806,8 +679,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     const float *__restrict__ final_T, const int32_t *__restrict__ final_idx,
     const float *__restrict__ v_out, float *__restrict__ v_xy, float *__restrict__ v_conic,
     float *__restrict__ v_colors, float *__restrict__ v_opacity, int gstride, int cstride,
-    DetSlab det = DetSlab(), Seg2B seg2 = Seg2B(), QList ql = QList()) {
-    static_assert(!QR || S16, "quad lists: the 16-slot builds");
+    DetSlab det = DetSlab(), Seg2B seg2 = Seg2B()) {
     static_assert(!MG || (S16 && EX), "merged record flush: the 16-slot pair build");
     static_assert(!EX || (FULL && CHD == 32 && !DET), "the second array rides on the full 32-channel build");
     static_assert(!S16 || (FULL && CHD == 32 && !DET && ABL == 0), "S16: the full 32-channel build");
@@ -821,7 +693,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     //  the in-order memory counter, measured no gain in r02 — pair 1.064 against 1.051 ms: the waits are load latency,
     //  not the counter's ordering — and was removed in r03.)
     using R = Red6<KB>;
-    typedef WaveQueueT<QR ? BQ_CAP_QR : BQ_CAP> QUEUE;
+    typedef WaveQueueT<BQ_CAP> QUEUE;
     __shared__ QUEUE queues[GG_WPB_WIDE_BWD];
     constexpr int FS = S16 ? GG_S16_STRIDE : 65;   // slab row stride in floats (FIDX)
     __shared__ float s_fac[GG_WPB_WIDE_BWD][NSLOT * FS];
@@ -854,10 +726,6 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     float T = T_final;
     float W;
     const int wch = lane & 31, half = lane >> 5;
-    // QR: this quadrant's survivors (the forward's count, held to the segment's capacity: the buffer is the caller's)
-    const float4 *qseg = QR ? ql.recs + 2 * ((size_t)4 * range.x + (size_t)wave * (range.y - range.x)) : nullptr;
-    const int n_q = QR ? __builtin_amdgcn_readfirstlane(min(max(ql.cnt[tile * 4 + wave], 0), range.y - range.x)) : 0;
-    int q_next = 0;   // QR, wave-uniform: run_batch(fetch_next) requests the chunk below this survivor index
     const bool wch_ok = FULL || wch < nch;
     // The quadrant's cotangents V_OUT[64 pixels x CH] are needed three ways: <background, v_out> per pixel (lane =
     // pixel), the D product's A operands (pixel-major, half a row per lane) and the flush's B operands (lane =
@@ -895,22 +763,9 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     // records of the NEXT chunk, requested between a batch's walk and its flush: the vector memory counter is
     // in order, so loads issued behind the flush's 24-32 atomic instructions wait for every one of them
     float4 ra_p = make_float4(0.f, 0.f, 0.f, 0.f), rb_p = ra_p;
-    // QR: records of survivors [top_n - 64, top_n) in processing order (lane l = survivor top_n - 1 - l; lanes past the
-    // first survivor read record 0 and are replaced by null records when the chunk enters the queue)
-    auto qload = [&](int top_n) {
-        const int idx = max(top_n - 1 - lane, 0);
-        ra_p = qseg[2 * idx];
-        rb_p = qseg[2 * idx + 1];
-    };
     if (S16) {   // the tile goes through the (16-slot) slab in two halves of 32 pixels
-        if (QR) {
-            hi = range.x;
-            g_first = 0;
-            if (n_q > 0) qload(n_q);   // requested beside the cotangent tile
-        } else {
-            hi = wave_hi();
-            g_first = load_id(hi);
-        }
+        hi = wave_hi();
+        g_first = load_id(hi);
         const int sl = lane & 15, q4 = lane >> 4;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
@@ -1015,10 +870,8 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     }
     // the first chunk's records: requested here (the ids have arrived beside the tile), consumed after the rest of
     // the prologue
-    if (!QR) {
-        ra_p = reinterpret_cast<const float4 *>(rec + g_first)[0];
-        rb_p = reinterpret_cast<const float4 *>(rec + g_first)[1];
-    }
+    ra_p = reinterpret_cast<const float4 *>(rec + g_first)[0];
+    rb_p = reinterpret_cast<const float4 *>(rec + g_first)[1];
     // F16: s_w from the largest |cotangent| of the quadrant — every element of the first array's tile is in exactly one
     // lane's va16, every element of the second array's in one lane's t8
     float mloc = 0.0f;
@@ -1161,10 +1014,8 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
             const int q4 = lane >> 4;
             const float *row = colors + (size_t)(cgid < 0 ? 0 : cgid) * C + ch_off + 8 * q4;
             float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
-            if (feat_any || !GG_FEATANY_D) {
-                c0 = *reinterpret_cast<const float4 *>(row);
-                c1 = *reinterpret_cast<const float4 *>(row + 4);
-            }
+            c0 = *reinterpret_cast<const float4 *>(row);
+            c1 = *reinterpret_cast<const float4 *>(row + 4);
             const float colb[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
             float colb2[2] = {0.0f, 0.0f};
             float va2[4][2];
@@ -1201,10 +1052,8 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                 const float sg = cgid < 0 ? 0.0f : pow2_scale(m);   // (null slot: every operand 0)
                 const float unscale = pow2_inv(cgid < 0 ? 1.0f : sg) * inv_sw;
                 unsigned ch_[4] = {0u, 0u, 0u, 0u}, cl_[4] = {0u, 0u, 0u, 0u};
-                if (feat_any || !GG_FEATANY_D) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) split2h(colb[2 * t] * sg, colb[2 * t + 1] * sg, ch_[t], cl_[t]);
-                }
+                for (int t = 0; t < 4; ++t) split2h(colb[2 * t] * sg, colb[2 * t + 1] * sg, ch_[t], cl_[t]);
                 const h16x8 Bh = H8(ch_[0], ch_[1], ch_[2], ch_[3]), Bl = H8(cl_[0], cl_[1], cl_[2], cl_[3]);
                 const float b2[2] = {colb2[0] * sg, colb2[1] * sg};   // (zeros without a second array)
 #pragma unroll
@@ -1213,14 +1062,12 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                     const h16x8 Ah = H8(vah[bb][0], vah[bb][F16 ? 1 : 0], vah[bb][F16 ? 2 : 0], vah[bb][F16 ? 3 : 0]);
                     const h16x8 Al = H8(val[bb][0], val[bb][F16 ? 1 : 0], val[bb][F16 ? 2 : 0], val[bb][F16 ? 3 : 0]);
                     d[blk] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                    if (feat_any || !GG_FEATANY_D) {
 #if !GG_F16_NLL
-                        d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bl, d[blk], 0, 0, 0);
+                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bl, d[blk], 0, 0, 0);
 #endif
-                        d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh, d[blk], 0, 0, 0);
-                        d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl, d[blk], 0, 0, 0);
-                        d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh, d[blk], 0, 0, 0);
-                    }
+                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh, d[blk], 0, 0, 0);
+                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl, d[blk], 0, 0, 0);
+                    d[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh, d[blk], 0, 0, 0);
                     if (EX) {
 #pragma unroll
                         for (int t = 0; t < 2; ++t)   // the second array's channels: fp32 k-steps on operands carrying s_w, s_g
@@ -1418,12 +1265,8 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         }
         STAMP(4);
         if (fetch_next) {
-            if (QR) {
-                qload(q_next);
-            } else {
-                ra_p = reinterpret_cast<const float4 *>(rec + g_nxt)[0];
-                rb_p = reinterpret_cast<const float4 *>(rec + g_nxt)[1];
-            }
+            ra_p = reinterpret_cast<const float4 *>(rec + g_nxt)[0];
+            rb_p = reinterpret_cast<const float4 *>(rec + g_nxt)[1];
         }
         // flush: FAC[32 slots x 64 pixels] * V_OUT[64 x 32 channels]; rows outside slotmask still hold D and
         // are not written
@@ -1583,33 +1426,6 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     bool have_p = true;   // wave-uniform: ra_p / rb_p hold this chunk's records
     // ONE call site of run_batch (the tail batch runs through the same loop): inlined twice, the allocator kept two
     // sets of loop invariants and spilled one
-    if constexpr (QR) {
-        // chunk by chunk down the quad list: 64 records into the queue (processing order = descending list position),
-        // up to four batches of 16, the next chunk requested between the last batch's walk and its flush (QR_PREFETCH)
-        // or right here (then the wave waits for it: one load per 64 survivors, nothing dependent before it)
-        bool have_q = n_q > 0;   // ra_p / rb_p hold the chunk (requested in the prologue / by the previous chunk's last batch)
-        for (int top_n = n_q; top_n > 0; top_n -= 64) {
-            if (!have_q) qload(top_n);
-            // (a record whose Gaussian id is not one — a stale or foreign buffer — becomes a null record: the id
-            //  indexes the colour and gradient rows)
-            const bool real = top_n - 1 - lane >= 0 && (unsigned)__builtin_bit_cast(int, rb_p.w) < (unsigned)ql.npoints;
-            Q.a[lane] = real ? ra_p : make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, 0x7fffffff));
-            Q.b[lane] = real ? rb_p : make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, -1));
-            __builtin_amdgcn_wave_barrier();
-            const int m = min(64, top_n);
-            const bool more = top_n > 64;
-            q_next = top_n - 64;
-            have_q = false;
-            for (int b0 = 0; b0 < m; b0 += 16) {
-                const bool pre = (GG_QR_PREFETCH == 1) && more && (b0 + 16 >= m);
-                run_batch(b0, min(16, m - b0), pre);
-                have_q = have_q || pre;
-            }
-            __builtin_amdgcn_wave_barrier();   // the queue is rewritten by the next chunk
-        }
-        STAMP_END();
-        return;
-    }
     for (int top = hi;; top -= 64) {
       const bool more = top > range.x;   // wave-uniform: another chunk to stage
       if (more) {
@@ -1719,18 +1535,18 @@ void gg_launch_blend2_fwd_blocks(int ncb, int C, int off, int img_h, int img_w, 
     dim3 grid(gg_blend_grid(ntiles, GG_WPB_OTHER)), block(64 * GG_WPB_OTHER);
     const int n = 32;
     if (ncb == 2)
-        hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, false, 0, false, 2>), grid, block, 0, s, B2_FWD_ARGS);
+        hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, false, 0, 2>), grid, block, 0, s, B2_FWD_ARGS);
     else if (ncb == 3)
-        hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, false, 0, false, 3>), grid, block, 0, s, B2_FWD_ARGS);
+        hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, false, 0, 3>), grid, block, 0, s, B2_FWD_ARGS);
     else
-        hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, false, 0, false, 4>), grid, block, 0, s, B2_FWD_ARGS);
+        hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, false, 0, 4>), grid, block, 0, s, B2_FWD_ARGS);
 }
 
 // ncb: 32-channel blocks of the first array in this walk (1, 2 or 4; channels [0, 32 ncb))
 void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int ntiles, const int32_t *ids,
                                const int2 *bins, const GRec *rec, const float *colors, const float *background,
                                float *out_img, float *final_Ts, int32_t *final_idx, const float *colors2, int C2,
-                               const float *background2, float *out_img2, QList ql, hipStream_t s, int ncb) {
+                               const float *background2, float *out_img2, hipStream_t s, int ncb) {
     dim3 grid(gg_blend_grid(ntiles, GG_WPB_OTHER)), block(64 * GG_WPB_OTHER);
     Seg2 seg2;
     seg2.colors = colors2;
@@ -1749,19 +1565,14 @@ void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
         default: break;
     }
 #endif
-    if (ncb == 2 && !ql.recs) {
-        hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, true, 0, false, 2>), grid, block, 0, s, C, 0, 32, img_h,
+    if (ncb == 2) {
+        hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, true, 0, 2>), grid, block, 0, s, C, 0, 32, img_h,
                            img_w, tiles_x, ntiles, ids, bins, rec, colors, background, out_img, final_Ts, final_idx, 1, seg2);
         return;
     }
-    if (ncb == 4 && !ql.recs) {
-        hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, true, 0, false, 4>), grid, block, 0, s, C, 0, 32, img_h,
+    if (ncb == 4) {
+        hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, true, 0, 4>), grid, block, 0, s, C, 0, 32, img_h,
                            img_w, tiles_x, ntiles, ids, bins, rec, colors, background, out_img, final_Ts, final_idx, 1, seg2);
-        return;
-    }
-    if (ql.recs) {   // the survivors of the quadrant cull are persisted for the backward walk
-        hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, true, 0, true>), grid, block, 0, s, C, 0, 32, img_h, img_w,
-                           tiles_x, ntiles, ids, bins, rec, colors, background, out_img, final_Ts, final_idx, 1, seg2, ql);
         return;
     }
     B2_FPAIR(0);
@@ -1835,7 +1646,7 @@ void gg_launch_blend2_bwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
                                float *v_conic, float *v_colors, float *v_opacity, int gstride, int cstride,
                                const float *colors2, int C2, const float *background2,
                                const float *const *v_out2_parts, const int *v_out2_channels, int num_parts,
-                               float *v_colors2, int cstride2, QList ql, hipStream_t s) {
+                               float *v_colors2, int cstride2, hipStream_t s) {
     dim3 grid(gg_blend_grid(ntiles, GG_WPB_WIDE_BWD)), block(64 * GG_WPB_WIDE_BWD);
     Seg2B seg2;
     seg2.colors = colors2;
@@ -1858,18 +1669,11 @@ void gg_launch_blend2_bwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
 #endif
     if (GG_BWD_S16 && !ablated && C % 4 == 0 && (reinterpret_cast<uintptr_t>(colors) & 15) == 0 &&
         (reinterpret_cast<uintptr_t>(v_out) & 15) == 0) {   // the 16-slot build (four waves per SIMD)
-        if (ql.recs) {   // ... streaming the forward's quad lists
-            hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, 0, 32, false, true, GG_BWD_S16 != 0, GG_BWD_S16 != 0>), grid,
-                               block, 0, s, C, 0, 32, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background,
-                               final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, gstride, cstride, DetSlab(),
-                               seg2, ql);
-            return;
-        }
         // one 16-float record per Gaussian on a 64-byte boundary, geometry 0..5 | second array 6..: the merged flush
         const bool merged = GG_BWD_MERGE && gstride == 16 && seg2.cs2 == 16 && v_colors2 == v_xy + 6 && v_conic == v_xy + 2 &&
                             v_opacity == v_xy + 5 && (reinterpret_cast<uintptr_t>(v_xy) & 63) == 0;
         if (merged)
-            hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, 0, 32, false, true, GG_BWD_S16 != 0, false, GG_BWD_S16 != 0>), grid,
+            hipLaunchKernelGGL((blend2_bwd_wide_kernel<true, 0, 32, false, true, GG_BWD_S16 != 0, GG_BWD_S16 != 0>), grid,
                                block, 0, s, C, 0, 32, img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background,
                                final_Ts, final_idx, v_out, v_xy, v_conic, v_colors, v_opacity, gstride, cstride, DetSlab(),
                                seg2);

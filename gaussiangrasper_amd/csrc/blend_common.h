@@ -16,23 +16,6 @@ struct DetSlab {
     int ks, goff, coff;
 };
 
-// Quad lists (round 3): what a forward walk's exact quadrant cull kept, persisted for the backward walk of the same
-// view.  Of the tile-list entries a quadrant wave stages, a third survive its cull (profiles/r02_walk_stats.txt:
-// 11.59 M staged, 3.90 M kept); without the lists the backward wave repeats the chain list id -> 32-byte record
-// gather -> cull -> LDS compaction for every entry and throws two thirds of that away again.  The forward wave of
-// quadrant w of a tile with list range [s, e) appends its survivors, in list order, as 32-byte records
-//     {x, y, opacity, list position (int bits)} {conic a, b, c, Gaussian id (int bits)}
-// — the backward's queue record as it stands — at recs[2 (4 s + w (e - s) + k)], and leaves in cnt[4 tile + w] how
-// many of them lie below the quadrant's largest final_idx (the others can never pass the backward's pos < final_idx
-// test).  The backward then streams records [cnt - 1 .. 0]: contiguous, coalesced, no dependent load, no cull.
-// Capacity: 4 records per list entry (a quadrant may keep its whole list); written: ~0.74 per entry.
-struct QList {
-    int32_t *cnt;    // (ntiles, 4)
-    float4 *recs;    // 2 float4 per record
-    int npoints;     // Gaussian ids of the records are checked against this before they index anything
-};
-static inline size_t gg_quad_lists_cnt_bytes(int ntiles) { return ((size_t)ntiles * 4 * sizeof(int32_t) + 255) / 256 * 256; }
-
 struct __attribute__((aligned(16))) GRec {
     float x, y, opac, thr;  // thr: sigma above which alpha < 1/255 for certain (conservative)
     float ca, cb, cc, pad;

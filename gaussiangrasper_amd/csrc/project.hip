@@ -20,7 +20,7 @@ void gg_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 extern "C" const char *gg_last_error(void) { return g_err; }
-extern "C" int gg_abi_version(void) { return 2; }
+extern "C" int gg_abi_version(void) { return 3; }
 
 __device__ __forceinline__ void quat_to_R(const float4 q, float *R, float *qn, float &inv) {
     float nn = ((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w;  // (w,x,y,z) stored in .x.y.z.w

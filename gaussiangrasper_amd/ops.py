@@ -586,12 +586,6 @@ def _rasterize_forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, o
 
 
 _DETERMINISTIC = False
-# quad lists (include/gg_raster.h): the fused operator's forward walk persists every quadrant's cull survivors and
-# its backward walk streams them; off = the backward stages the tile lists again (gg_blend_bwd_pair).
-# OFF by default: built, parity-green and measured in round 3 — on the bench view the forward pays
-# +0.06 ms for the lists (0.47 -> 0.53) and the backward gains nothing (0.97 -> 1.00): its waves do not wait for the
-# staging chain the lists remove, they share a SIMD whose matrix and vector pipes are both half busy.
-USE_QUAD_LISTS = False
 
 
 def set_deterministic_backward(on: bool = True) -> bool:
@@ -803,28 +797,13 @@ class RasterizeSegments(Function):
         final_Ts = torch.empty(img_height, img_width, dtype=torch.float32, device=dev)
         final_idx = torch.empty(img_height, img_width, dtype=torch.int32, device=dev)
         outs = [torch.empty(img_height, img_width, c.shape[1], dtype=torch.float32, device=dev) for c in cols_c]
-        # quad lists: only when a backward will follow, and only for the atomic (default) backward
-        want_lists = USE_QUAD_LISTS and not _DETERMINISTIC and any(ctx.needs_input_grad)
-        qlists = None
         for attempt in range(2):
-            qlists = None
             if bins.num_intersects is not None and bins.num_intersects < 1:
                 break
             # a >= 32-channel array carries a <= 8-channel one through its first forward walk
             wide = next((i for i, c in enumerate(cols_c) if c.shape[1] >= 32), None)
             small = next((i for i, c in enumerate(cols_c) if c.shape[1] <= 8), None) if wide is not None else None
-            if small is not None and want_lists:
-                # the forward walk persists every quadrant's cull survivors for the backward walk (quad lists)
-                cap = int(bins.gaussian_ids_sorted.numel())
-                qlists = torch.empty(lib.gg_quad_lists_workspace(cap, img_height, img_width), dtype=torch.uint8,
-                                     device=dev)
-                _lib.check(lib.gg_blend_fwd_pair_lists(
-                    cols_c[wide].shape[1], cols_c[small].shape[1], n, img_height, img_width,
-                    _ptr(bins.gaussian_ids_sorted), _ptr(bins.tile_bins), _ptr(xys_c), _ptr(conics_c),
-                    _ptr(cols_c[wide]), _ptr(cols_c[small]), _ptr(opacity_c), _ptr(bgs_c[wide]), _ptr(bgs_c[small]),
-                    _ptr(outs[wide]), _ptr(outs[small]), _ptr(final_Ts), _ptr(final_idx), _ptr(ws), ws.numel(),
-                    cap, _ptr(qlists), qlists.numel(), _stream(dev)), "gg_blend_fwd_pair_lists")
-            elif small is not None:
+            if small is not None:
                 _lib.check(lib.gg_blend_fwd_pair(
                     cols_c[wide].shape[1], cols_c[small].shape[1], n, img_height, img_width,
                     _ptr(bins.gaussian_ids_sorted), _ptr(bins.tile_bins), _ptr(xys_c), _ptr(conics_c),
@@ -863,9 +842,6 @@ class RasterizeSegments(Function):
         else:
             ctx.save_for_backward(xys_c, conics_c, opacity_c, bins.gaussian_ids_sorted, bins.tile_bins, final_Ts,
                                   final_idx, ws, *cols_c, *bgs_c)
-            # (not through save_for_backward: a scratch buffer no autograd graph node owns; sized by the capacity the
-            #  lists were built with, which the count read back later may be below)
-            ctx.qlists = qlists
         return tuple(outs[i] if (e - b) == outs[i].shape[2] else outs[i][..., b:e] for i, b, e in out_map)
 
     @staticmethod
@@ -929,25 +905,13 @@ class RasterizeSegments(Function):
                 rp = [(cotangent(rider), cols[rider].shape[1])]
             part_ptrs = (C.c_void_p * len(rp))(*[_ptr(v) for v, _ in rp])
             part_chs = (C.c_int * len(rp))(*[c for _, c in rp])
-            qlists = getattr(ctx, "qlists", None)
-            if qlists is not None:
-                cap = (qlists.numel() - lib.gg_quad_lists_workspace(0, img_height, img_width)) // 128 + 1
-                _lib.check(lib.gg_blend_bwd_pair_lists(
-                    cols[wide].shape[1], cols[rider].shape[1], n, img_height, img_width, _ptr(ids_sorted),
-                    _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(cols[wide]), _ptr(cols[rider]), _ptr(opacity),
-                    _ptr(bgs[wide]), _ptr(bgs[rider]), _ptr(final_Ts), _ptr(final_idx), _ptr(vo_w), part_ptrs,
-                    part_chs, len(rp), _ptr(v_xy), _ptr(v_conic), _ptr(v_colors), _ptr(rec_g[:, 6:gwidth]),
-                    _ptr(v_opacity), gstride, 0, gstride, _ptr(ws), ws.numel(), flags, cap, _ptr(qlists),
-                    qlists.numel(), _stream(dev)), "gg_blend_bwd_pair_lists")
-                ctx.qlists = None
-            else:
-                _lib.check(lib.gg_blend_bwd_pair(
-                    cols[wide].shape[1], cols[rider].shape[1], n, img_height, img_width, _ptr(ids_sorted),
-                    _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(cols[wide]), _ptr(cols[rider]), _ptr(opacity),
-                    _ptr(bgs[wide]), _ptr(bgs[rider]), _ptr(final_Ts), _ptr(final_idx), _ptr(vo_w), part_ptrs,
-                    part_chs, len(rp), _ptr(v_xy), _ptr(v_conic), _ptr(v_colors), _ptr(rec_g[:, 6:gwidth]),
-                    _ptr(v_opacity), gstride, 0, gstride, _ptr(ws), ws.numel(), flags, _stream(dev)),
-                    "gg_blend_bwd_pair")
+            _lib.check(lib.gg_blend_bwd_pair(
+                cols[wide].shape[1], cols[rider].shape[1], n, img_height, img_width, _ptr(ids_sorted),
+                _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(cols[wide]), _ptr(cols[rider]), _ptr(opacity),
+                _ptr(bgs[wide]), _ptr(bgs[rider]), _ptr(final_Ts), _ptr(final_idx), _ptr(vo_w), part_ptrs,
+                part_chs, len(rp), _ptr(v_xy), _ptr(v_conic), _ptr(v_colors), _ptr(rec_g[:, 6:gwidth]),
+                _ptr(v_opacity), gstride, 0, gstride, _ptr(ws), ws.numel(), flags, _stream(dev)),
+                "gg_blend_bwd_pair")
             grads[rider] = rec_g[:, 6:gwidth]
             if flags & 2:
                 if sink[2] is not None:

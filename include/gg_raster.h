@@ -254,37 +254,6 @@ int gg_blend_bwd_pair(int channels, int channels2, int num_points, int img_heigh
                       int color_stride, int color_stride2, void *ws, size_t ws_bytes, int flags,
                       gg_stream_t stream);
 
-/* ---- quad lists (round 3): the forward's quadrant-cull survivors, persisted for the backward walk ----------
- * gsplat's backward re-walks every tile list from `final_idx` down (csrc/backward.cu rasterize_backward_kernel);
- * gg_blend_bwd* do the same per 8x8 quadrant, and repeat for every entry the chain list id -> record -> exact
- * ellipse-vs-quadrant cull that the forward walk already ran — two thirds of the entries are thrown away again.
- * gg_blend_fwd_pair_lists is gg_blend_fwd_pair that also appends every quadrant's survivors, in list order, to
- * `quad_lists` (32-byte records {x, y, opacity, list position} {conic, Gaussian id}; layout in
- * csrc/blend_common.h), gg_blend_bwd_pair_lists is gg_blend_bwd_pair streaming those records instead of the
- * tile lists.  Same images, same gradients (the survivors are exactly the entries the backward's own cull keeps).
- * quad_lists: gg_quad_lists_workspace(num_intersects, H, W) bytes, 16-byte aligned; num_intersects = length of
- * gaussian_ids_sorted (4 x 32 bytes of capacity per list entry; about 0.74 records per entry are written).
- * The lists belong to one (tile lists, xys, conics, opacity) state: hand the backward the buffer its own forward
- * call wrote.  Counts are held to each quadrant's capacity, so a stale buffer cannot index out of bounds. */
-size_t gg_quad_lists_workspace(int64_t num_intersects, int img_height, int img_width);
-int gg_blend_fwd_pair_lists(int channels, int channels2, int num_points, int img_height, int img_width,
-                            const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
-                            const float *conics, const float *colors, const float *colors2,
-                            const float *opacity, const float *background, const float *background2,
-                            float *out_img, float *out_img2, float *final_Ts, int32_t *final_idx, void *ws,
-                            size_t ws_bytes, int64_t num_intersects, void *quad_lists, size_t quad_lists_bytes,
-                            gg_stream_t stream);
-int gg_blend_bwd_pair_lists(int channels, int channels2, int num_points, int img_height, int img_width,
-                            const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
-                            const float *conics, const float *colors, const float *colors2, const float *opacity,
-                            const float *background, const float *background2, const float *final_Ts,
-                            const int32_t *final_idx, const float *v_out_img, const float *const *v_out_img2_parts,
-                            const int *v_out_img2_channels, int num_parts, float *v_xy,
-                            float *v_conic, float *v_colors, float *v_colors2, float *v_opacity, int geom_stride,
-                            int color_stride, int color_stride2, void *ws, size_t ws_bytes, int flags,
-                            int64_t num_intersects, const void *quad_lists, size_t quad_lists_bytes,
-                            gg_stream_t stream);
-
 /* gg_blend_bwd_deterministic: gg_blend_bwd with bit-reproducible results.  gsplat's backward
  * (csrc/backward.cu: one atomicAdd per warp per Gaussian) and gg_blend_bwd add in whatever order the
  * hardware schedules; here the kernels store the total of every (tile-list entry, 8x8 quadrant) into a slab
@@ -313,12 +282,6 @@ int gg_blend_bwd_deterministic(int channels, int num_points, int img_height, int
 int gg_mlp_fwd(int64_t num_rows, int in_dim, int hidden_dim, int out_dim, const float *x,
                const float *w1, const float *b1, const float *w2, const float *b2, float *y,
                gg_stream_t stream);
-
-/* Tuning / test entry (round 3): 1 = the depth sort's four radix passes as one launch each (decoupled look-back over
- * per-digit counts, csrc/binning.hip radix_os_kernel: measured slower, 0.32 against 0.28 ms for the whole binning at 1 M
- * Gaussians), 0 = three launches per pass (the default).  Same order either way
- * (stable LSD passes); returns the previous value. */
-int gg_debug_set_depth_onesweep(int on);
 
 /* Tuning entry (round 3): how many 32-channel blocks of a wide colour array one forward walk takes — in the pair walk
  * of gg_blend_fwd_pair (1, 2 or 4) and in the walks of the remaining chunks / of gg_blend_fwd (1..4).  Images are

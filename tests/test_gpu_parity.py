@@ -1223,31 +1223,6 @@ def test_split_segment_returns_channel_slices_and_takes_separate_cotangents(orac
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,h,w", [(1, 16, 16), (3000, 64, 80), (50000, 300, 400), (300000, 600, 800)])
-def test_one_launch_depth_sort_passes_give_the_same_lists(oracle, n, h, w):
-    """gg_debug_set_depth_onesweep(1): the depth sort's radix passes as one launch each (decoupled look-back over
-    per-digit counts, csrc/binning.hip radix_os_kernel; an option, measured slower than the three-launch passes) —
-    tile lists, ranges and sorted tile ids bit-identical to the default's and to the oracle's 64-bit sort."""
-    from gaussiangrasper_amd import _lib
-    lib = _lib.load()
-    xys, depths, radii, conics, nth, colors, opac, bg = _blend_inputs(oracle, n, h, w, 3, seed=5)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
-    ref = oracle.bin_and_sort(xys, depths, radii, nth, ((w + 15) // 16, (h + 15) // 16, 1))
-    got = []
-    try:
-        for on in (0, 1):
-            lib.gg_debug_set_depth_onesweep(on)
-            P.clear_bin_cache()
-            b = P.bin_and_sort_gaussians(t(xys), t(depths), t(radii), t(nth), h, w)
-            got.append((_np(b.gaussian_ids_sorted)[:b.num_intersects].copy(), _np(b.tile_bins).copy()))
-    finally:
-        lib.gg_debug_set_depth_onesweep(0)
-    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
-    assert np.array_equal(got[1][0], ref["gaussian_ids_sorted"])
-    assert np.array_equal(got[1][1].reshape(-1, 2), np.asarray(ref["tile_bins"]).reshape(-1, 2))
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("c", [64, 96, 128, 160, 100])
 def test_forward_walks_over_several_channel_blocks_are_bit_identical(oracle, c):
     """A forward walk can take 2, 3 or 4 blocks of 32 channels at once (csrc/blend2.hip NCB, gg_debug_set_fwd_blocks;

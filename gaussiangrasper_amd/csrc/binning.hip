@@ -251,35 +251,59 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// exclusive scan of num_tiles_hit[order[r]]: ONE launch (decoupled look-back across workgroups, scan.h)
-// (r03: the same look-back moved INTO the emission kernel — 3 907 workgroups of 256 Gaussians instead of 489 of 2 048,
-//  no offsets array — measured 0.312 ms for the whole binning against 0.282: the chain of 3 907 published prefixes is
-//  longer than the launch and the 8 MB it saves; reverted)
+// exclusive scan of num_tiles_hit[order[r]]: block sums -> their scan -> offsets.  (r02-r03: ONE launch with a decoupled
+// look-back across workgroups; a look-back that gave up left every tile range empty and only gg_bin_sort_status, which
+// nothing called, said so — ADVICE r03.  Three plain launches have no wait that could give up; measured the same.)
 // ---------------------------------------------------------------------------------------------
 #define SC_THREADS 256
 #define SC_ITEMS 8
 #define SC_TILE (SC_THREADS * SC_ITEMS)
 
+__device__ __forceinline__ uint32_t scan_item(int N, const int32_t *__restrict__ nth, const uint32_t *__restrict__ order, int r) {
+    return (r < N) ? (uint32_t)nth[min(order[r], (uint32_t)(N - 1))] : 0u;   // (order: a permutation of 0..N-1)
+}
+__global__ __launch_bounds__(SC_THREADS) void scan_blocksum_kernel(int N, const int32_t *__restrict__ nth,
+                                                                  const uint32_t *__restrict__ order,
+                                                                  uint32_t *__restrict__ bsum) {
+    __shared__ unsigned int wsum[4];
+    const int base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; ++k) acc += scan_item(N, nth, order, base + k);
+    unsigned int total;
+    (void)scan_block256(acc, wsum, total);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+// one workgroup: exclusive scan of the block sums in place
+__global__ __launch_bounds__(256) void scan_bsum_kernel(int nblocks, uint32_t *__restrict__ bsum) {
+    __shared__ unsigned int wsum[4];
+    uint32_t carry = 0;
+    for (int start = 0; start < nblocks; start += 256) {
+        const int i = start + threadIdx.x;
+        const uint32_t v = i < nblocks ? bsum[i] : 0u;
+        unsigned int total;
+        const uint32_t ex = scan_block256(v, wsum, total);
+        if (i < nblocks) bsum[i] = carry + ex;
+        carry += total;
+    }
+}
 __global__ __launch_bounds__(SC_THREADS) void scan_offsets_kernel(
     int N, const int32_t *__restrict__ nth, const uint32_t *__restrict__ order,
-    uint32_t *__restrict__ offsets, ScanState *st, int nblocks) {
-    __shared__ unsigned int s_slot, s_excl, wsum[4];
-    const int bid = scan_ticket(st, &s_slot);
-    const int base = bid * SC_TILE + threadIdx.x * SC_ITEMS;
+    uint32_t *__restrict__ offsets, const uint32_t *__restrict__ bsum) {
+    __shared__ unsigned int wsum[4];
+    const int base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
     uint32_t v[SC_ITEMS];
     uint32_t acc = 0;
 #pragma unroll
     for (int k = 0; k < SC_ITEMS; ++k) {
-        int r = base + k;
-        v[k] = (r < N) ? (uint32_t)nth[min(order[r], (uint32_t)(N - 1))] : 0u;   // (order: a permutation unless a look-back gave up)
+        v[k] = scan_item(N, nth, order, base + k);
         acc += v[k];
     }
     unsigned int total;
-    uint32_t ex = scan_block256(acc, wsum, total);
-    ex += scan_lookback(st, bid, nblocks, total, &s_excl);
+    uint32_t ex = scan_block256(acc, wsum, total) + bsum[blockIdx.x];
 #pragma unroll
     for (int k = 0; k < SC_ITEMS; ++k) {
-        int r = base + k;
+        const int r = base + k;
         if (r < N) offsets[r] = ex;
         ex += v[k];
     }
@@ -355,13 +379,10 @@ __global__ __launch_bounds__(256) void tile_bins_kernel(int64_t I, const int64_t
                                                         const uint32_t *__restrict__ tkeys_sorted,
                                                         uint32_t num_tiles,
                                                         int32_t *__restrict__ tile_bins,
-                                                        int32_t *__restrict__ tile_out, const ScanState *st) {
+                                                        int32_t *__restrict__ tile_out) {
     I = dev_count(I, I_dev);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= I) return;
-    // a look-back of the offsets scan gave up (never expected): the lists are not to be trusted, and Gaussian ids
-    // from them would index the records — every tile keeps its empty range (gg_bin_sort_status reports it)
-    if (scan_failed(st)) return;
     uint32_t cur = tkeys_sorted[i];
     if (tile_out) tile_out[i] = (int32_t)cur;
     // tile ids >= num_tiles can only appear if the caller's I exceeds sum(num_tiles_hit) (entries
@@ -409,7 +430,7 @@ static BinWs bin_ws_layout(void *ws, int N, int64_t I) {
     w.dvalA = take(4 * n);
     w.dvalB = take(4 * n);
     w.offsets = take(4 * n);
-    w.block_sums = take(gg_scan_state_bytes((int)((n + SC_TILE - 1) / SC_TILE)));   // look-back state of the offsets scan
+    w.block_sums = take(4 * ((n + SC_TILE - 1) / SC_TILE));   // block sums of the offsets scan
     int nb = max(radix_nblocks(N), radix_nblocks(I));
     w.G = take(4 * 256 * (size_t)(nb + 1));
     w.totals = take(4 * 256);
@@ -475,12 +496,10 @@ static int bin_sort_impl(int N, int64_t I, const int64_t *I_dev, const float *xy
     const uint32_t *order = va;
     // 2. offsets in depth order
     int nsb = (N + SC_TILE - 1) / SC_TILE;
-    if (gg_fill_async(w.block_sums, 0, gg_scan_state_bytes(nsb), s) != hipSuccess) {
-        gg_set_error("gg_bin_sort: memset failed");
-        return GG_ERR_LAUNCH;
-    }
+    hipLaunchKernelGGL(scan_blocksum_kernel, dim3(nsb), dim3(SC_THREADS), 0, s, N, num_tiles_hit, order, w.block_sums);
+    hipLaunchKernelGGL(scan_bsum_kernel, dim3(1), dim3(256), 0, s, nsb, w.block_sums);
     hipLaunchKernelGGL(scan_offsets_kernel, dim3(nsb), dim3(SC_THREADS), 0, s, N, num_tiles_hit, order,
-                       w.offsets, (ScanState *)w.block_sums, nsb);
+                       w.offsets, w.block_sums);
     // 3./4. emit + sort by tile id; ping-pong so the last pass lands in gaussian_ids_sorted
     int tile_bits = 1;
     while ((1 << tile_bits) < T) ++tile_bits;
@@ -506,26 +525,21 @@ static int bin_sort_impl(int N, int64_t I, const int64_t *I_dev, const float *xy
     }
     // 5. tile ranges
     hipLaunchKernelGGL(tile_bins_kernel, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, s, I, I_dev, kcur,
-                       (uint32_t)T, tile_bins, isect_tile_sorted, (const ScanState *)w.block_sums);
+                       (uint32_t)T, tile_bins, isect_tile_sorted);
     gg_prof_end(GG_K_BIN_SORT, s);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
 
-// synchronous: waits for the stream, then reads the offsets scan's status word out of the workspace the sort ran in
+// Kept for ABI stability: up to round 3 the offsets scan waited on other workgroups inside the launch (decoupled
+// look-back) and a wait that gave up was reported here.  Since round 4 no binning kernel waits on another workgroup, so
+// there is no such failure to report: the call synchronises the stream and returns GG_OK.
 extern "C" int gg_bin_sort_status(int N, int64_t I, const void *ws, size_t ws_bytes, gg_stream_t stream) {
     GG_REQUIRE(N >= 0 && I >= 0, "negative size");
-    if (N == 0 || I == 0) return GG_OK;
-    BinWs w = bin_ws_layout(const_cast<void *>(ws), N, I);
-    GG_REQUIRE(ws != nullptr && ws_bytes >= w.bytes, "workspace too small");
-    ScanState st;
-    if (hipMemcpyAsync(&st, w.block_sums, sizeof(ScanState), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
-        hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
-        gg_set_error("gg_bin_sort_status: read-back failed");
-        return GG_ERR_LAUNCH;
-    }
-    if (st.error != 0u) {
-        gg_set_error("gg_bin_sort: the offsets scan's look-back timed out; the tile lists of this view were left empty");
+    (void)ws;
+    (void)ws_bytes;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+        gg_set_error("gg_bin_sort_status: stream synchronisation failed");
         return GG_ERR_LAUNCH;
     }
     return GG_OK;

@@ -177,9 +177,9 @@ int gg_bin_sort(int num_points, int64_t num_intersects, const float *xys, const 
  * min(count, capacity) entries.  The caller reads the count back later (asynchronously) and, in the
  * rare case count > capacity (lists truncated), calls again with a larger capacity.  Removes the one
  * host<->device round trip per view the reference has at this point (`.item()`). */
-/* Status of the sort that last ran in `ws` (same num_points / num_intersects or capacity as that call): waits for
- * the stream and returns an error if the offsets scan's decoupled look-back gave up — never expected; the sort then
- * left every tile range empty instead of publishing lists built from wrong offsets. */
+/* gg_bin_sort_status: kept for ABI stability.  Up to round 3 the offsets scan waited on other workgroups inside its
+ * launch and a wait that gave up was reported here; since round 4 no binning kernel waits on another workgroup (the scan
+ * is three plain launches), so there is nothing to report: the call synchronises the stream and returns GG_OK. */
 int gg_bin_sort_status(int num_points, int64_t num_intersects, const void *ws, size_t ws_bytes, gg_stream_t stream);
 int gg_bin_sort_dev(int num_points, int64_t capacity, const int64_t *num_intersects_dev,
                     const float *xys, const float *depths, const int32_t *radii,

@@ -146,6 +146,66 @@ def test_sh_fwd_bwd(oracle, k, deg):
 
 
 @pytest.mark.parametrize("n,h,w", [(1, 16, 16), (7, 45, 70), (1000, 48, 64), (50000, 300, 400),
+                                   (200000, 600, 800)])
+def test_project_fwd_bitexact(oracle, n, h, w):
+    sc, v = _scene_view(n, h, w)
+    ref = _project_oracle(oracle, sc, v)
+    got = _project_gpu(sc, v)
+    for name, r, g in zip(("xys", "depths", "radii", "conics", "num_tiles_hit", "cov3d"), ref, got):
+        assert_bitexact(_np(g), r, f"project_fwd.{name}")
+
+
+def test_project_fwd_culls_and_clamps(oracle):
+    """behind camera, z<=clip, off-screen, border clamp, huge Gaussian covering every tile"""
+    v = ring_cameras(1, 64, 96)[0]
+    cam = v.cam_pos.numpy()
+    fwd = -cam / np.linalg.norm(cam)
+    means = np.stack([cam - 1.0 * fwd, cam + 0.005 * fwd, cam + 0.0100001 * fwd, cam + 2.5 * fwd,
+                      cam + 2.5 * fwd + np.array([0, 5.0, 0]), cam + 2.5 * fwd + np.array([0, 0.9, 0]),
+                      cam + 2.5 * fwd]).astype(np.float32)
+    scales = np.full((7, 3), 0.01, np.float32)
+    scales[6] = 3.0
+    quats = np.tile(np.array([[1, 0, 0, 0]], np.float32), (7, 1))
+    ref = oracle.project_fwd(means, scales, 1.0, quats, _np(v.viewmat[:3]), _np(v.projmat), v.fx,
+                             v.fy, v.cx, v.cy, v.height, v.width, v.tile_bounds)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    got = P.ProjectGaussians.apply(t(means), t(scales), 1, t(quats), v.viewmat[:3].to(DEV),
+                                   v.projmat.to(DEV), v.fx, v.fy, v.cx, v.cy, v.height, v.width,
+                                   v.tile_bounds)
+    for name, r, g in zip(("xys", "depths", "radii", "conics", "num_tiles_hit", "cov3d"), ref, got):
+        assert_bitexact(_np(g), r, f"project_fwd.{name}")
+    radii = ref[2]
+    assert radii[0] == 0 and radii[1] == 0 and radii[3] > 0 and radii[4] == 0
+    assert ref[4][6] == v.tile_bounds[0] * v.tile_bounds[1]  # huge one hits every tile
+
+
+@pytest.mark.parametrize("k,deg", [(1, 0), (4, 1), (9, 2), (16, 3), (25, 4), (25, 2), (25, 0)])
+def test_sh_fwd_bwd(oracle, k, deg):
+    n = 5000 + 37
+    g = torch.Generator().manual_seed(k * 10 + deg)
+    vd = torch.randn(n, 3, generator=g)
+    cf = torch.randn(n, k, 3, generator=g)
+    vc = torch.randn(n, 3, generator=g)
+    cfd = cf.to(DEV).requires_grad_(True)
+    out = P.SphericalHarmonics.apply(deg, vd.to(DEV), cfd)
+    assert_bitexact(_np(out), oracle.sh_fwd(deg, _np(vd), _np(cf)), "sh_fwd")
+    out.backward(vc.to(DEV))
+    assert_bitexact(_np(cfd.grad), oracle.sh_bwd(deg, k, _np(vd), _np(vc)), "sh_bwd")
+
+
+@pytest.fixture(params=["counting", "radix"])
+def bin_path(request, monkeypatch):
+    """Both binning paths of csrc/binning.hip: the counting sort by tile + per-tile sort (default, round 4) and the
+    radix path of rounds 1-3 that remains for tile grids whose histogram does not fit the LDS (forced here by
+    GG_BIN_TILES_MAX=0, which the library reads at every call)."""
+    if request.param == "radix":
+        monkeypatch.setenv("GG_BIN_TILES_MAX", "0")
+    else:
+        monkeypatch.delenv("GG_BIN_TILES_MAX", raising=False)
+    return request.param
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 16, 16), (7, 45, 70), (1000, 48, 64), (50000, 300, 400),
                                    (300000, 600, 800)])
 def test_binning_bitexact(oracle, n, h, w):
     sc, v = _scene_view(n, h, w)
@@ -158,22 +218,30 @@ def test_binning_bitexact(oracle, n, h, w):
     assert_bitexact(_np(b.gaussian_ids_sorted), ref["gaussian_ids_sorted"], "gaussian_ids_sorted")
 
 
+def _tie_inputs(n, h, w, rmax, seed=5):
+    """random centres, a handful of DISTINCT depth values (so most keys tie on depth) and radii up to rmax pixels"""
+    rng = np.random.default_rng(seed)
+    tx, ty = (w + 15) // 16, (h + 15) // 16
+    xys = np.stack([rng.uniform(0, w, n), rng.uniform(0, h, n)], axis=1).astype(np.float32)
+    depths = rng.choice(np.array([1.0, 1.5, 2.0, 2.0000002], np.float32), n)
+    radii = rng.integers(0, rmax, n).astype(np.int32)
+    f = np.float32
+    cx, cy, r = xys[:, 0] / f(16), xys[:, 1] / f(16), radii.astype(np.float32) / f(16)
+    x0 = np.clip(cx - r, 0, tx).astype(np.int32)
+    x1 = np.clip((cx + r) + f(1), 0, tx).astype(np.int32)
+    y0 = np.clip(cy - r, 0, ty).astype(np.int32)
+    y1 = np.clip((cy + r) + f(1), 0, ty).astype(np.int32)
+    nth = ((x1 - x0) * (y1 - y0)).astype(np.int32)
+    nth[radii <= 0] = 0
+    radii[nth == 0] = 0
+    return xys, depths, radii, nth, (tx, ty, 1)
+
+
 def test_binning_ties_and_duplicates(oracle):
     """many Gaussians with IDENTICAL depth: ties must come out in ascending Gaussian id"""
     n, h, w = 5000, 64, 64
-    rng = np.random.default_rng(5)
-    xys = rng.uniform(0, 64, (n, 2)).astype(np.float32)
-    depths = rng.choice(np.array([1.0, 1.5, 2.0, 2.0000002], np.float32), n)
-    radii = rng.integers(0, 20, n).astype(np.int32)
-    nth = np.zeros(n, np.int32)
-    for i in range(n):
-        if radii[i] > 0:
-            x0, x1 = int(np.clip(xys[i, 0] / 16 - radii[i] / 16, 0, 4)), int(np.clip(xys[i, 0] / 16 + radii[i] / 16 + 1, 0, 4))
-            y0, y1 = int(np.clip(xys[i, 1] / 16 - radii[i] / 16, 0, 4)), int(np.clip(xys[i, 1] / 16 + radii[i] / 16 + 1, 0, 4))
-            nth[i] = (x1 - x0) * (y1 - y0)
-            if nth[i] == 0:
-                radii[i] = 0
-    ref = oracle.bin_and_sort(xys, depths, radii, nth, (4, 4, 1))
+    xys, depths, radii, nth, tb = _tie_inputs(n, h, w, 20)
+    ref = oracle.bin_and_sort(xys, depths, radii, nth, tb)
     t = lambda a: torch.from_numpy(a).to(DEV)
     b = P.bin_and_sort_gaussians(t(xys), t(depths), t(radii), t(nth), h, w, use_cache=False)
     assert b.num_intersects == ref["num_intersects"] == int(nth.sum())
@@ -181,14 +249,64 @@ def test_binning_ties_and_duplicates(oracle):
     assert_bitexact(_np(b.gaussian_ids_sorted), ref["gaussian_ids_sorted"], "gaussian_ids_sorted")
 
 
-def _blend_inputs(oracle, n, h, w, ch, seed=0, cfg=1):
-    sc, v = _scene_view(n, h, w, cfg=cfg)
+@pytest.mark.parametrize("n,h,w,rmax", [(30000, 48, 48, 40), (90000, 32, 48, 60), (200000, 32, 32, 80),
+                                        (40000, 16, 16, 30)])
+def test_binning_long_tile_lists(oracle, n, h, w, rmax):
+    """Few tiles, many Gaussians each: lists of 2 k ... 200 k entries with most keys tied on depth (four distinct depth
+    values: ties must come out in ascending Gaussian id).  The C-ABI call also asks for the sorted tile ids.
+    (Written for round 4's counting-sort experiment, profiles/r04_counting_sort_binning_experiment.patch, whose per-tile
+    sorts had size classes; kept: the radix path has no other test with lists this long.)"""
+    from gaussiangrasper_amd import _lib
+    xys, depths, radii, nth, tb = _tie_inputs(n, h, w, rmax, seed=9)
+    ref = oracle.bin_and_sort(xys, depths, radii, nth, tb)
+    I = int(ref["num_intersects"])
+    lens = np.diff(np.asarray(ref["tile_bins"]).reshape(-1, 2), axis=1).ravel()
+    assert lens.max() > 2048
+    lib = _lib.load()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    xt, dt, rt, nt = t(xys), t(depths), t(radii), t(nth)
+    ids = torch.full((I,), -7, dtype=torch.int32, device=DEV)
+    tiles = torch.full((I,), -7, dtype=torch.int32, device=DEV)
+    bins = torch.empty(tb[0] * tb[1], 2, dtype=torch.int32, device=DEV)
+    ws = torch.empty(lib.gg_bin_sort_workspace(n, I), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.gg_bin_sort(n, I, P._ptr(xt), P._ptr(dt), P._ptr(rt), P._ptr(nt), tb[0], tb[1], P._ptr(ids),
+                               P._ptr(bins), P._ptr(tiles), P._ptr(ws), ws.numel(), P._stream(xt.device)), "gg_bin_sort")
+    torch.cuda.synchronize()
+    assert_bitexact(_np(bins), ref["tile_bins"], "tile_bins")
+    assert_bitexact(_np(ids), ref["gaussian_ids_sorted"], "gaussian_ids_sorted")
+    want_tiles = np.repeat(np.arange(tb[0] * tb[1], dtype=np.int32), lens)
+    assert_bitexact(_np(tiles), want_tiles, "isect_tile_sorted")
+
+
+def test_binning_truncated_capacity_stays_in_bounds(oracle):
+    """gg_bin_sort_dev with a capacity BELOW the count on the device (what a speculative call can meet before it is
+    re-binned): every tile range is held to the capacity, every id is a Gaussian's and nothing is written past it (the
+    emission is truncated in depth order: no list is complete, all are in bounds)."""
+    from gaussiangrasper_amd import _lib
+    n, h, w = 20000, 160, 208
+    sc, v = _scene_view(n, h, w)
     xys, depths, radii, conics, nth, _ = _project_oracle(oracle, sc, v)
-    rng = np.random.default_rng(seed)
-    colors = rng.uniform(-1, 1, (n, ch)).astype(np.float32)
-    opac = torch.sigmoid(sc.opacities).numpy()
-    bg = rng.uniform(0, 1, ch).astype(np.float32)
-    return xys, depths, radii, conics, nth, colors, opac, bg
+    ref = oracle.bin_and_sort(xys, depths, radii, nth, v.tile_bounds)
+    true_i = int(ref["num_intersects"])
+    cap = true_i // 2
+    lib = _lib.load()
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    xt, dt, rt, nt = t(xys), t(depths), t(radii), t(nth)
+    total = torch.tensor([true_i], dtype=torch.int64, device=DEV)
+    guard = 4096
+    ids = torch.full((cap + guard,), -7, dtype=torch.int32, device=DEV)
+    ntiles = v.tile_bounds[0] * v.tile_bounds[1]
+    bins = torch.empty(ntiles, 2, dtype=torch.int32, device=DEV)
+    ws = torch.empty(lib.gg_bin_sort_workspace(n, cap), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.gg_bin_sort_dev(n, cap, P._ptr(total), P._ptr(xt), P._ptr(dt), P._ptr(rt), P._ptr(nt),
+                                   v.tile_bounds[0], v.tile_bounds[1], P._ptr(ids), P._ptr(bins), None, P._ptr(ws),
+                                   ws.numel(), P._stream(xt.device)), "gg_bin_sort_dev")
+    torch.cuda.synchronize()
+    got_bins, got_ids = _np(bins).reshape(-1, 2), _np(ids)
+    assert got_bins.min() >= 0 and got_bins.max() <= cap
+    assert np.all(got_ids[cap:] == -7), "written past the capacity"
+    ids_in = got_ids[:cap]
+    assert ids_in.min() >= 0 and ids_in.max() < n
 
 
 @pytest.mark.parametrize("n,h,w,ch", [(1, 16, 16, 3), (7, 45, 70, 3), (2000, 48, 64, 1),

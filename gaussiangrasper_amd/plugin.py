@@ -158,13 +158,52 @@ def _camera_scalars(camera):
     return fx, fy, cx, cy, ax, ay, w, h
 
 
-def make_fused_model_class(base, ops=_ops, background_override=lambda: None, fused_training: bool = False):
+def _default_loss_ops():
+    from . import losses
+    return losses
+
+
+def _default_mlp_class():
+    from .mlp import MLP
+    return MLP
+
+
+def _resize_image(mod, img_hwc, newsize):
+    """`TF.resize(img.permute(2, 0, 1), newsize, antialias=None).permute(1, 2, 0)` (gaussian_splatting.py:849-851) with
+    the reference module's own torchvision if it has one; without torchvision, the call torchvision makes for a
+    tensor with antialias off: bilinear interpolation, align_corners=False."""
+    tf = getattr(mod, "TF", None)
+    chw = img_hwc.permute(2, 0, 1)
+    if tf is not None:
+        return tf.resize(chw, newsize, antialias=None).permute(1, 2, 0)
+    return torch.nn.functional.interpolate(chw[None], size=tuple(newsize), mode="bilinear", align_corners=False,
+                                           antialias=False)[0].permute(1, 2, 0)
+
+
+def _nearest_columns(src_chw: torch.Tensor, size, pixels: torch.Tensor) -> torch.Tensor:
+    """`F.interpolate(src[None], size=size, mode="nearest")[0][:, pixels[:, 0], pixels[:, 1]]` without the (C, H, W)
+    intermediate (512 x 1200 x 1600 floats = 3.9 GB per view at the bench size; the reference builds it at :875-876 and
+    then reads <= 1000 columns of it, :918).  ATen's nearest rule: source index = min(floor(dst * float(in / out)), in - 1)."""
+    c, hs, ws = src_chw.shape
+    sy = torch.tensor(hs / size[0], dtype=torch.float32)
+    sx = torch.tensor(ws / size[1], dtype=torch.float32)
+    iy = torch.clamp((pixels[:, 0].to(torch.float32) * sy.to(pixels.device)).floor().long(), max=hs - 1)
+    ix = torch.clamp((pixels[:, 1].to(torch.float32) * sx.to(pixels.device)).floor().long(), max=ws - 1)
+    return src_chw[:, iy, ix]
+
+
+def make_fused_model_class(base, ops=_ops, background_override=lambda: None, fused_training: bool = False,
+                           loss_ops=None, mlp_class="default"):
     """Subclass of the reference's GaussianSplattingModel whose get_outputs uses `fused_view`.
     `base` is nerfstudio.models.gaussian_splatting.GaussianSplattingModel (or `stub.StubGaussianSplattingModel`,
     which restates the attributes used here, where nerfstudio is not installed).
     fused_training: the optimizer-side callbacks run on csrc/densify.hip too (`after_train`,
     `refinement_after` through `densify.Refiner`: statistics, masks, split / duplicate / cull and the Adam-state
-    surgery of the six groups in a handful of launches, reference :373-546)."""
+    surgery of the six groups in a handful of launches, reference :373-546), `get_loss_dict` (:841-935) computes its
+    image-space terms with the fused loss kernels (`loss_ops`, default gaussiangrasper_amd.losses: main_loss,
+    depth_normal_loss, cosine_similarity_loss, gather_pixels) and `fea_up` (:258) becomes `mlp_class` (default
+    gaussiangrasper_amd.mlp.MLP: same sub-modules and state-dict keys, fused forward / backward kernels; None keeps the
+    reference's module)."""
 
     class FusedGaussianSplattingModel(base):
         """GaussianSplattingModel on the fused MI355X rasterizer call (gaussiangrasper_amd.plugin)."""
@@ -259,6 +298,91 @@ def make_fused_model_class(base, ops=_ops, background_override=lambda: None, fus
                 return LazyOutputs(out, lazy)
             out.update({k: f() for k, f in lazy.items()})
             return out
+
+        # ---- losses and fea_up (fused_training) --------------------------------------------------
+        def populate_modules(self):
+            super().populate_modules()
+            cls = _default_mlp_class() if mlp_class == "default" else mlp_class
+            if fused_training and cls is not None and hasattr(self, "fea_up"):
+                old = self.fea_up
+                l0, l2 = old.layers[0], old.layers[-1]
+                new = cls(l0.in_features, l2.out_features, hidden_list=[l0.out_features])
+                new.load_state_dict(old.state_dict())        # same keys: fea_up.layers.{0,2}.{weight,bias}
+                self.fea_up = new.to(l0.weight.device)
+
+        def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, torch.Tensor]:
+            """gaussian_splatting.py:841-935 with the same keys, the same ground-truth preparation (resize /
+            interpolate / masks, :846-876), the same sampling helpers and random draws (:909-910) and the same
+            regularisers (:920-929); the image-space terms run on the fused kernels:
+              main_loss (:882-885, :931)      one pass each way instead of ten grouped conv2d launches each way;
+              depth_loss, normal_loss (:879-880)  one pass each way, no boolean-index gathers;
+              feature_loss, up_loss (:911-918)    ONE gather of all sampled pixel sets, fused cosine losses, `fea_up`
+                                               on the MLP kernels; the nearest-neighbour up-sampling of the
+                                               (h, w, 512) ground-truth feature map is evaluated at the <= 1000 sampled
+                                               pixels only (same values, no (512, H, W) intermediate).
+            Unlike the reference it does not zero `gt_img` / `outputs["rgb"]` at the invalid pixels in place (:883-884:
+            a side effect of how the reference feeds its SSIM; nothing reads either afterwards)."""
+            if not fused_training:
+                return super().get_loss_dict(outputs, batch, metrics_dict)
+            import sys
+            F = torch.nn.functional
+            L = loss_ops if loss_ops is not None else _default_loss_ops()
+            mod = sys.modules.get(base.__module__)
+            sampling_pairs_in_mask, sampling_in_mask = mod.sampling_pairs_in_mask, mod.sampling_in_mask
+            d = self._get_downscale_factor()
+            if d > 1:
+                newsize = [batch["image"].shape[0] // d, batch["image"].shape[1] // d]
+                gt_img = _resize_image(mod, batch["image"], newsize)
+            else:
+                gt_img = batch["image"]
+            size = (gt_img.shape[0], gt_img.shape[1])
+            gt_normal = batch["normal"].permute(2, 0, 1).unsqueeze(0).to(self.device)
+            gt_normal = F.interpolate(gt_normal, size=size, mode='bilinear').squeeze(0)
+            gt_normal = F.normalize(gt_normal, dim=0)
+            gt_depth = batch["depth"].permute(2, 0, 1).unsqueeze(0).to(self.device)
+            depth_mask = (gt_depth > 0.05) * 1.0
+            gt_depth = F.interpolate(gt_depth, size=size, mode='bilinear').squeeze(0)
+            depth_mask = F.interpolate(depth_mask, size=size, mode='nearest').squeeze(0)
+            gt_mask = batch["sam_mask"].to(self.device)
+            gt_mask = F.interpolate(gt_mask.float().unsqueeze(0).unsqueeze(0), size=size,
+                                    mode='nearest').squeeze(0).squeeze(0)
+            valid_mask = batch["valid_mask"].to(self.device)
+            valid_mask = F.interpolate(valid_mask.float().unsqueeze(0).unsqueeze(0), size=size,
+                                       mode='nearest').squeeze(0).squeeze(0)
+            depth_mask = depth_mask * valid_mask
+            depth_mask = depth_mask > 0
+            valid_mask = valid_mask > 0
+            gt_mask[~valid_mask] = -1.0
+            gt_fea = batch["feature"].permute(2, 0, 1).float().to(self.device)      # (:875-876: read below, at the samples)
+
+            depth_loss, normal_loss = L.depth_normal_loss(outputs["depth"], gt_depth, outputs["normal"], gt_normal,
+                                                          depth_mask[0])                       # :879-880
+            main_loss = L.main_loss(outputs["rgb"], gt_img.to(self.device), valid_mask,
+                                    self.config.ssim_lambda)[0]                                 # :882-885, :931
+
+            feature = outputs["feature"]
+            selected_pairs = sampling_pairs_in_mask(gt_mask, 800)                               # :909
+            selected_points = sampling_in_mask(gt_mask, 1000)                                   # :910
+            sets = [p for pair in selected_pairs for p in pair] + [selected_points]
+            rows = L.gather_pixels(feature, *sets)             # the reference's 2 len(pairs) + 1 gathers (:912-917) in one
+            fea_loss = 0
+            for i in range(len(selected_pairs)):
+                fea_loss += L.cosine_similarity_loss(rows[2 * i].permute(1, 0), rows[2 * i + 1].permute(1, 0))
+            fea_loss = fea_loss / len(selected_pairs)
+            fea_up = self.fea_up(rows[-1]).permute(1, 0)
+            up_loss = L.cosine_similarity_loss(fea_up, _nearest_columns(gt_fea, size, selected_points))
+
+            if self.step % 10 == 0:                                                             # :920-929, as they are
+                sh_reg = self.colors_all[:, 1:, :].norm(dim=1).mean()
+                scale_exp = torch.exp(self.scales)
+                scale_reg = torch.maximum(scale_exp.amax(dim=-1) / scale_exp.amin(dim=-1),
+                                          torch.tensor(self.config.max_gauss_ratio)) - self.config.max_gauss_ratio
+                scale_reg = 0.1 * scale_reg.mean()
+            else:
+                sh_reg = torch.tensor(0.0).to(self.device)
+                scale_reg = torch.tensor(0.0).to(self.device)
+            return {"main_loss": main_loss, "feature_loss": fea_loss, "up_loss": up_loss, "depth_loss": depth_loss,
+                    "normal_loss": normal_loss, "sh_reg": sh_reg, "scale_reg": scale_reg}
 
         # ---- optimizer side (fused_training) -----------------------------------------------------
         def _refiner(self, optimizers=None):

@@ -8,9 +8,13 @@ reference's own `get_outputs` / callbacks read are restated, with the reference'
 
   StubCameras                 nerfstudio/cameras/cameras.py:69-99 (fields), :935-961 (rescale_output_resolution)
   StubGaussianSplattingModel  nerfstudio/models/gaussian_splatting.py:248-299 (populate_modules: the six Gaussian
-                              parameters, statistics, step, crop_box, back_color, config), :599-603
+                              parameters, `fea_up`, statistics, step, crop_box, back_color, config), :599-603
                               (_get_downscale_factor), :548-571 (get_training_callbacks: after_train, then
-                              refinement_after every refine_every steps), :574-586 (step_cb, param groups)"""
+                              refinement_after every refine_every steps), :574-586 (step_cb, param groups)
+  sampling_in_mask, sampling_pairs_in_mask, MLP
+                              the module-level helpers of gaussian_splatting.py that `get_loss_dict` calls (:120-148,
+                              :198-213): the plugin's override looks them up in its base class's MODULE, which is the
+                              reference's own file under nerfstudio and this one here"""
 from __future__ import annotations
 
 import types
@@ -18,6 +22,55 @@ from typing import Dict, List, Optional
 
 import torch
 from torch.nn import Parameter
+
+
+def sampling_in_mask(mask, sample_num):
+    """Behaviour of gaussian_splatting.py:120-132: for every label > -1 of the mask (ascending, `torch.unique`), up to
+    sample_num // (number of labels - 1) of its pixels, drawn by ONE `torch.randperm` over the label's pixel count
+    (row-major `torch.where` order) — the same draws from the global RNG, in the same order, as the reference's.
+    Returns (M, 2) long (row, col)."""
+    mask = mask.detach()
+    labels = torch.unique(mask)
+    per_label = sample_num // (len(labels) - 1)
+    out = []
+    for lab in labels:
+        if lab > -1:
+            rows, cols = torch.where(mask == lab)
+            pick = torch.randperm(rows.shape[0])[:min(per_label, rows.shape[0])]
+            out.append(torch.stack((rows[pick], cols[pick]), dim=1))
+    return torch.cat(out)
+
+
+def sampling_pairs_in_mask(mask, sample_num):
+    """Behaviour of gaussian_splatting.py:134-148: for every label > -1, two independent draws (two `torch.randperm`
+    calls, first set first) of up to sample_num of its pixels.  Returns [[first (M, 2), second (M, 2)], ...]."""
+    mask = mask.detach()
+    pairs = []
+    for lab in torch.unique(mask):
+        if lab > -1:
+            rows, cols = torch.where(mask == lab)
+            m = min(sample_num, rows.shape[0])
+            one = torch.randperm(rows.shape[0])[:m]
+            first = torch.stack((rows[one], cols[one]), dim=1)
+            two = torch.randperm(rows.shape[0])[:m]
+            pairs.append([first, torch.stack((rows[two], cols[two]), dim=1)])
+    return pairs
+
+
+class MLP(torch.nn.Module):
+    """gaussian_splatting.py:198-213 (`self.fea_up = MLP(self.feature_dim, self.clip_dim, hidden_list=[128])`, :258)"""
+
+    def __init__(self, in_dim=8, out_dim=512, hidden_list=(128,)):
+        super().__init__()
+        layers, lastv = [], in_dim
+        for hidden in hidden_list:
+            layers += [torch.nn.Linear(lastv, hidden), torch.nn.ReLU()]
+            lastv = hidden
+        layers.append(torch.nn.Linear(lastv, out_dim))
+        self.layers = torch.nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.layers(x)
 
 
 class StubCameras:
@@ -96,10 +149,16 @@ class StubGaussianSplattingModel(torch.nn.Module):
         self.crop_box = None
         self.back_color = torch.zeros(3)
         self.feature_dim = scene.feature.shape[1]
+        self.clip_dim = 512
         self.camera_optimizer = StubCameraOptimizer()
         self.xys_grad_norm = None
         self.vis_counts = None
         self.max_2Dsize = None
+        self.populate_modules()          # models/base_model.py: Model.__init__ ends with this call
+
+    def populate_modules(self):
+        """the part of gaussian_splatting.py:248-299 the plugin's override builds on: `fea_up` (:258)"""
+        self.fea_up = MLP(self.feature_dim, self.clip_dim, hidden_list=[128])
 
     @property
     def device(self):

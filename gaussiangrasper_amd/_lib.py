@@ -65,6 +65,7 @@ SIGNATURES = {
     "gg_blend_workspace": (_SZ, [_I]),
     "gg_blend_fwd": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gg_blend_fwd_pair": (_I, [_I, _I, _I, _I, _I] + [_P] * 14 + [_SZ, _P]),
+    "gg_blend_fwd_pair_fast": (_I, [_I, _I, _I, _I, _I] + [_P] * 14 + [_SZ, _P]),
     "gg_blend_bwd": (_I, [_I, _I, _I, _I] + [_P] * 14 + [_I, _I, _P, _SZ, _I, _P]),
     "gg_shade_tail_bwd_split": (_I, [_I, _P, _I, _P, _P, _P, _P, _P]),
     "gg_sh_bwd_multi": (_I, [_I, _I, _I, _I, C.POINTER(_P), C.POINTER(_P), _P, _I, _P]),

@@ -71,7 +71,7 @@ void gg_launch_blend2_bwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
 void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int ntiles, const int32_t *ids,
                                const int2 *bins, const GRec *rec, const float *colors, const float *background,
                                float *out_img, float *final_Ts, int32_t *final_idx, const float *colors2, int C2,
-                               const float *background2, float *out_img2, hipStream_t s, int ncb);
+                               const float *background2, float *out_img2, hipStream_t s, int ncb, bool fast);
 void gg_launch_blend2_fwd_blocks(int ncb, int C, int off, int img_h, int img_w, int tiles_x, int ntiles,
                                  const int32_t *ids, const int2 *bins, const GRec *rec, const float *colors,
                                  const float *background, float *out_img, float *final_Ts, int32_t *final_idx,
@@ -182,7 +182,7 @@ static int blend_fwd_pair_impl(int C, int C2, int N, int img_h, int img_w, const
                                  const float *colors, const float *colors2, const float *opacity,
                                  const float *background, const float *background2, float *out_img,
                                  float *out_img2, float *final_Ts, int32_t *final_idx, void *ws,
-                                 size_t ws_bytes, gg_stream_t stream) {
+                                 size_t ws_bytes, gg_stream_t stream, bool fast) {
     GG_REQUIRE(C >= 32, "the first colour array needs >= 32 channels (its first chunk carries the second array)");
     GG_REQUIRE(C2 >= 1 && C2 <= 8, "the second colour array has 1..8 channels");
     GG_REQUIRE(N >= 0, "num_points < 0");
@@ -204,16 +204,20 @@ static int blend_fwd_pair_impl(int C, int C2, int N, int img_h, int img_w, const
     }
     const int tiles_x = (img_w + GG_BLOCK - 1) / GG_BLOCK, tiles_y = (img_h + GG_BLOCK - 1) / GG_BLOCK;
     const int ntiles = tiles_x * tiles_y;
+    // the batched kernel (fp32-grade images, not the exact summation order) needs 16-byte aligned image rows; without
+    // them the exact-order kernel runs (its scalar-store epilogue takes any layout)
+    fast = fast && (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_img) & 15) == 0) &&
+           ((reinterpret_cast<uintptr_t>(background) & 15) == 0);
     // the pair walk takes 1, 2 or 4 blocks of the first array (aligned rows)
     int pair_blocks = 1;
-    if ((C % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_img) & 15) == 0)) {
+    if (!fast && (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_img) & 15) == 0)) {
         if (g_fwd_blocks_pair >= 4 && C >= 128) pair_blocks = 4;
         else if (g_fwd_blocks_pair >= 2 && C >= 64) pair_blocks = 2;
     }
     gg_prof_begin(GG_K_BLEND_FWD_PAIR, s);
     gg_launch_blend2_fwd_pair(C, img_h, img_w, tiles_x, ntiles, ids, (const int2 *)tile_bins, rec, colors,
                               background, out_img, final_Ts, final_idx, colors2, C2, background2, out_img2, s,
-                              pair_blocks);
+                              pair_blocks, fast);
     gg_prof_end(GG_K_BLEND_FWD_PAIR, s);
     fwd_remaining_chunks(C, 32 * pair_blocks, img_h, img_w, tiles_x, ntiles, ids, tile_bins, rec, colors, background,
                          out_img, final_Ts, final_idx, false, s);
@@ -228,7 +232,17 @@ extern "C" int gg_blend_fwd_pair(int C, int C2, int N, int img_h, int img_w, con
                                  float *out_img2, float *final_Ts, int32_t *final_idx, void *ws,
                                  size_t ws_bytes, gg_stream_t stream) {
     return blend_fwd_pair_impl(C, C2, N, img_h, img_w, ids, tile_bins, xys, conics, colors, colors2, opacity, background,
-                               background2, out_img, out_img2, final_Ts, final_idx, ws, ws_bytes, stream);
+                               background2, out_img, out_img2, final_Ts, final_idx, ws, ws_bytes, stream, false);
+}
+
+extern "C" int gg_blend_fwd_pair_fast(int C, int C2, int N, int img_h, int img_w, const int32_t *ids,
+                                      const int32_t *tile_bins, const float *xys, const float *conics,
+                                      const float *colors, const float *colors2, const float *opacity,
+                                      const float *background, const float *background2, float *out_img,
+                                      float *out_img2, float *final_Ts, int32_t *final_idx, void *ws,
+                                      size_t ws_bytes, gg_stream_t stream) {
+    return blend_fwd_pair_impl(C, C2, N, img_h, img_w, ids, tile_bins, xys, conics, colors, colors2, opacity, background,
+                               background2, out_img, out_img2, final_Ts, final_idx, ws, ws_bytes, stream, true);
 }
 
 // ---------------------------------------------------------------------------------------------

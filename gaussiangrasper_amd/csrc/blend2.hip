@@ -392,6 +392,261 @@ void blend2_fwd_kernel(
 }
 
 // =============================================================================================
+// forward, pair, BATCHED (round 4; gg_blend_fwd_pair_fast): the backward's architecture for the forward walk
+// =============================================================================================
+// The exact-order pair forward above contracts over TWO Gaussians per v_mfma_f32_32x32x2_f32 (64 cycles each: a quarter
+// of the kernel's issue budget, r03 counters), spends 5.5 issue slots per pair on the v_permlane32_swap that builds its A
+// operand and 8 fma per (pixel, Gaussian) on the second array.  Here the survivors of the quadrant cull are QUEUED
+// (ascending list order) until 32 are there; the walk — the same sigma / exp / alpha / T arithmetic, operation for
+// operation, so final_T, final_idx and every pass / stop decision keep their bits — only writes vis = alpha T into a
+// slab [pixel][slot]; the batch then ends with ONE product
+//     OUT[64 pixels x 48 channels] += VIS[64 x 32 slots] * COL[32 x 48]        (32 feature channels | <= 8 of the second
+// array | padding) as 4 x 3 tiles of v_mfma_f32_16x16x32_f16 on fp16 TWO-PIECE operands (gg_common.h: x s = hi + lo,
+// four piece products per tile, fp32 accumulation): 48 MFMAs of 16 cycles per 32 Gaussians instead of 32 of 64 cycles
+// plus 256 fma.  Scales (powers of two, exact): vis x 2^15 (alpha T lies in [3.9e-7, 1)); the colours of a batch one
+// scale per CHANNEL (largest |colour| of the 32 slots into [2^14, 2^15)), taken out of the tile's result before it is
+// added to the fp32 accumulators.  Images therefore equal the exact-order kernel's to fp32 rounding, not bit for bit:
+// per channel the error is <= ~2^-22 of (largest |colour| of the batch) x (sum of vis) — elements more than 2^12 below
+// their channel's largest colour of the batch keep an ABSOLUTE error of 2^-40 of that colour (fp16 denormals) —
+// against the exact kernel's own ~n 2^-24 of the sequential fp32 sum.  tests/test_fast_forward.py holds the images to
+// 1e-6 (1 + |value|) of the oracle's and final_T / final_idx to its bits.
+// LDS per wave: queue 3.2 KB + slab 8 KB (16-byte chunks of a pixel's 32 slots XOR-swizzled by the pixel: the walk's
+// ds_write_b128 and the product's ds_read_b128 both spread over the banks).  One quadrant per 64-thread workgroup
+// (as the wide backward): 14 waves per CU by LDS.
+#define FB_SLOTS 32
+#define FB_QCAP 100     // <= 31 left over + 64 staged + 4 null records behind the last survivor
+#ifndef GG_FB_WAVES
+#define GG_FB_WAVES 3
+#endif
+struct __attribute__((aligned(16))) FwdQueue {
+    float4 a[FB_QCAP];   // x, y, opacity, list position + 1 (int bits)
+    float4 b[FB_QCAP];   // conic a, b, c, Gaussian id (int bits)
+};
+#define GG_VIS_SCALE 32768.0f
+#define GG_VIS_UNSCALE (1.0f / 32768.0f)
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GG_FB_WAVES))) void blend2_fwd_batch_kernel(
+    int C, int img_h, int img_w, int tiles_x, int ntiles, const int32_t *__restrict__ ids,
+    const int2 *__restrict__ bins, const GRec *__restrict__ rec, const float *__restrict__ colors,
+    const float *__restrict__ background, float *__restrict__ out_img, float *__restrict__ final_T,
+    int32_t *__restrict__ final_idx, Seg2 seg2) {
+    __shared__ FwdQueue s_q;
+    __shared__ __attribute__((aligned(16))) float s_vis[64 * FB_SLOTS];
+    int wave;
+    const int tile = blend_tile_wave<1>(blockIdx.x, threadIdx.x, ntiles, wave);
+    if (tile < 0) return;
+    const int lane = threadIdx.x & 63;
+    FwdQueue &Q = s_q;
+    float *vis_w = s_vis;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int qx0 = tx * GG_BLOCK + (wave & 1) * 8, qy0 = ty * GG_BLOCK + (wave >> 1) * 8;
+    const int j = qx0 + (lane & 7), i = qy0 + (lane >> 3);
+    const bool inside = (i < img_h) && (j < img_w);
+    const float px = (float)j, py = (float)i;
+    const int2 range = bins[tile];
+    const int sl = lane & 15, q4 = lane >> 4;
+
+    float T = 1.0f;
+    int last = range.x;
+    bool done = !inside;
+    bool alive = true;   // wave-uniform: some pixel of the quadrant still takes contributions
+    f32x4 acc[4][3];     // [pixel block of 16][channel block of 16]: pixel 16 blk + 4 q4 + r, channel 16 nb + sl
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) acc[blk][nb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const bool ch2_ok = sl < seg2.nch2;
+
+    // one batch: queue entries [base, base + n), n <= 32, null records behind the last one up to a multiple of GRP
+    auto run_batch = [&](const int base, const int n) {
+        // B operands COL[slot 8 q4 + t][channel 16 nb + sl]: requested here, used after the walk
+        float cb[3][8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int s_ = min(8 * q4 + t, n - 1);          // slots past the batch repeat its last Gaussian (vis = 0 there)
+            const int gid = __builtin_bit_cast(int, Q.b[base + s_].w);
+            const float *row = colors + (size_t)gid * C;
+            cb[0][t] = row[sl];
+            cb[1][t] = row[16 + sl];
+            cb[2][t] = ch2_ok ? seg2.colors[(size_t)gid * seg2.C2 + sl] : 0.0f;
+        }
+        // the walk: vis[pixel = lane][slot] = alpha T of the pairs that blend, 0 otherwise
+        int nw = 0;
+        for (int g = 0; g < n; g += GRP) {
+            if (__ballot(!done) == 0ull) { alive = false; break; }
+            float vis[GRP];
+#pragma unroll
+            for (int q = 0; q < GRP; ++q) {
+                const float4 A = Q.a[base + g + q], B = Q.b[base + g + q];
+                const float dx = A.x - px, dy = A.y - py;
+                const float sigma = __builtin_fmaf(
+                    0.5f, __builtin_fmaf(B.x * dx, dx, (B.z * dy) * dy), (B.y * dx) * dy);
+                const float alpha = fminf(GG_ALPHA_MAX_FWD, A.z * gg_expf_walk(-sigma));
+                const bool pass = sigma >= 0.0f && !(alpha < GG_ALPHA_MIN);
+                const float next_T = T * (1.0f - alpha);
+                const bool live = pass && !done;
+                const bool stop = live && (next_T <= GG_T_EPS);
+                const bool blend = live && !stop;
+                vis[q] = blend ? alpha * T : 0.0f;
+                T = blend ? next_T : T;
+                last = blend ? __builtin_bit_cast(int, A.w) : last;
+                done = done || stop;
+                if (q == 1) __builtin_amdgcn_sched_barrier(0);   // two Gaussians' records in flight at a time
+            }
+            *reinterpret_cast<float4 *>(vis_w + lane * FB_SLOTS + ((((g >> 2) ^ lane) & 7) << 2)) =
+                make_float4(vis[0], vis[1], vis[2], vis[3]);
+            nw = g + GRP;
+        }
+        for (int g = nw; g < FB_SLOTS; g += GRP)
+            *reinterpret_cast<float4 *>(vis_w + lane * FB_SLOTS + ((((g >> 2) ^ lane) & 7) << 2)) =
+                make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        __builtin_amdgcn_wave_barrier();
+        // B: one power of two per channel and batch, two fp16 pieces
+        h16x8 Bh[3], Bl[3];
+        float unsc[3];
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) {
+            float m = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) m = fmaxf(m, fabsf(cb[nb][t]));
+            {
+                auto r16 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+                m = fmaxf(__builtin_bit_cast(float, (unsigned)r16[0]), __builtin_bit_cast(float, (unsigned)r16[1]));
+                auto r32 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+                m = fmaxf(__builtin_bit_cast(float, (unsigned)r32[0]), __builtin_bit_cast(float, (unsigned)r32[1]));
+            }
+            const float sc = pow2_scale(m);
+            unsc[nb] = pow2_inv(sc) * GG_VIS_UNSCALE;
+            unsigned h_[4], l_[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) split2h(cb[nb][2 * t] * sc, cb[nb][2 * t + 1] * sc, h_[t], l_[t]);
+            Bh[nb] = H8(h_[0], h_[1], h_[2], h_[3]);
+            Bl[nb] = H8(l_[0], l_[1], l_[2], l_[3]);
+        }
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            // A: VIS[pixel 16 blk + sl][slot 8 q4 + 0..7] x 2^15
+            const int P = 16 * blk + sl;
+            const float4 v0 = *reinterpret_cast<const float4 *>(vis_w + P * FB_SLOTS + ((((2 * q4) ^ P) & 7) << 2));
+            const float4 v1 = *reinterpret_cast<const float4 *>(vis_w + P * FB_SLOTS + ((((2 * q4 + 1) ^ P) & 7) << 2));
+            unsigned ah[4], al[4];
+            split2h(v0.x * GG_VIS_SCALE, v0.y * GG_VIS_SCALE, ah[0], al[0]);
+            split2h(v0.z * GG_VIS_SCALE, v0.w * GG_VIS_SCALE, ah[1], al[1]);
+            split2h(v1.x * GG_VIS_SCALE, v1.y * GG_VIS_SCALE, ah[2], al[2]);
+            split2h(v1.z * GG_VIS_SCALE, v1.w * GG_VIS_SCALE, ah[3], al[3]);
+            const h16x8 Ah = H8(ah[0], ah[1], ah[2], ah[3]), Al = H8(al[0], al[1], al[2], al[3]);
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb) {
+                f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bl[nb], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh[nb], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl[nb], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh[nb], d, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[blk][nb][r] = __builtin_fmaf(d[r], unsc[nb], acc[blk][nb][r]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // the slab is rewritten by the next batch's walk
+    };
+
+    int qn = 0;
+    int g_nxt = (range.x + lane < range.y) ? ids[range.x + lane] : 0;   // list ids one chunk ahead
+    for (int cbase = range.x; cbase < range.y; cbase += 64) {
+        if (__ballot(!done) == 0ull) { alive = false; break; }
+        const int e = cbase + lane;
+        const bool valid = e < range.y;
+        const int g = g_nxt;
+        g_nxt = (e + 64 < range.y) ? ids[e + 64] : 0;
+        const float4 ra = reinterpret_cast<const float4 *>(rec + g)[0];
+        const float4 rb = reinterpret_cast<const float4 *>(rec + g)[1];
+        int qxl = qx0, qyl = qy0;
+        asm volatile("" : "+s"(qxl), "+s"(qyl));
+        const bool hit = valid && rec_hits_rect(ra, rb, (float)qxl, (float)(qxl + 7), (float)qyl, (float)(qyl + 7));
+        const uint64_t m = __ballot(hit);
+        if (hit) {   // ascending list order
+            const int pos = qn + lane_prefix(m);
+            Q.a[pos] = make_float4(ra.x, ra.y, ra.z, __builtin_bit_cast(float, e + 1));
+            Q.b[pos] = make_float4(rb.x, rb.y, rb.z, __builtin_bit_cast(float, g));
+        }
+        qn += __builtin_popcountll(m);
+        __builtin_amdgcn_wave_barrier();
+        int done_n = 0;
+        while (qn - done_n >= FB_SLOTS && alive) {
+            run_batch(done_n, FB_SLOTS);
+            done_n += FB_SLOTS;
+        }
+        if (!alive) break;
+        if (done_n > 0) {   // bring the left-over (< 32) to the front; source and destination do not overlap
+            const int left = qn - done_n;
+            if (lane < left) { const float4 ta = Q.a[done_n + lane]; __builtin_amdgcn_wave_barrier(); Q.a[lane] = ta; }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < left) { const float4 tb = Q.b[done_n + lane]; __builtin_amdgcn_wave_barrier(); Q.b[lane] = tb; }
+            qn = left;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (alive && qn > 0) {   // what is left at the end of the list (< 32): null records behind it, one last batch
+        if (lane < GRP) {
+            Q.a[qn + lane] = make_float4(0.f, 0.f, 0.f, 0.f);                                 // opacity 0: never passes
+            Q.b[qn + lane] = make_float4(0.f, 0.f, 0.f, Q.b[qn - 1].w);
+        }
+        __builtin_amdgcn_wave_barrier();
+        run_batch(0, qn);
+    }
+
+    if (inside) {
+        const size_t p = (size_t)i * img_w + j;
+        final_T[p] = T;
+        final_idx[p] = last;
+    }
+    // first array: the accumulators go through the slab ([pixel][32 channels]) and leave as float4, one image row of the
+    // quadrant (1 KB) per store instruction
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vis_w[(16 * blk + 4 * q4 + r) * 32 + 16 * nb + sl] = acc[blk][nb][r];
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int chunk = lane & 7;
+        const float4 bg4 = *reinterpret_cast<const float4 *>(background + 4 * chunk);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int pq = (lane >> 3) + 8 * t;
+            const float4 v = *reinterpret_cast<const float4 *>(vis_w + pq * 32 + 4 * chunk);
+            const float Tp = __shfl(T, pq, 64);
+            const int pj = qx0 + (pq & 7), pi = qy0 + (pq >> 3);
+            if (pi < img_h && pj < img_w) {
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                const f4v o = {__builtin_fmaf(Tp, bg4.x, v.x), __builtin_fmaf(Tp, bg4.y, v.y),
+                               __builtin_fmaf(Tp, bg4.z, v.z), __builtin_fmaf(Tp, bg4.w, v.w)};
+                *reinterpret_cast<f4v *>(out_img + ((size_t)pi * img_w + pj) * C + 4 * chunk) = o;
+            }
+        }
+    }
+    // second array: [pixel][8] through the slab, every lane stores its own pixel's channels
+    __builtin_amdgcn_wave_barrier();
+    if (sl < 8) {
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vis_w[(16 * blk + 4 * q4 + r) * 8 + sl] = acc[blk][2][r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (inside) {
+        const float4 w0 = *reinterpret_cast<const float4 *>(vis_w + lane * 8);
+        const float4 w1 = *reinterpret_cast<const float4 *>(vis_w + lane * 8 + 4);
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        float *o2 = seg2.out_img + ((size_t)i * img_w + j) * seg2.C2;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < seg2.nch2) o2[c] = __builtin_fmaf(T, seg2.background[c], wv[c]);
+    }
+}
+
+// =============================================================================================
 // backward, narrow (<= 3 channels): wave-autonomous, no workgroup barrier, no LDS slab
 // =============================================================================================
 // Every wave walks its quadrant's part of the tile list back to front on its own, four survivors
@@ -1542,11 +1797,12 @@ void gg_launch_blend2_fwd_blocks(int ncb, int C, int off, int img_h, int img_w, 
         hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, false, 0, 4>), grid, block, 0, s, B2_FWD_ARGS);
 }
 
-// ncb: 32-channel blocks of the first array in this walk (1, 2 or 4; channels [0, 32 ncb))
+// ncb: 32-channel blocks of the first array in this walk (1, 2 or 4; channels [0, 32 ncb)); fast: the batched fp16
+// two-piece kernel for the first block + second array (ncb is then 1)
 void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int ntiles, const int32_t *ids,
                                const int2 *bins, const GRec *rec, const float *colors, const float *background,
                                float *out_img, float *final_Ts, int32_t *final_idx, const float *colors2, int C2,
-                               const float *background2, float *out_img2, hipStream_t s, int ncb) {
+                               const float *background2, float *out_img2, hipStream_t s, int ncb, bool fast) {
     dim3 grid(gg_blend_grid(ntiles, GG_WPB_OTHER)), block(64 * GG_WPB_OTHER);
     Seg2 seg2;
     seg2.colors = colors2;
@@ -1554,6 +1810,11 @@ void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
     seg2.out_img = out_img2;
     seg2.C2 = C2;
     seg2.nch2 = C2;
+    if (fast) {
+        hipLaunchKernelGGL(blend2_fwd_batch_kernel, dim3(gg_blend_grid(ntiles, 1)), dim3(64), 0, s, C, img_h, img_w, tiles_x,
+                           ntiles, ids, bins, rec, colors, background, out_img, final_Ts, final_idx, seg2);
+        return;
+    }
 #define B2_FPAIR(L) hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, true, L>), grid, block, 0, s, C, 0, 32, \
         img_h, img_w, tiles_x, ntiles, ids, bins, rec, colors, background, out_img, final_Ts, final_idx, 1, seg2)
 #ifdef GG_ABLATION

@@ -586,6 +586,21 @@ def _rasterize_forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, o
 
 
 _DETERMINISTIC = False
+# True: the fused operator's forward walk (feature 32 | rgb + depth + normal) runs the exact-summation-order kernel —
+# images bit-identical to the oracle's sequential fma chain (gg_blend_fwd_pair); False (default): the batched kernel with
+# fp16 two-piece products (gg_blend_fwd_pair_fast): same final_T / final_idx / decisions, images to fp32 rounding
+# (~1e-7 of the colours' range; BASELINE asks for 1e-5).  Like mlp.EXACT_ORDER.
+EXACT_FORWARD = False
+
+
+def set_exact_forward(on: bool = True) -> bool:
+    global EXACT_FORWARD
+    prev, EXACT_FORWARD = EXACT_FORWARD, bool(on)
+    return prev
+
+
+def set_fast_forward(on: bool = True) -> bool:
+    return not set_exact_forward(not on)
 
 
 def set_deterministic_backward(on: bool = True) -> bool:
@@ -804,7 +819,8 @@ class RasterizeSegments(Function):
             wide = next((i for i, c in enumerate(cols_c) if c.shape[1] >= 32), None)
             small = next((i for i, c in enumerate(cols_c) if c.shape[1] <= 8), None) if wide is not None else None
             if small is not None:
-                _lib.check(lib.gg_blend_fwd_pair(
+                pair_fwd = lib.gg_blend_fwd_pair if (EXACT_FORWARD or _DETERMINISTIC) else lib.gg_blend_fwd_pair_fast
+                _lib.check(pair_fwd(
                     cols_c[wide].shape[1], cols_c[small].shape[1], n, img_height, img_width,
                     _ptr(bins.gaussian_ids_sorted), _ptr(bins.tile_bins), _ptr(xys_c), _ptr(conics_c),
                     _ptr(cols_c[wide]), _ptr(cols_c[small]), _ptr(opacity_c), _ptr(bgs_c[wide]), _ptr(bgs_c[small]),

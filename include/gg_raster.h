@@ -211,6 +211,23 @@ int gg_blend_fwd_pair(int channels, int channels2, int num_points, int img_heigh
                       float *out_img, float *out_img2, float *final_Ts, int32_t *final_idx, void *ws,
                       size_t ws_bytes, gg_stream_t stream);
 
+/* gg_blend_fwd_pair_fast (round 4): the same call on the batched kernel — the survivors of a quadrant's cull queued to
+ * batches of 32, alpha T written to a slab, ONE product OUT[64 pixels x 48 channels] += VIS[64 x 32] COL[32 x 48] per
+ * batch on v_mfma_f32_16x16x32_f16 with fp16 two-piece operands scaled by powers of two (csrc/blend2.hip
+ * blend2_fwd_batch_kernel).  final_Ts, final_idx and every alpha / stop decision are the exact kernel's, bit for bit (the
+ * walk's arithmetic is unchanged); the IMAGES agree with gg_blend_fwd_pair to fp32 rounding — |difference| <=
+ * ~1e-6 (1 + |value|) for colours of ordinary range; per channel and batch the error is bounded by 2^-22 of the batch's
+ * largest |colour| times the pixel's sum of alpha T — not bit for bit (the exact kernel sums in list order).  Needs
+ * channels % 4 == 0 and 16-byte aligned out_img / background; otherwise it runs the exact kernel.  What gsplat computes
+ * here is a CUDA fma chain with __expf (rasterize_forward / nd_rasterize_forward): no summation order that could be
+ * matched bit for bit on either kernel. */
+int gg_blend_fwd_pair_fast(int channels, int channels2, int num_points, int img_height, int img_width,
+                           const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+                           const float *conics, const float *colors, const float *colors2,
+                           const float *opacity, const float *background, const float *background2,
+                           float *out_img, float *out_img2, float *final_Ts, int32_t *final_idx, void *ws,
+                           size_t ws_bytes, gg_stream_t stream);
+
 /* gg_blend_bwd replaces gsplat `_C.rasterize_backward` / `_C.nd_rasterize_backward`.
  * v_xy (N,2), v_conic (N,3), v_colors (N,C), v_opacity (N,) are fully written.
  * ws_from_forward != 0: `ws` is the very workspace the matching gg_blend_fwd call (same xys, conics,

@@ -13,6 +13,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def exact_forward_for_the_suite():
+    """The suite's bit-exactness statements about forward images (oracle == HIP, bit for bit) are statements about the
+    exact-summation-order kernels: every test runs with ops.EXACT_FORWARD = True.  The product's default — the batched
+    pair forward with fp16 two-piece products, images to fp32 rounding — has its own tests (tests/test_fast_forward.py),
+    which switch it on themselves."""
+    from gaussiangrasper_amd import ops
+    prev = ops.set_exact_forward(True)
+    yield
+    ops.set_exact_forward(prev)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (test infrastructure); built on first use."""

@@ -146,66 +146,6 @@ def test_sh_fwd_bwd(oracle, k, deg):
 
 
 @pytest.mark.parametrize("n,h,w", [(1, 16, 16), (7, 45, 70), (1000, 48, 64), (50000, 300, 400),
-                                   (200000, 600, 800)])
-def test_project_fwd_bitexact(oracle, n, h, w):
-    sc, v = _scene_view(n, h, w)
-    ref = _project_oracle(oracle, sc, v)
-    got = _project_gpu(sc, v)
-    for name, r, g in zip(("xys", "depths", "radii", "conics", "num_tiles_hit", "cov3d"), ref, got):
-        assert_bitexact(_np(g), r, f"project_fwd.{name}")
-
-
-def test_project_fwd_culls_and_clamps(oracle):
-    """behind camera, z<=clip, off-screen, border clamp, huge Gaussian covering every tile"""
-    v = ring_cameras(1, 64, 96)[0]
-    cam = v.cam_pos.numpy()
-    fwd = -cam / np.linalg.norm(cam)
-    means = np.stack([cam - 1.0 * fwd, cam + 0.005 * fwd, cam + 0.0100001 * fwd, cam + 2.5 * fwd,
-                      cam + 2.5 * fwd + np.array([0, 5.0, 0]), cam + 2.5 * fwd + np.array([0, 0.9, 0]),
-                      cam + 2.5 * fwd]).astype(np.float32)
-    scales = np.full((7, 3), 0.01, np.float32)
-    scales[6] = 3.0
-    quats = np.tile(np.array([[1, 0, 0, 0]], np.float32), (7, 1))
-    ref = oracle.project_fwd(means, scales, 1.0, quats, _np(v.viewmat[:3]), _np(v.projmat), v.fx,
-                             v.fy, v.cx, v.cy, v.height, v.width, v.tile_bounds)
-    t = lambda a: torch.from_numpy(a).to(DEV)
-    got = P.ProjectGaussians.apply(t(means), t(scales), 1, t(quats), v.viewmat[:3].to(DEV),
-                                   v.projmat.to(DEV), v.fx, v.fy, v.cx, v.cy, v.height, v.width,
-                                   v.tile_bounds)
-    for name, r, g in zip(("xys", "depths", "radii", "conics", "num_tiles_hit", "cov3d"), ref, got):
-        assert_bitexact(_np(g), r, f"project_fwd.{name}")
-    radii = ref[2]
-    assert radii[0] == 0 and radii[1] == 0 and radii[3] > 0 and radii[4] == 0
-    assert ref[4][6] == v.tile_bounds[0] * v.tile_bounds[1]  # huge one hits every tile
-
-
-@pytest.mark.parametrize("k,deg", [(1, 0), (4, 1), (9, 2), (16, 3), (25, 4), (25, 2), (25, 0)])
-def test_sh_fwd_bwd(oracle, k, deg):
-    n = 5000 + 37
-    g = torch.Generator().manual_seed(k * 10 + deg)
-    vd = torch.randn(n, 3, generator=g)
-    cf = torch.randn(n, k, 3, generator=g)
-    vc = torch.randn(n, 3, generator=g)
-    cfd = cf.to(DEV).requires_grad_(True)
-    out = P.SphericalHarmonics.apply(deg, vd.to(DEV), cfd)
-    assert_bitexact(_np(out), oracle.sh_fwd(deg, _np(vd), _np(cf)), "sh_fwd")
-    out.backward(vc.to(DEV))
-    assert_bitexact(_np(cfd.grad), oracle.sh_bwd(deg, k, _np(vd), _np(vc)), "sh_bwd")
-
-
-@pytest.fixture(params=["counting", "radix"])
-def bin_path(request, monkeypatch):
-    """Both binning paths of csrc/binning.hip: the counting sort by tile + per-tile sort (default, round 4) and the
-    radix path of rounds 1-3 that remains for tile grids whose histogram does not fit the LDS (forced here by
-    GG_BIN_TILES_MAX=0, which the library reads at every call)."""
-    if request.param == "radix":
-        monkeypatch.setenv("GG_BIN_TILES_MAX", "0")
-    else:
-        monkeypatch.delenv("GG_BIN_TILES_MAX", raising=False)
-    return request.param
-
-
-@pytest.mark.parametrize("n,h,w", [(1, 16, 16), (7, 45, 70), (1000, 48, 64), (50000, 300, 400),
                                    (300000, 600, 800)])
 def test_binning_bitexact(oracle, n, h, w):
     sc, v = _scene_view(n, h, w)
@@ -307,6 +247,16 @@ def test_binning_truncated_capacity_stays_in_bounds(oracle):
     assert np.all(got_ids[cap:] == -7), "written past the capacity"
     ids_in = got_ids[:cap]
     assert ids_in.min() >= 0 and ids_in.max() < n
+
+
+def _blend_inputs(oracle, n, h, w, ch, seed=0, cfg=1):
+    sc, v = _scene_view(n, h, w, cfg=cfg)
+    xys, depths, radii, conics, nth, _ = _project_oracle(oracle, sc, v)
+    rng = np.random.default_rng(seed)
+    colors = rng.uniform(-1, 1, (n, ch)).astype(np.float32)
+    opac = torch.sigmoid(sc.opacities).numpy()
+    bg = rng.uniform(0, 1, ch).astype(np.float32)
+    return xys, depths, radii, conics, nth, colors, opac, bg
 
 
 @pytest.mark.parametrize("n,h,w,ch", [(1, 16, 16, 3), (7, 45, 70, 3), (2000, 48, 64, 1),

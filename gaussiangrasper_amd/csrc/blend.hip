@@ -71,7 +71,8 @@ void gg_launch_blend2_bwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
 void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int ntiles, const int32_t *ids,
                                const int2 *bins, const GRec *rec, const float *colors, const float *background,
                                float *out_img, float *final_Ts, int32_t *final_idx, const float *colors2, int C2,
-                               const float *background2, float *out_img2, hipStream_t s, int ncb, bool fast);
+                               const float *background2, float *out_img2, hipStream_t s, int ncb, bool fast,
+                               unsigned bytes1, unsigned bytes2);
 void gg_launch_blend2_fwd_blocks(int ncb, int C, int off, int img_h, int img_w, int tiles_x, int ntiles,
                                  const int32_t *ids, const int2 *bins, const GRec *rec, const float *colors,
                                  const float *background, float *out_img, float *final_Ts, int32_t *final_idx,
@@ -206,8 +207,11 @@ static int blend_fwd_pair_impl(int C, int C2, int N, int img_h, int img_w, const
     const int ntiles = tiles_x * tiles_y;
     // the batched kernel (fp32-grade images, not the exact summation order) needs 16-byte aligned image rows; without
     // them the exact-order kernel runs (its scalar-store epilogue takes any layout)
+    // ... and reads the colour rows through buffer descriptors with 32-bit offsets (id x row bytes as a 24-bit multiply)
+    const uint64_t bytes1 = (uint64_t)(N > 0 ? N : 1) * (uint64_t)C * 4u, bytes2 = (uint64_t)(N > 0 ? N : 1) * (uint64_t)C2 * 4u;
     fast = fast && (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_img) & 15) == 0) &&
-           ((reinterpret_cast<uintptr_t>(background) & 15) == 0);
+           ((reinterpret_cast<uintptr_t>(background) & 15) == 0) && N < (1 << 24) && C < (1 << 20) &&
+           bytes1 < ((uint64_t)1 << 32) && bytes2 < ((uint64_t)1 << 32);
     // the pair walk takes 1, 2 or 4 blocks of the first array (aligned rows)
     int pair_blocks = 1;
     if (!fast && (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_img) & 15) == 0)) {
@@ -217,7 +221,7 @@ static int blend_fwd_pair_impl(int C, int C2, int N, int img_h, int img_w, const
     gg_prof_begin(GG_K_BLEND_FWD_PAIR, s);
     gg_launch_blend2_fwd_pair(C, img_h, img_w, tiles_x, ntiles, ids, (const int2 *)tile_bins, rec, colors,
                               background, out_img, final_Ts, final_idx, colors2, C2, background2, out_img2, s,
-                              pair_blocks, fast);
+                              pair_blocks, fast, (unsigned)bytes1, (unsigned)bytes2);
     gg_prof_end(GG_K_BLEND_FWD_PAIR, s);
     fwd_remaining_chunks(C, 32 * pair_blocks, img_h, img_w, tiles_x, ntiles, ids, tile_bins, rec, colors, background,
                          out_img, final_Ts, final_idx, false, s);

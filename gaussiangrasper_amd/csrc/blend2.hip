@@ -429,7 +429,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GG_FB_WAVES)
     int C, int img_h, int img_w, int tiles_x, int ntiles, const int32_t *__restrict__ ids,
     const int2 *__restrict__ bins, const GRec *__restrict__ rec, const float *__restrict__ colors,
     const float *__restrict__ background, float *__restrict__ out_img, float *__restrict__ final_T,
-    int32_t *__restrict__ final_idx, Seg2 seg2) {
+    int32_t *__restrict__ final_idx, Seg2 seg2, unsigned bytes1, unsigned bytes2) {
     __shared__ FwdQueue s_q;
     __shared__ __attribute__((aligned(16))) float s_vis[64 * FB_SLOTS];
     int wave;
@@ -446,29 +446,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GG_FB_WAVES)
     const int2 range = bins[tile];
     const int sl = lane & 15, q4 = lane >> 4;
 
-    float T = 1.0f;
+    // The walk carries Ts = 2^15 T instead of T: a multiplication by a power of two commutes with every rounding of the
+    // recurrence (no overflow, no denormal: T in [1e-4, 1]), so next_Ts <= 2^15 T_EPS decides exactly as next_T <= T_EPS,
+    // final_T = 2^-15 Ts is the same bits, and alpha Ts IS the slab's 2^15 alpha T — the product's A operands need no
+    // scaling multiply (32 per batch and lane).
+    float T = GG_VIS_SCALE;
     int last = range.x;
     bool done = !inside;
     bool alive = true;   // wave-uniform: some pixel of the quadrant still takes contributions
-    f32x4 acc[4][3];     // [pixel block of 16][channel block of 16]: pixel 16 blk + 4 q4 + r, channel 16 nb + sl
+    // acc[pixel block of 16][channel block of 16]: pixel 16 blk + 4 q4 + r, channel 16 nb + sl — in units of
+    // 2^15 / inv(csc[nb]): csc[nb] is this lane's channel's current colour scale, a power of two that only ever shrinks
+    // (the largest |colour| seen so far in [2^14, 2^15)); the MFMAs accumulate in place and the accumulators are
+    // rescaled (exactly) when a batch brings a larger colour — instead of one fma per accumulator and batch
+    float csc[3];
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) csc[nb] = pow2_scale(0.0f);
+    f32x4 acc[4][3];
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk)
 #pragma unroll
         for (int nb = 0; nb < 3; ++nb) acc[blk][nb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     const bool ch2_ok = sl < seg2.nch2;
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(colors), 0, (int)bytes1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(seg2.colors), 0, (int)bytes2, 0x00020000);
+    const unsigned rowb1 = 4u * (unsigned)C, rowb2 = 4u * (unsigned)seg2.C2;
+    const unsigned lane_off1 = 4u * (unsigned)sl, lane_off2 = ch2_ok ? 4u * (unsigned)sl : 0u;
 
     // one batch: queue entries [base, base + n), n <= 32, null records behind the last one up to a multiple of GRP
     auto run_batch = [&](const int base, const int n) {
         // B operands COL[slot 8 q4 + t][channel 16 nb + sl]: requested here, used after the walk
+        // (buffer loads: row offset = id x row bytes as ONE 24-bit multiply-add per load instead of 64-bit address
+        //  arithmetic — the launcher takes this kernel only for arrays below 4 GB and ids below 2^24)
         float cb[3][8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int s_ = min(8 * q4 + t, n - 1);          // slots past the batch repeat its last Gaussian (vis = 0 there)
-            const int gid = __builtin_bit_cast(int, Q.b[base + s_].w);
-            const float *row = colors + (size_t)gid * C;
-            cb[0][t] = row[sl];
-            cb[1][t] = row[16 + sl];
-            cb[2][t] = ch2_ok ? seg2.colors[(size_t)gid * seg2.C2 + sl] : 0.0f;
+            const unsigned gid = (unsigned)__builtin_bit_cast(int, Q.b[base + s_].w);
+            const unsigned o1 = __umul24(gid, rowb1) + lane_off1;
+            cb[0][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, (int)o1, 0, 0));
+            cb[1][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, (int)o1 + 64, 0, 0));
+            const unsigned o2 = __umul24(gid, rowb2) + lane_off2;
+            const float c2v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, (int)o2, 0, 0));
+            cb[2][t] = ch2_ok ? c2v : 0.0f;
         }
         // the walk: vis[pixel = lane][slot] = alpha T of the pairs that blend, 0 otherwise
         int nw = 0;
@@ -485,7 +504,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GG_FB_WAVES)
                 const bool pass = sigma >= 0.0f && !(alpha < GG_ALPHA_MIN);
                 const float next_T = T * (1.0f - alpha);
                 const bool live = pass && !done;
-                const bool stop = live && (next_T <= GG_T_EPS);
+                const bool stop = live && (next_T <= GG_T_EPS * GG_VIS_SCALE);
                 const bool blend = live && !stop;
                 vis[q] = blend ? alpha * T : 0.0f;
                 T = blend ? next_T : T;
@@ -501,56 +520,68 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GG_FB_WAVES)
             *reinterpret_cast<float4 *>(vis_w + lane * FB_SLOTS + ((((g >> 2) ^ lane) & 7) << 2)) =
                 make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         __builtin_amdgcn_wave_barrier();
-        // B: one power of two per channel and batch, two fp16 pieces
+        // B: two fp16 pieces of colour x csc (the channel's running scale); a batch with a larger colour shrinks the
+        // scale and rescales the channel's accumulators first (rare after a wave's first batches: wave-uniform branch)
         h16x8 Bh[3], Bl[3];
-        float unsc[3];
+        float fac[3];
+        bool shrink = false;
 #pragma unroll
         for (int nb = 0; nb < 3; ++nb) {
-            float m = 0.0f;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) m = fmaxf(m, fabsf(cb[nb][t]));
+            float m = fmaxf(fmaxf(fabsf(cb[nb][0]), fabsf(cb[nb][1])), fabsf(cb[nb][2]));
+            m = fmaxf(fmaxf(m, fabsf(cb[nb][3])), fabsf(cb[nb][4]));
+            m = fmaxf(fmaxf(m, fabsf(cb[nb][5])), fmaxf(fabsf(cb[nb][6]), fabsf(cb[nb][7])));
             {
                 auto r16 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
                 m = fmaxf(__builtin_bit_cast(float, (unsigned)r16[0]), __builtin_bit_cast(float, (unsigned)r16[1]));
                 auto r32 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
                 m = fmaxf(__builtin_bit_cast(float, (unsigned)r32[0]), __builtin_bit_cast(float, (unsigned)r32[1]));
             }
-            const float sc = pow2_scale(m);
-            unsc[nb] = pow2_inv(sc) * GG_VIS_UNSCALE;
+            const float sb = fminf(csc[nb], pow2_scale(m));
+            fac[nb] = sb * pow2_inv(csc[nb]);      // 1, or the power of two < 1 the accumulators shrink by
+            shrink = shrink || sb != csc[nb];
+            csc[nb] = sb;
             unsigned h_[4], l_[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) split2h(cb[nb][2 * t] * sc, cb[nb][2 * t + 1] * sc, h_[t], l_[t]);
+            for (int t = 0; t < 4; ++t) split2h(cb[nb][2 * t] * sb, cb[nb][2 * t + 1] * sb, h_[t], l_[t]);
             Bh[nb] = H8(h_[0], h_[1], h_[2], h_[3]);
             Bl[nb] = H8(l_[0], l_[1], l_[2], l_[3]);
         }
+        if (__ballot(shrink) != 0ull) {
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[blk][nb][r] *= fac[nb];
+        }
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk) {
-            // A: VIS[pixel 16 blk + sl][slot 8 q4 + 0..7] x 2^15
+            // A: 2^15 VIS[pixel 16 blk + sl][slot 8 q4 + 0..7]
             const int P = 16 * blk + sl;
             const float4 v0 = *reinterpret_cast<const float4 *>(vis_w + P * FB_SLOTS + ((((2 * q4) ^ P) & 7) << 2));
             const float4 v1 = *reinterpret_cast<const float4 *>(vis_w + P * FB_SLOTS + ((((2 * q4 + 1) ^ P) & 7) << 2));
             unsigned ah[4], al[4];
-            split2h(v0.x * GG_VIS_SCALE, v0.y * GG_VIS_SCALE, ah[0], al[0]);
-            split2h(v0.z * GG_VIS_SCALE, v0.w * GG_VIS_SCALE, ah[1], al[1]);
-            split2h(v1.x * GG_VIS_SCALE, v1.y * GG_VIS_SCALE, ah[2], al[2]);
-            split2h(v1.z * GG_VIS_SCALE, v1.w * GG_VIS_SCALE, ah[3], al[3]);
+            split2h(v0.x, v0.y, ah[0], al[0]);
+            split2h(v0.z, v0.w, ah[1], al[1]);
+            split2h(v1.x, v1.y, ah[2], al[2]);
+            split2h(v1.z, v1.w, ah[3], al[3]);
             const h16x8 Ah = H8(ah[0], ah[1], ah[2], ah[3]), Al = H8(al[0], al[1], al[2], al[3]);
 #pragma unroll
             for (int nb = 0; nb < 3; ++nb) {
-                f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
-                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bl[nb], d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh[nb], d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl[nb], d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh[nb], d, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[blk][nb][r] = __builtin_fmaf(d[r], unsc[nb], acc[blk][nb][r]);
+                acc[blk][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bl[nb], acc[blk][nb], 0, 0, 0);
+                acc[blk][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh[nb], acc[blk][nb], 0, 0, 0);
+                acc[blk][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl[nb], acc[blk][nb], 0, 0, 0);
+                acc[blk][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh[nb], acc[blk][nb], 0, 0, 0);
             }
         }
         __builtin_amdgcn_wave_barrier();   // the slab is rewritten by the next batch's walk
     };
 
     int qn = 0;
-    int g_nxt = (range.x + lane < range.y) ? ids[range.x + lane] : 0;   // list ids one chunk ahead
+    // list ids one chunk ahead of the cull.  (Records a chunk ahead as well — 8 more registers — measured nothing:
+    // 0.424 ms at three waves per SIMD, 0.407 at four with 3 spills, against 0.409 without; the kernel is VALU-bound,
+    // VALUBusy 87 %.)
+    int g_nxt = (range.x + lane < range.y) ? ids[range.x + lane] : 0;
     for (int cbase = range.x; cbase < range.y; cbase += 64) {
         if (__ballot(!done) == 0ull) { alive = false; break; }
         const int e = cbase + lane;
@@ -594,10 +625,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GG_FB_WAVES)
         run_batch(0, qn);
     }
 
+    T *= GG_VIS_UNSCALE;   // (exact)
     if (inside) {
         const size_t p = (size_t)i * img_w + j;
         final_T[p] = T;
         final_idx[p] = last;
+    }
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) {
+        const float un = pow2_inv(csc[nb]) * GG_VIS_UNSCALE;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[blk][nb][r] *= un;
     }
     // first array: the accumulators go through the slab ([pixel][32 channels]) and leave as float4, one image row of the
     // quadrant (1 KB) per store instruction
@@ -1802,7 +1842,8 @@ void gg_launch_blend2_fwd_blocks(int ncb, int C, int off, int img_h, int img_w, 
 void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int ntiles, const int32_t *ids,
                                const int2 *bins, const GRec *rec, const float *colors, const float *background,
                                float *out_img, float *final_Ts, int32_t *final_idx, const float *colors2, int C2,
-                               const float *background2, float *out_img2, hipStream_t s, int ncb, bool fast) {
+                               const float *background2, float *out_img2, hipStream_t s, int ncb, bool fast,
+                               unsigned bytes1, unsigned bytes2) {
     dim3 grid(gg_blend_grid(ntiles, GG_WPB_OTHER)), block(64 * GG_WPB_OTHER);
     Seg2 seg2;
     seg2.colors = colors2;
@@ -1812,7 +1853,7 @@ void gg_launch_blend2_fwd_pair(int C, int img_h, int img_w, int tiles_x, int nti
     seg2.nch2 = C2;
     if (fast) {
         hipLaunchKernelGGL(blend2_fwd_batch_kernel, dim3(gg_blend_grid(ntiles, 1)), dim3(64), 0, s, C, img_h, img_w, tiles_x,
-                           ntiles, ids, bins, rec, colors, background, out_img, final_Ts, final_idx, seg2);
+                           ntiles, ids, bins, rec, colors, background, out_img, final_Ts, final_idx, seg2, bytes1, bytes2);
         return;
     }
 #define B2_FPAIR(L) hipLaunchKernelGGL((blend2_fwd_kernel<32, true, true, true, L>), grid, block, 0, s, C, 0, 32, \

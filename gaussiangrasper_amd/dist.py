@@ -250,7 +250,12 @@ class ShardedAdamStep:
         self.shard = self.padded // self.world
         dev = bucket.flat.device
         self.flat_params = torch.zeros(self.padded, dtype=torch.float32, device=dev)
-        self.flat_grads = bucket.flat if self.padded == L else None     # (padding needed: a padded copy per step)
+        # the reduce-scatter's source: the bucket's flat gradient itself when its length divides among the ranks,
+        # otherwise ONE padded buffer allocated here (its tail stays zero; the gradients are copied in per step)
+        self.padded_grads = None if self.padded == L else torch.zeros(self.padded, dtype=torch.float32, device=dev)
+        # what this object was built over: densification / culling replaces the Parameters and re-binds the bucket
+        # (GradBucket.rebind) — stepping the stale views would update nothing the model still uses
+        self._bound = (bucket.flat.data_ptr(), L, tuple(id(p) for p in bucket.params))
         self.offsets = []
         for p, sl in zip(bucket.params, bucket.slices):
             off = sl.storage_offset() - bucket.flat.storage_offset()
@@ -271,12 +276,16 @@ class ShardedAdamStep:
     def step(self) -> None:
         """after the step's backward passes: reduce-scatter, Adam on the shard, all-gather"""
         b = self.bucket
+        if (b.flat.data_ptr(), b.flat.numel(), tuple(id(p) for p in b.params)) != self._bound:
+            raise RuntimeError("ShardedAdamStep: the gradient bucket was re-bound (densification or culling replaced the "
+                               "Parameters) after this object was built; build a new ShardedAdamStep over the new "
+                               "bucket (its moments start at zero for new rows, as the reference's do)")
         b.flush()
         lo = self.rank * self.shard
         if self.world > 1:
             src = b.flat
-            if self.padded != src.numel():
-                src = torch.zeros(self.padded, dtype=torch.float32, device=src.device)
+            if self.padded_grads is not None:
+                src = self.padded_grads
                 src[:b.flat.numel()].copy_(b.flat)
             if dist.get_backend() == "gloo":
                 dist.all_reduce(src, op=dist.ReduceOp.SUM)

@@ -425,11 +425,17 @@ def _bin_key(xys, depths, radii, num_tiles_hit, img_height, img_width):
                  (xys, depths, radii, num_tiles_hit)) + (int(img_height), int(img_width))
 
 
-def last_num_intersects() -> Optional[int]:
+def last_num_intersects(radii: Optional[Tensor] = None) -> Optional[int]:
     """Length of the tile lists of the view binned last, once known to the host (the rasterize operators resolve
     it before they return); None before any binning.  0 means nothing was visible — what the reference's
-    `(self.radii).sum() == 0` (gaussian_splatting.py:714) asks with a host round trip BEFORE the render."""
-    return None if _bin_cache is None else _bin_cache.num_intersects
+    `(self.radii).sum() == 0` (gaussian_splatting.py:714) asks with a host round trip BEFORE the render.
+    With `radii` (the projection output of THIS call): None as well unless the lists binned last are this call's —
+    a view whose operator did not bin must not be judged by the previous view's count."""
+    if _bin_cache is None:
+        return None
+    if radii is not None and not any(t is radii for t in _bin_cache.keep):
+        return None
+    return _bin_cache.num_intersects
 
 
 def clear_bin_cache() -> None:

@@ -37,10 +37,11 @@ DESCRIPTION = ("GaussianGrasper feature-field splatting on the MI355X-native fus
 
 
 def fused_view(model, means, log_scales, quats, opacities, colors_all, feature, viewmat, projmat, cam_pos,
-               fx, fy, cx, cy, H, W, tile_bounds, sh_degree_to_use: int, ops=_ops
+               fx, fy, cx, cy, H, W, tile_bounds, sh_degree_to_use: int, ops=_ops, full_proj=None
                ) -> Optional[Dict[str, torch.Tensor]]:
     """Operator part of `get_outputs` (reference :699-784) with the four rasterize calls fused.
-    Sets model.xys / model.radii / model.normals as the reference does.  None if nothing is visible."""
+    Sets model.xys / model.radii / model.normals as the reference does.  None if nothing is visible.
+    full_proj: `projmat @ viewmat` (:707) if the caller has it already (cached per dataset camera)."""
     fused_act = hasattr(ops, "ActivateGaussians")
     if fused_act:      # exp / normalise / sigmoid / view directions / normals: one kernel each way
         scales_e, quats_n, opac, viewdirs, model.normals = ops.ActivateGaussians.apply(
@@ -48,7 +49,8 @@ def fused_view(model, means, log_scales, quats, opacities, colors_all, feature, 
     else:
         scales_e, quats_n = torch.exp(log_scales), quats / quats.norm(dim=-1, keepdim=True)
         opac = torch.sigmoid(opacities)
-    full_proj = projmat @ viewmat                                    # :707
+    if full_proj is None:
+        full_proj = projmat @ viewmat                                # :707
     model._gg_last_view = (viewmat, full_proj)                        # (what the operators were given: tests, debugging)
     model.xys, depths, model.radii, conics, num_tiles_hit, _cov3d = ops.ProjectGaussians.apply(
         means, scales_e, 1, quats_n, viewmat[:3, :], full_proj, fx, fy, cx, cy, H, W, tile_bounds)
@@ -83,8 +85,10 @@ def fused_view(model, means, log_scales, quats, opacities, colors_all, feature, 
     # feature | rgb | depth (background 10, :769) | normal from one binning (pipeline.fused_images)
     feat_im, rgb, depth_im, normal_im = fused_images(ops, model.xys, depths, model.radii, conics, num_tiles_hit,
                                                      opac, H, W, feature, rgbs, model.normals, tail=tail)
-    if count_known_late and ops.last_num_intersects() == 0:
-        return None
+    if count_known_late:
+        count = ops.last_num_intersects(model.radii)     # None: the lists binned last are not this call's
+        if count == 0 or (count is None and (model.radii).sum() == 0):
+            return None
     return {"rgb": rgb, "feature": feat_im, "depth": depth_im, "normal": normal_im}
 
 
@@ -92,14 +96,14 @@ class LazyOutputs(dict):
     """The output dictionary of get_outputs with `normal_vis` / `feature_vis` computed when first read.
     The reference computes both on every call (:785-795) — a rank-3 `torch.pca_lowrank` of the (H W, 32) feature
     image included — although training reads neither (get_metrics_dict / get_loss_dict index rgb, depth, normal,
-    feature: :804-935); the viewer, eval images and render.sh do, and get exactly the reference's values (they are
-    materialised by `[]`, `get`, `items`, `values`, `pop`, `copy`, `==` and iteration over values)."""
+    feature: :804-935).  The lazy keys are NOT in the underlying dict storage until they are computed: `[]` reaches them
+    through `__missing__`, and `__iter__` / `keys` are overridden, which makes CPython's `dict(out)`, `{**out}` and
+    `other.update(out)` leave their C fast path and go through `keys()` + `[]` — a copy holds real tensors, never a
+    placeholder.  Returned in training mode only; eval / viewer / render.sh get a plain dict."""
 
     def __init__(self, base: Dict, lazy: Dict):
         super().__init__(base)
         self._lazy = dict(lazy)
-        for k in self._lazy:
-            super().__setitem__(k, None)     # the keys exist from the start (`in`, `keys()`, `len`)
 
     def _force(self, key=None):
         for k in ([key] if key is not None else list(self._lazy)):
@@ -107,13 +111,32 @@ class LazyOutputs(dict):
             if fn is not None:
                 super().__setitem__(k, fn())
 
-    def __getitem__(self, key):
-        self._force(key)
-        return super().__getitem__(key)
+    def __missing__(self, key):
+        if key in self._lazy:
+            self._force(key)
+            return super().__getitem__(key)
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return super().__contains__(key) or key in self._lazy
+
+    def __iter__(self):
+        yield from super().__iter__()
+        yield from list(self._lazy)
+
+    def __len__(self):
+        return super().__len__() + len(self._lazy)
+
+    def keys(self):
+        return list(iter(self))
 
     def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def setdefault(self, key, default=None):
         if key in self:
             return self[key]
+        super().__setitem__(key, default)
         return default
 
     def pop(self, key, *a):
@@ -130,15 +153,30 @@ class LazyOutputs(dict):
 
     def copy(self):
         self._force()
-        return dict(self)
+        return dict(super().items())
 
     def __eq__(self, other):
         self._force()
         return dict.__eq__(self, other)
 
+    __hash__ = None
+
+    def __or__(self, other):
+        return {**self.copy(), **other}
+
+    def __ror__(self, other):
+        return {**other, **self.copy()}
+
+    def __reduce__(self):
+        return (dict, (self.copy(),))
+
     def __setitem__(self, key, value):
         self._lazy.pop(key, None)
         super().__setitem__(key, value)
+
+    def __delitem__(self, key):
+        if self._lazy.pop(key, None) is None:
+            super().__delitem__(key)
 
 
 def _camera_scalars(camera):
@@ -208,8 +246,9 @@ def make_fused_model_class(base, ops=_ops, background_override=lambda: None, fus
     class FusedGaussianSplattingModel(base):
         """GaussianSplattingModel on the fused MI355X rasterizer call (gaussiangrasper_amd.plugin)."""
 
-        # "lazy": normal_vis / feature_vis (the reference's rank-3 PCA of the feature image, :785-795) are computed
-        # when something reads them; "eager": on every call, as the reference does; "off": feature_vis = first 3 channels
+        # "lazy": in TRAINING mode normal_vis / feature_vis (the reference's rank-3 PCA of the feature image, :785-795) are
+        # computed when something reads them (eval / viewer / render.sh always get them computed, in a plain dict);
+        # "eager": on every call, as the reference does; "off": feature_vis = first 3 channels
         feature_vis_mode = "lazy"
 
         def get_outputs(self, camera) -> Dict[str, Union[torch.Tensor, List]]:
@@ -219,7 +258,10 @@ def make_fused_model_class(base, ops=_ops, background_override=lambda: None, fus
             assert camera.shape[0] == 1, "Only one camera at a time"
             if self.training:
                 self.camera_optimizer.apply_to_camera(camera)
-                background = torch.rand(self.feature_dim, device=self.device)
+                # :642 `background = torch.rand(feature_dim)` is read by the two early exits only (:652 is eval-only, :715
+                # "nothing visible"): drawn where it is returned, not on every call (a Philox launch per view; the
+                # device RNG stream then differs from the reference's from the first step on: PARITY.md)
+                background = None
             else:
                 over = background_override()
                 background = over if over is not None else self.back_color.to(self.device)
@@ -231,17 +273,31 @@ def make_fused_model_class(base, ops=_ops, background_override=lambda: None, fus
             camera_downscale = self._get_downscale_factor()
             if camera_downscale != 1:     # (x 1.0 changes nothing: seven launches and a host-to-device copy saved)
                 camera.rescale_output_resolution(1 / camera_downscale)
-            # world -> camera, gsplat convention: rotate pi about x, analytic inverse (:658-668)
-            c2w = camera.camera_to_worlds[0]
-            flips = self.__dict__.setdefault("_gg_flip", {})
-            fkey = (str(c2w.device), c2w.dtype)
-            if fkey not in flips:
-                flips[fkey] = torch.diag(torch.tensor([1.0, -1.0, -1.0], device=c2w.device, dtype=c2w.dtype))
-            R = c2w[:3, :3] @ flips[fkey]
-            R_inv = R.T
-            viewmat = torch.eye(4, device=c2w.device, dtype=c2w.dtype)
-            viewmat[:3, :3] = R_inv
-            viewmat[:3, 3:4] = -R_inv @ c2w[:3, 3:4]
+            md = getattr(camera, "metadata", None)
+            key = (int(md["cam_idx"]), camera_downscale) if (self.training and isinstance(md, dict)
+                                                            and "cam_idx" in md) else None
+            # With the camera optimizer off (the reference's configuration: CameraOptimizerConfig(mode="off"), :191) a
+            # training camera's pose is a dataset constant like its intrinsics: viewmat and projmat @ viewmat of a
+            # (dataset index, downscale) are formed once — the same torch operations on the same values, i.e. the same
+            # bits — instead of ~10 small launches per view (a 3x3 and two 4x4 products through hipBLASLt, eye, fills,
+            # neg, copies: 12 % of a view's wall time in round 3's rocprofv3 table)
+            pose_const = getattr(getattr(getattr(self, "config", None), "camera_optimizer", None), "mode", "off") == "off"
+            vcache = self.__dict__.setdefault("_gg_view_cache", {})
+            view_c = vcache.get(key) if (key is not None and pose_const) else None
+            if view_c is None:
+                # world -> camera, gsplat convention: rotate pi about x, analytic inverse (:658-668)
+                c2w = camera.camera_to_worlds[0]
+                flips = self.__dict__.setdefault("_gg_flip", {})
+                fkey = (str(c2w.device), c2w.dtype)
+                if fkey not in flips:
+                    flips[fkey] = torch.diag(torch.tensor([1.0, -1.0, -1.0], device=c2w.device, dtype=c2w.dtype))
+                R = c2w[:3, :3] @ flips[fkey]
+                R_inv = R.T
+                viewmat = torch.eye(4, device=c2w.device, dtype=c2w.dtype)
+                viewmat[:3, :3] = R_inv
+                viewmat[:3, 3:4] = -R_inv @ c2w[:3, 3:4]
+            else:
+                viewmat = view_c[0]
             # The intrinsics are host values in every operator signature, and reading them off a device-resident
             # camera is a stream synchronisation: the host then cannot enqueue view k + 1 while view k runs (measured
             # on the bench workload: 520 -> 459 views/s with one read-back per view).  The datamanager stamps every
@@ -249,9 +305,6 @@ def make_fused_model_class(base, ops=_ops, background_override=lambda: None, fus
             # and intrinsics are per-dataset constants (camera optimisation, if on, moves poses only), so each
             # (index, downscale) is read back once.  Cameras without the stamp, and eval mode (where train and eval
             # datasets share index values), are read every time.
-            md = getattr(camera, "metadata", None)
-            key = (int(md["cam_idx"]), camera_downscale) if (self.training and isinstance(md, dict)
-                                                            and "cam_idx" in md) else None
             cache = self.__dict__.setdefault("_gg_camera_scalars", {})
             scal = cache.get(key) if key is not None else None
             if scal is None:
@@ -268,14 +321,22 @@ def make_fused_model_class(base, ops=_ops, background_override=lambda: None, fus
             projmat = pcache[pkey]
             tile_bounds = ((W + BLOCK - 1) // BLOCK, (H + BLOCK - 1) // BLOCK, 1)
             pick = (lambda t: t[crop_ids]) if crop_ids is not None else (lambda t: t)
-            cam_pos = camera.camera_to_worlds.detach()[..., :3, 3]
+            if view_c is None:
+                cam_pos = camera.camera_to_worlds.detach()[..., :3, 3]
+                full_proj = projmat @ viewmat                        # :707
+                if key is not None and pose_const:
+                    vcache[key] = (viewmat, full_proj, cam_pos.clone())
+            else:
+                _, full_proj, cam_pos = view_c
             n = min(self.step // self.config.sh_degree_interval, self.config.sh_degree)
             out = fused_view(self, pick(self.means), pick(self.scales), pick(self.quats), pick(self.opacities),
                              pick(self.colors_all), pick(self.feature), viewmat, projmat, cam_pos, fx, fy, cx, cy,
-                             H, W, tile_bounds, n, ops)
+                             H, W, tile_bounds, n, ops, full_proj=full_proj)
             if out is None:
                 # :714-715 — the reference leaves through this exit WITHOUT scaling the camera back (:798 is not
                 # reached); kept as it is (PARITY.md)
+                if background is None:
+                    background = torch.rand(self.feature_dim, device=self.device)     # :642
                 return {"rgb": background.repeat(H, W, 1)}
             if camera_downscale != 1:
                 camera.rescale_output_resolution(camera_downscale)  # :798
@@ -294,7 +355,7 @@ def make_fused_model_class(base, ops=_ops, background_override=lambda: None, fus
                 return torch.matmul(flat, V[:, :3]).view(feat.size()[:-1] + (3,))
 
             lazy = {"normal_vis": normal_vis, "feature_vis": feature_vis}
-            if self.feature_vis_mode == "lazy":
+            if self.feature_vis_mode == "lazy" and self.training:
                 return LazyOutputs(out, lazy)
             out.update({k: f() for k, f in lazy.items()})
             return out

@@ -6,8 +6,8 @@ kernel's and the oracle's, BIT FOR BIT; the images agree to fp32 rounding — he
 
         |image - oracle| <= 1e-6 (1 + |oracle|)          (BASELINE asks for 1e-5 max-abs)
 
-on colours of ordinary range, and to the channel-wise bound 2^-21 x (largest |colour| of the channel) for colour arrays
-spread over six decades.  The reference side of these calls is gsplat's rasterize_forward / nd_rasterize_forward (call
+on colours of ordinary range, and to the channel-wise bound 2^-20 x (largest |colour| of the channel) — sixteen fp32
+ulps of it: two summation orders of some tens of fp32 terms — for colour arrays spread over six decades.  The reference side of these calls is gsplat's rasterize_forward / nd_rasterize_forward (call
 sites nerfstudio/models/gaussian_splatting.py:735-784); the oracle is oracle/gg_oracle.c (parity UNPINNED against the
 real gsplat: PARITY.md).  Every other test of the suite runs with ops.EXACT_FORWARD = True (tests/conftest.py), i.e. on
 the exact-order kernel whose images are the oracle's bit for bit."""
@@ -120,8 +120,8 @@ def test_fast_pair_forward_against_a_float64_sum(oracle):
 
 @pytest.mark.parametrize("spread", ["channels", "rows", "tiny", "huge"])
 def test_fast_pair_forward_over_a_wide_dynamic_range(oracle, spread):
-    """colour arrays spread over six decades: per channel the error stays below 2^-21 of the channel's largest |colour|
-    (the batch scale is per channel: a channel of 1e-3 next to one of 1e3 keeps its own relative accuracy)"""
+    """colour arrays spread over six decades: per channel the error stays below 2^-20 of the channel's largest |colour|
+    (the colour scale is per channel: a channel of 1e-3 next to one of 1e3 keeps its own relative accuracy)"""
     def colors(col):
         rng = np.random.default_rng(3)
         col = col.copy()
@@ -143,7 +143,7 @@ def test_fast_pair_forward_over_a_wide_dynamic_range(oracle, spread):
     for img, ref, cc, bb in ((_np(f_img), o1, col[:, :32], bg[:32]), (_np(f_img2), o2, col[:, 32:], bg[32:])):
         cmax = np.maximum(np.abs(cc).max(axis=0), np.abs(bb)).astype(np.float64)       # per channel
         err = np.abs(img.astype(np.float64) - ref).reshape(-1, img.shape[-1]).max(axis=0)
-        assert (err <= 2.0 ** -21 * cmax + 1e-37).all(), (spread, (err / cmax).max())
+        assert (err <= 2.0 ** -20 * cmax + 1e-37).all(), (spread, (err / cmax).max())
 
 
 def test_fast_forward_is_the_operators_default_and_backward_is_unchanged(oracle):

@@ -277,3 +277,81 @@ def test_plugin_class_empty_view_without_a_host_round_trip():
     out = m(cam)
     assert set(out) == {"rgb"} and out["rgb"].shape == (64, 96, 3) and float(out["rgb"].abs().sum()) == 0.0
     assert P.last_num_intersects() == 0 and int(m.radii.sum()) == 0
+
+
+def test_lazy_outputs_copies_hold_tensors_and_eval_returns_a_plain_dict():
+    """`dict(out)`, `{**out}`, `other.update(out)` and `setdefault` on the training-mode output dictionary
+    must see tensors for normal_vis / feature_vis, never a placeholder; eval mode (viewer, render.sh, eval images)
+    returns a plain dict with both computed"""
+    import oracle_ops
+    from gaussiangrasper_amd.plugin import LazyOutputs, make_fused_model_class
+    sc = make_scene(300, feature_dim=8, config_index=9)
+    sc.scales.add_(1.7)
+    view, cam = _view_and_camera(32, 48)
+    m = make_fused_model_class(StubGaussianSplattingModel, ops=oracle_ops)(sc).train()
+    keys = {"rgb", "feature", "depth", "normal", "normal_vis", "feature_vis"}
+
+    def fresh():
+        out = m.get_outputs(StubCameras.from_view(view))
+        assert isinstance(out, LazyOutputs) and set(out._lazy) == {"normal_vis", "feature_vis"}
+        assert not dict.__contains__(out, "feature_vis")            # nothing parked in the storage
+        return out
+    out = fresh()
+    assert set(out.keys()) == keys and len(out) == 6 and "feature_vis" in out and set(iter(out)) == keys
+    d = dict(fresh())
+    assert set(d) == keys and all(torch.is_tensor(v) for v in d.values())
+    d = {**fresh()}
+    assert set(d) == keys and torch.is_tensor(d["feature_vis"]) and torch.is_tensor(d["normal_vis"])
+    other = {}
+    other.update(fresh())
+    assert set(other) == keys and all(torch.is_tensor(v) for v in other.values())
+    out = fresh()
+    assert torch.is_tensor(out.setdefault("feature_vis", None)) and out.setdefault("extra", 7) == 7
+    assert torch.is_tensor(fresh().get("normal_vis")) and fresh().get("nope", 3) == 3
+    assert set((fresh() | {"a": 1})) == keys | {"a"}
+    out = fresh()
+    del out["feature_vis"]
+    assert "feature_vis" not in out and len(out) == 5
+    with pytest.raises(KeyError):
+        fresh()["missing"]
+    m.eval()
+    ev = m.get_outputs(StubCameras.from_view(view))
+    assert type(ev) is dict and set(ev) == keys and all(torch.is_tensor(v) for v in ev.values())
+
+
+def test_training_cameras_reuse_their_pose_matrices_and_an_unbinned_view_is_not_judged_by_the_last_one():
+    """viewmat / projmat @ viewmat of a stamped training camera are formed once (camera optimizer off, :191): the second
+    call with the same dataset index renders the same bits from the cached matrices; an eval call never uses them.
+    And the nothing-visible exit asks about THIS call's radii: ops.last_num_intersects(radii) answers None for lists that
+    were binned for other tensors."""
+    import oracle_ops
+    from gaussiangrasper_amd import ops as P
+    from gaussiangrasper_amd.plugin import make_fused_model_class
+    sc = make_scene(300, feature_dim=8, config_index=9)
+    sc.scales.add_(1.7)
+    view, _ = _view_and_camera(32, 48)
+    m = make_fused_model_class(StubGaussianSplattingModel, ops=oracle_ops)(sc).train()
+    cam = lambda idx: StubCameras.from_view(view, cam_idx=idx)
+    a = m.get_outputs(cam(3))
+    assert set(m._gg_view_cache) == {(3, 1)}
+    vm0 = m._gg_last_view[0]
+    b = m.get_outputs(cam(3))
+    assert m._gg_last_view[0] is vm0                                   # the cached matrix itself
+    for k in ("rgb", "feature", "depth", "normal"):
+        assert torch.equal(a[k], b[k]), k
+    m.get_outputs(StubCameras.from_view(view))                         # unstamped: computed, not cached
+    assert set(m._gg_view_cache) == {(3, 1)} and m._gg_last_view[0] is not vm0
+    assert torch.equal(m._gg_last_view[0], vm0)
+    m.eval()
+    m.get_outputs(cam(3))
+    assert m._gg_last_view[0] is not vm0
+    # the count of the lists binned last answers only for the tensors they were binned for
+    class _B:
+        keep = (torch.zeros(2), torch.zeros(2), torch.ones(2, dtype=torch.int32), torch.zeros(2))
+        num_intersects = 0
+    prev, P._bin_cache = P._bin_cache, _B()
+    try:
+        assert P.last_num_intersects() == 0 and P.last_num_intersects(_B.keep[2]) == 0
+        assert P.last_num_intersects(torch.ones(2, dtype=torch.int32)) is None
+    finally:
+        P._bin_cache = prev

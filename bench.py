@@ -225,6 +225,29 @@ def cpu_baseline_render(args, scene, view, fea_up):
                       f"extrapolated view time {est:.1f} s; oracle/gg_oracle.c with OpenMP"}
 
 
+def parse_rccl_log(path):
+    """what RCCL's INFO log (NCCL_DEBUG_FILE of rank 0) says about algorithms / protocols / channels: a few distinct
+    lines, or None (no log, gloo, or a build that prints nothing of the kind)"""
+    if not path or not os.path.exists(path):
+        return None
+    keep, seen = [], set()
+    try:
+        with open(path, errors="replace") as f:
+            for line in f:
+                low = line.lower()
+                if any(k in low for k in ("algo", "proto", "channel", "ring", "tree", "xgmi", "p2p")) and "via" not in low:
+                    txt = line.split("NCCL INFO", 1)[-1].strip()[:160]
+                    key = "".join(c for c in txt if not c.isdigit())
+                    if key not in seen:
+                        seen.add(key)
+                        keep.append(txt)
+                if len(keep) >= 24:
+                    break
+    except OSError:
+        return None
+    return keep or None
+
+
 def read_kernel_times(lib):
     kernels = {}
     for kid in range(32):
@@ -247,17 +270,18 @@ def load_pmc():
         return {}, None
 
 
-# cycles one MFMA holds the matrix pipe (to turn busy cycles into an instruction count): the forward kernels use
-# v_mfma_f32_32x32x2_f32 (64); the 16-slot backward kernels v_mfma_f32_16x16x32_f16 (16) for D and the colour flush
+# cycles one MFMA holds the matrix pipe (to turn busy cycles into an instruction count): the exact-order forward kernels
+# use v_mfma_f32_32x32x2_f32 (64), the batched pair forward (r04, the default) v_mfma_f32_16x16x32_f16 (16); the 16-slot
+# backward kernels v_mfma_f32_16x16x32_f16 (16) for D and the colour flush
 # and, in the pair build, v_mfma_f32_16x16x4_f32 (32) for the second array: 32 x 16 + 24 x 32 cycles per batch of 56
-MFMA_CYCLES_F32 = {"blend_fwd_pair_kernel<40>": 64.0, "blend_fwd_kernel<32>": 64.0,
+MFMA_CYCLES_F32 = {"blend_fwd_pair_kernel<40>": 16.0, "blend_fwd_kernel<32>": 64.0,
                    "blend_bwd_pair_kernel<40>": 1280.0 / 56.0, "blend_bwd_kernel<32>": 16.0}
 # float atomics execute at the L2: ~20.4 G 64-byte requests/s chip-wide whatever the lanes of an instruction cover
 # (tools/ubench_atomics.hip, profiles/r03_ubench_atomics.txt)
 ATOMIC_REQUESTS_PEAK = 20.4e9
 
 
-def build_roofline(args, kernels, n_vis, n_isect, ms_per_view):
+def build_roofline(args, kernels, n_vis, n_isect, ms_per_view, extra_view_bytes: int = 0, extra_note: str = ""):
     P = args.height * args.width
     pmc, pmc_file = load_pmc()
     per = {}
@@ -303,9 +327,13 @@ def build_roofline(args, kernels, n_vis, n_isect, ms_per_view):
     dom = max(per, key=lambda n: per[n]["total_ms"])
     d = per[dom]
     N, K, D = args.points, 25, args.feature_dim
-    b_view = algorithmic_bytes_whole_view(N, n_vis, n_isect, P, K, D, render_only=args.config == 5)
+    b_view = algorithmic_bytes_whole_view(N, n_vis, n_isect, P, K, D, render_only=args.config == 5) + extra_view_bytes
     gbs_view = b_view / (ms_per_view * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": dom, "achieved": d["achieved"], "peak": HBM_PEAK_GBS,
+    # which roof does the dominant kernel answer to?  (the counters decide: VALUBusy / the issue fraction against the
+    # HBM fraction; "hbm" stays the bound BASELINE.json prices the path against)
+    fi = (d.get("fp32_issue") or {}).get("frac") or (d.get("valu") or {}).get("frac") or 0.0
+    measured = "fp32_issue" if (fi > d["frac"] or (d.get("valu_busy_pct") or 0.0) > 60.0) else "hbm"
+    return {"bound": "hbm", "bound_measured": measured, "kernel": dom, "achieved": d["achieved"], "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": d["frac"], "traffic": d.get("traffic"),
             "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
             "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
@@ -314,7 +342,7 @@ def build_roofline(args, kernels, n_vis, n_isect, ms_per_view):
             "valu_busy_pct": d.get("valu_busy_pct"),
             "whole_view": {"bytes": b_view, "ms_per_view": ms_per_view, "achieved": gbs_view,
                            "frac": gbs_view / HBM_PEAK_GBS,
-                           "note": "SURVEY 8d B_alg from the measured N_vis and I over wall time per view"},
+                           "note": "SURVEY 8d B_alg from the measured N_vis and I over wall time per view" + extra_note},
             "kernels": {k: {kk: vv for kk, vv in v.items() if kk != "launches"} for k, v in per.items()},
             "pmc_source": pmc_file, "pmc_commit": pmc.get("_commit") if isinstance(pmc, dict) else None,
             "note": "issue-bound kernels (DESIGN.md 3.5c/3.5d): `frac` is against HBM as BASELINE asks, "
@@ -347,8 +375,17 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
             raise SystemExit("--device cpu is a test hook and needs --ops <non-product module>: the "
                              "product operators have no CPU path")
         dev = torch.device("cpu")
+    rccl_log = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl" and "NCCL_DEBUG" not in os.environ:
+            # let RCCL say which algorithm / protocol it picks for the gradient messages (into a file of this rank's own;
+            # rank 0's is parsed into the line's `comm.rccl` — whether the 472 MB ride a ring or the direct links is
+            # what DESIGN 6's 6.0x-or-7.6x estimate turns on)
+            rccl_log = "/tmp/gg_rccl_%d_rank%d.log" % (os.getpid(), rank)
+            os.environ["NCCL_DEBUG"] = "INFO"
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING,GRAPH")
+            os.environ["NCCL_DEBUG_FILE"] = rccl_log
         kw = {"device_id": dev} if (args.device == "cuda" and args.backend == "nccl") else {}
         dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
 
@@ -489,7 +526,9 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
     #   shim    PYTHONPATH=<repo>/shim only: the reference's model file with its four separate rasterize
     #           calls per view (they share the binning) — reported next to it.
     plugin_first = args.route == "plugin"
+    bucket.comm_stats()                                       # (drop what the probe / set-up left)
     elapsed, kernels, t_prof, grads = measure(fused=plugin_first, warmup=args.warmup)
+    comm = bucket.comm_stats() if world > 1 else None         # warm-up + timed + profiled steps of the headline route
     if args.torch_profile and rank == 0:
         from torch.profiler import ProfilerActivity, profile
         fn = make_step(plugin_first)
@@ -544,6 +583,14 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
                                       if overlap else "one collective after the last view"),
                    "backend": args.backend if world > 1 else None},
     }
+    if rank == 0 and world > 1:
+        # what the step waits for BEHIND its last kernel, and what RCCL chose (the first 8-GPU record should explain
+        # itself: DESIGN 6 predicts ~5 ms exposed on a ring, ~0.75 ms on the direct links)
+        result["comm"] = dict(comm or {}, backend=args.backend,
+                              scheme=("reduce-scatter + sharded Adam + all-gather" if stepper is not None else
+                                      ("all-reduce per parameter, armed on the last view" if overlap else
+                                       "one all-reduce after the last view")),
+                              rccl=parse_rccl_log(rccl_log))
     if rank == 0:
         result["roofline"] = build_roofline(args, kernels, n_vis, n_isect, ms_per_view_rank) \
             if kernels else None
@@ -561,8 +608,9 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
             except Exception as exc:  # noqa: BLE001
                 result["cpu_baseline"] = {"error": repr(exc)}
     # BASELINE config 5 (render.sh's body at 5 M Gaussians, 128-dim feature, 1080p) rides along on the default
-    # one-GPU run as a short object, so that the driver's line carries it: 2 steps of 2 views, its own kernel times
-    # and its own bounded CPU sample.  `--config 5` is the full-length form.
+    # one-GPU run as a short object, so that the driver's line carries it: 5 steps of 2 views through the plugin's
+    # model class in eval mode, its own kernel times, roofline and bounded CPU sample.  `--config 5` is the
+    # full-length form.
     if world == 1 and not selftest and args.device == "cuda" and not args.no_config5:
         del plugin_model, bucket, scene, cot, cameras
         ops.clear_bin_cache()
@@ -570,11 +618,11 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
         torch.cuda.empty_cache()
         a5 = argparse.Namespace(**vars(args))
         a5.config, a5.points, a5.height, a5.width, a5.feature_dim = 5, 5_000_000, 1080, 1920, 128
-        a5.views_per_step, a5.steps, a5.warmup = 2, 2, 1
+        a5.views_per_step, a5.steps, a5.warmup = 2, 5, 1
         try:
             r5 = render_only_result(a5, rank, world, dev, ops, lib, barrier, max_over_ranks)
             result["config5"] = {k: r5[k] for k in ("metric", "value", "unit", "ms_per_view", "steps", "kernels",
-                                                    "kernel_time_fraction_of_wall", "cpu_baseline") if k in r5}
+                                                    "kernel_time_fraction_of_wall", "roofline", "cpu_baseline") if k in r5}
             result["config5"]["workload"] = r5["config"]["workload"]
             result["config5"]["num_intersects"] = r5["config"]["num_intersects"]
         except Exception as exc:  # noqa: BLE001
@@ -601,24 +649,42 @@ def render_only_result(args, rank, world, dev, ops, lib, barrier, max_over_ranks
 
     scene = make_scene(args.points, feature_dim=args.feature_dim, config_index=4).to(dev)
     torch.manual_seed(5)
-    fea_up = MLP(args.feature_dim, 512, hidden_list=[128]).to(dev)
     total_views = args.views_per_step * world
     views = ring_cameras(total_views, args.height, args.width, device=dev)
     my_views = shard_views(total_views, rank, world)
 
     fused = args.route == "plugin" and hasattr(ops, "rasterize_segments")
+    model = None
+    if fused:
+        # the class render.sh loads (plugin.FusedGaussianSplattingModel on stub.py's stand-ins) in EVAL mode, as
+        # eval_setup leaves it (utils/eval_utils.py:67-112): outputs = model(camera); model.fea_up(outputs["feature"])
+        from gaussiangrasper_amd.plugin import make_fused_model_class
+        from gaussiangrasper_amd.stub import StubCameras, StubGaussianSplattingModel
+        model = make_fused_model_class(StubGaussianSplattingModel, ops=ops, fused_training=True)(scene).to(dev).eval()
+        fea_up = model.fea_up
+        cams = {v: StubCameras.from_view(views[v], device=dev) for v in my_views}
+    else:
+        fea_up = MLP(args.feature_dim, 512, hidden_list=[128]).to(dev)
 
     def render(v):
-        # plugin route: the model subclass's get_outputs (ShadeTail + one RasterizeSegments forward);
-        # shim route: the reference's four rasterize forwards
-        out = render_view(scene, views[v], ops, fused=fused)
+        # plugin route: the model class's get_outputs (ActivateGaussians, ShadeTail, one RasterizeSegments forward; the
+        # visualisation images of :785-795 included, as the reference computes them); shim route: the reference's four
+        # rasterize forwards
+        if model is not None:
+            out = model(cams[v])
+        else:
+            out = render_view(scene, views[v], ops, fused=False)
         clip = fea_up(out["feature"])
         return out, clip
 
     with torch.no_grad():
         out, _ = render(my_views[0])
-        n_vis = int((out["radii"] > 0).sum())
-        n_isect = int(out["num_tiles_hit"].long().sum())
+        if model is not None:
+            n_vis = int((model.radii > 0).sum())
+            n_isect = int(ops.last_num_intersects() or 0)
+        else:
+            n_vis = int((out["radii"] > 0).sum())
+            n_isect = int(out["num_tiles_hit"].long().sum())
         del out
         for _ in range(args.warmup):
             for v in my_views:
@@ -653,7 +719,8 @@ def render_only_result(args, rank, world, dev, ops, lib, barrier, max_over_ranks
                                "SH deg 4 rgb + %d-ch feature + depth + normal forwards (%s) and the "
                                "fea_up MLP %d->128->512 on every pixel, render-only, %d views/step/GPU"
                                % (args.points, args.width, args.height, args.feature_dim,
-                                  "plugin route: one fused rasterize operator" if fused
+                                  "plugin route: FusedGaussianSplattingModel.get_outputs in eval mode + model.fea_up, "
+                                  "one fused rasterize operator" if fused
                                   else "shim route: the reference's 4 rasterize calls",
                                   args.feature_dim, args.views_per_step),
                    "route": "plugin" if fused else "shim",
@@ -665,7 +732,10 @@ def render_only_result(args, rank, world, dev, ops, lib, barrier, max_over_ranks
     if rank != 0:
         return None
     result["ms_per_view"] = ms_per_view
-    result["roofline"] = build_roofline(args, kernels, n_vis, n_isect, ms_per_view) if kernels else None
+    mlp_bytes = 4 * 512 * args.height * args.width
+    result["roofline"] = build_roofline(
+        args, kernels, n_vis, n_isect, ms_per_view, extra_view_bytes=mlp_bytes,
+        extra_note=" (render-only) + the fea_up MLP's 4 x 512 x P output bytes") if kernels else None
     result["kernels"] = {k: round(v["avg_ms"], 4) for k, v in sorted(kernels.items())}
     if kernels:
         result["kernel_time_fraction_of_wall"] = sum(v["total_ms"] for v in kernels.values()) / (1e3 * t_prof)

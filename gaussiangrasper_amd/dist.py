@@ -18,6 +18,7 @@ splatting model (parameters are replaced every 100 steps); this is the explicit 
 from __future__ import annotations
 
 import os
+import time
 import socket
 import subprocess
 import sys
@@ -73,6 +74,7 @@ class GradBucket:
                        for i, p in enumerate(self.params) if p.requires_grad and p.is_leaf]
         self._armed = False
         self._work = []
+        self._exposed = getattr(self, "_exposed", [])
         self._order = None     # parameter indices in the order autograd completes them (agreed by all ranks)
         self._fired: List[int] = []
         self._ready: List[bool] = []
@@ -178,9 +180,41 @@ class GradBucket:
         else:
             self._ready = [True] * n
         self._issue_ready()
+        # how long does the step wait for its collectives BEHIND its last kernel?  On a GPU: two events on the current
+        # stream around the waits (wait() makes the stream wait for the collective's stream: the gap between the events
+        # is the time the stream had nothing to run but the hand-over); on the CPU (gloo): wall time of the waits.
+        cuda = self.flat.is_cuda
+        if cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        else:
+            t0 = time.perf_counter()
         for w in self._work:
             w.wait()
+        if cuda:
+            e1.record()
+            self._exposed.append((e0, e1))
+        else:
+            self._exposed.append(1e3 * (time.perf_counter() - t0))
+        self._collectives = len(self._work)
         self._work = []
+
+    def comm_stats(self, reset: bool = True) -> dict:
+        """Per-step communication figures of the armed reductions since the last call (bench.py --gpus N > 1):
+        exposed_ms = time finish() waited for the collectives after the step's last kernel (mean / max over the steps),
+        bytes = gradient bytes reduced per step, collectives = messages per step."""
+        vals = []
+        for x in self._exposed:
+            if isinstance(x, tuple):
+                x[1].synchronize()
+                vals.append(float(x[0].elapsed_time(x[1])))
+            else:
+                vals.append(float(x))
+        if reset:
+            self._exposed = []
+        return {"steps": len(vals), "exposed_ms_mean": (sum(vals) / len(vals)) if vals else None,
+                "exposed_ms_max": max(vals) if vals else None, "bytes_per_step": self.nbytes,
+                "collectives_per_step": getattr(self, "_collectives", None)}
 
     def all_reduce(self) -> None:
         """Unoverlapped form: one collective over the whole bucket."""

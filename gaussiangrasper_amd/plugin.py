@@ -99,7 +99,7 @@ class LazyOutputs(dict):
     feature: :804-935).  The lazy keys are NOT in the underlying dict storage until they are computed: `[]` reaches them
     through `__missing__`, and `__iter__` / `keys` are overridden, which makes CPython's `dict(out)`, `{**out}` and
     `other.update(out)` leave their C fast path and go through `keys()` + `[]` — a copy holds real tensors, never a
-    placeholder.  Returned in training mode only; eval / viewer / render.sh get a plain dict."""
+    placeholder."""
 
     def __init__(self, base: Dict, lazy: Dict):
         super().__init__(base)
@@ -246,9 +246,9 @@ def make_fused_model_class(base, ops=_ops, background_override=lambda: None, fus
     class FusedGaussianSplattingModel(base):
         """GaussianSplattingModel on the fused MI355X rasterizer call (gaussiangrasper_amd.plugin)."""
 
-        # "lazy": in TRAINING mode normal_vis / feature_vis (the reference's rank-3 PCA of the feature image, :785-795) are
-        # computed when something reads them (eval / viewer / render.sh always get them computed, in a plain dict);
-        # "eager": on every call, as the reference does; "off": feature_vis = first 3 channels
+        # "lazy": normal_vis / feature_vis (the reference's rank-3 PCA of the feature image, :785-795) are computed when
+        # something reads them — `[]`, `get`, `items`, `values`, iteration and every kind of copy see tensors (LazyOutputs);
+        # "eager": on every call, in a plain dict, as the reference does; "off": feature_vis = first 3 channels
         feature_vis_mode = "lazy"
 
         def get_outputs(self, camera) -> Dict[str, Union[torch.Tensor, List]]:
@@ -355,7 +355,7 @@ def make_fused_model_class(base, ops=_ops, background_override=lambda: None, fus
                 return torch.matmul(flat, V[:, :3]).view(feat.size()[:-1] + (3,))
 
             lazy = {"normal_vis": normal_vis, "feature_vis": feature_vis}
-            if self.feature_vis_mode == "lazy" and self.training:
+            if self.feature_vis_mode == "lazy":
                 return LazyOutputs(out, lazy)
             out.update({k: f() for k, f in lazy.items()})
             return out

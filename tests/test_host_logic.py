@@ -203,6 +203,13 @@ def test_bench_spawns_its_own_ranks_and_reduces_gradients(tmp_path):
     assert lines[0]["config"]["backend"] == "gloo"
     nbytes = lines[0]["config"]["grad_allreduce_bytes"]
     assert nbytes == 4 * 300 * (3 + 3 + 4 + 1 + 75 + 4)
+    # the N > 1 line explains its communication itself: what the step waited for behind its last
+    # kernel, how many bytes in how many messages, by which scheme; `rccl` is RCCL's own account (none under gloo)
+    comm = lines[0]["comm"]
+    assert comm["bytes_per_step"] == nbytes and comm["collectives_per_step"] == 6 and comm["backend"] == "gloo"
+    assert comm["steps"] >= lines[0]["steps"] and comm["exposed_ms_mean"] >= 0.0
+    assert comm["exposed_ms_max"] >= comm["exposed_ms_mean"] and comm["rccl"] is None
+    assert comm["scheme"].startswith("all-reduce per parameter")
     r2b = _run_bench(["--dump-grads", str(g2b), "--no-overlap"], tmp_path, 2)
     assert r2b.returncode == 0, r2b.stderr[-2000:]
     # single process, same 4 views: 2 ranks x 2 views/step == 1 rank x 4 views/step
@@ -210,6 +217,7 @@ def test_bench_spawns_its_own_ranks_and_reduces_gradients(tmp_path):
     assert r1.returncode == 0, r1.stderr[-2000:]
     l1 = _json_lines(r1.stdout)
     assert len(l1) == 1 and l1[0]["n_gpus"] == 1 and l1[0]["config"]["grad_allreduce_bytes"] == nbytes
+    assert "comm" not in l1[0]
     a, b, c = (torch.load(f, weights_only=True) for f in (g2, g2b, g1))
     assert float(c.abs().sum()) > 0
     tol = 1e-6 * float(c.abs().max())

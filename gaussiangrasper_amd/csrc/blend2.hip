@@ -908,6 +908,15 @@ __global__ __launch_bounds__(64 * GG_WPB_OTHER) void blend2_bwd_narrow_kernel(
 #ifndef GG_S16_WAVES
 #define GG_S16_WAVES 4    // waves per SIMD the 16-slot backward is compiled for (128 registers)
 #endif
+// r04: the pair build's SECOND flush (FAC[16 x 64] V_OUT2[64 x 8]) on fp16 two-piece operands too: its A pieces are the
+// first flush's (same FAC tile, same layout), its B pieces — the second array's cotangent tile, 64 pixels x 8 channels,
+// carrying s_w — are split from the tile in LDS right where they are used: 8 v_mfma_f32_16x16x32_f16 (128 matrix cycles)
+// instead of 16 v_mfma_f32_16x16x4_f32 (512 of the batch's 1 280) for 48 more vector instructions per batch.
+// Measured (tools/pairbench.py, interleaved variants, bench view): 0.7825 -> 0.7604 ms.  The B pieces split ONCE per wave
+// and held in 16 registers across the walk: 25 spilled registers at four waves per SIMD, 0.8898 ms — not kept.
+#ifndef GG_F2_F16
+#define GG_F2_F16 1   // 0: the fp32 second flush of round 3
+#endif
 
 // =============================================================================================
 // backward, wide (32-channel chunk): wave-autonomous, matrix pipe for D = <colour, v_out> AND for the colour
@@ -993,7 +1002,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     constexpr int FS = S16 ? GG_S16_STRIDE : 65;   // slab row stride in floats (FIDX)
     __shared__ float s_fac[GG_WPB_WIDE_BWD][NSLOT * FS];
     __shared__ int s_slote[GG_WPB_WIDE_BWD][DET ? B2_SLOTS : 1];
-    __shared__ __attribute__((aligned(16))) float s_vt[GG_WPB_WIDE_BWD][EX ? 64 * 8 : 4];   // EX: V_OUT2[pixel][8]
+    __shared__ __attribute__((aligned(16))) float s_vt[GG_WPB_WIDE_BWD][EX ? 64 * 8 + 8 : 4];   // EX: V_OUT2[pixel][8] (+ F2: 8 column scales)
     __shared__ float s_geo[GG_WPB_WIDE_BWD][MG ? 16 * 8 : 1];   // MG: the batch's geometry sums [slot][8]
 
     int wave;
@@ -1038,6 +1047,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
     // 16 nb + (lane & 15)] x s_c.  s_w: one power of two for the quadrant's cotangents (all channels of both arrays),
     // s_c: one per channel of this lane; the raw values above are dead after the prologue.
     constexpr bool F16 = S16 && (GG_S16_F16 != 0);
+    constexpr bool F2 = F16 && EX && (GG_F2_F16 != 0);
     unsigned vah[F16 ? 4 : 1][F16 ? 4 : 1], val[F16 ? 4 : 1][F16 ? 4 : 1];
     unsigned vbh[F16 ? 2 : 1][F16 ? 2 : 1][F16 ? 4 : 1], vbl[F16 ? 2 : 1][F16 ? 2 : 1][F16 ? 4 : 1];
     float sw = 1.0f, inv_sw = 1.0f, inv_scf[2] = {1.0f, 1.0f};
@@ -1220,6 +1230,21 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         }                                               // second flush takes it out of its results
         reinterpret_cast<float4 *>(vt + lane * 8)[0] = make_float4(t8[0], t8[1], t8[2], t8[3]);
         reinterpret_cast<float4 *>(vt + lane * 8)[1] = make_float4(t8[4], t8[5], t8[6], t8[7]);
+        if (F2) {
+            // the second flush's B operands are split into fp16 pieces per CHANNEL: column c of the tile gets its own
+            // power of two on top of s_w (channels of one array can be decades apart — rgb | depth | normal are),
+            // kept behind the tile; lane (c = lane & 7, part = lane >> 3) takes the maximum of 8 pixels, three
+            // exchanges join the parts
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float m = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) m = fmaxf(m, fabsf(vt[(8 * (lane >> 3) + i) * 8 + (lane & 7)]));
+            for (int off = 8; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            if (lane < 8) vt[64 * 8 + lane] = pow2_scale(m);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     if (F16) {
 #pragma unroll
@@ -1567,13 +1592,14 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
         // are not written
         slotmask = __builtin_amdgcn_readfirstlane(slotmask);
         if (ABL >= 2 || slotmask == 0u) return;
+        f32x4 a4f_keep = {0.0f, 0.0f, 0.0f, 0.0f};   // F2: the second array's flush, formed beside the first one's
         if (S16) {   // FAC[16 slots x 64 pixels] * V_OUT[64 x 32 channels] as 2 x 16 v_mfma_f32_16x16x4_f32
             int sl = lane & 15, q4 = lane >> 4;
             asm volatile("" : "+v"(sl), "+v"(q4));
             f32x4 acc2[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
-            if (F16 && !feat_any && GG_FEATANY_FLUSH) {
-                // (no cotangent of this array in the quadrant: its colour gradients are zeros — nothing to add)
-            } else if (F16) {   // A: FAC[slot sl][pixel 32 ks + 8 q4 + 0..7] x 2^15 in two pieces; 2 x 2 x 4 v_mfma_f32_16x16x32_f16
+            const bool first_on = !(F16 && !feat_any && GG_FEATANY_FLUSH);   // (no cotangent of the first array in the
+            f32x4 &a4f = a4f_keep;                                            //  quadrant: its colour gradients are zeros)
+            if (F16 && (first_on || F2)) {   // A: FAC[slot sl][pixel 32 ks + 8 q4 + 0..7] x 2^15 in two pieces
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     unsigned fh[4], fl[4];
@@ -1582,6 +1608,7 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                         split2h(fac_w[FIDX(sl, 32 * ks + 8 * q4 + 2 * t)] * GG_FAC_SCALE,
                                 fac_w[FIDX(sl, 32 * ks + 8 * q4 + 2 * t + 1)] * GG_FAC_SCALE, fh[t], fl[t]);
                     const h16x8 Fh = H8(fh[0], fh[1], fh[2], fh[3]), Fl = H8(fl[0], fl[1], fl[2], fl[3]);
+                    if (first_on) {   // 2 x 2 x 4 v_mfma_f32_16x16x32_f16
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb) {
                         const int kk = F16 ? ks : 0, nn = F16 ? nb : 0;
@@ -1594,11 +1621,32 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                         acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Fh, Vl, acc2[nb], 0, 0, 0);
                         acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Fh, Vh, acc2[nb], 0, 0, 0);
                     }
+                    }
+                    if (F2) {         // the second array's flush rides on the same A pieces
+                        // B: V_OUT2[pixel 32 ks + 8 q4 + 0..7][channel sl] (x s_w x the channel's own scale; lanes of
+                        // channels 8..15 supply zeros)
+                        unsigned wh[4], wl[4];
+                        const float wm = sl < 8 ? vt[64 * 8 + (sl & 7)] : 0.0f;   // the channel's power of two
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            split2h(vt[(32 * ks + 8 * q4 + 2 * t) * 8 + (sl & 7)] * wm,
+                                    vt[(32 * ks + 8 * q4 + 2 * t + 1) * 8 + (sl & 7)] * wm, wh[t], wl[t]);
+                        const h16x8 Wh = H8(wh[0], wh[1], wh[2], wh[3]);
+                        const h16x8 Wl = H8(wl[0], wl[1], wl[2], wl[3]);
+#if !GG_F16_NLL
+                        a4f = __builtin_amdgcn_mfma_f32_16x16x32_f16(Fl, Wl, a4f, 0, 0, 0);
+#endif
+                        a4f = __builtin_amdgcn_mfma_f32_16x16x32_f16(Fl, Wh, a4f, 0, 0, 0);
+                        a4f = __builtin_amdgcn_mfma_f32_16x16x32_f16(Fh, Wl, a4f, 0, 0, 0);
+                        a4f = __builtin_amdgcn_mfma_f32_16x16x32_f16(Fh, Wh, a4f, 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc2[nb][r] *= inv_scf[nb];
+            } else if (F16) {
+                // (nothing to add for the first array, and the second flush takes its operands itself)
             } else {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
@@ -1671,10 +1719,15 @@ __global__ __launch_bounds__(64 * GG_WPB_WIDE_BWD) __attribute__((amdgpu_waves_p
                 if (((slotmask >> (16 * mb)) & 0xffffu) == 0u) continue;
                 f32x4 a4 = {0.0f, 0.0f, 0.0f, 0.0f};
                 const int m = 16 * mb + n16;
+                if (F2) {   // formed beside the first flush, on fp16 pieces: the 2^15 of FAC comes out here
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a4[r] = a4f_keep[r] * GG_FAC_UNSCALE * pow2_inv(vt[64 * 8 + (n16 & 7)]);
+                } else {
 #pragma unroll
                 for (int s = 0; s < 16; ++s)
                     a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fac_w[FIDX(m, 4 * s + k4)], vbp[32 * s] * vmask, a4,
                                                               0, 0, 0);
+                }
                 if (MG) {
                     // record row of slot 4 k4 + r: lanes n16 < 8 carry channel n16 of the second array (column 6 + n16),
                     // lanes 8..13 the geometry sum n16 - 8 (column n16 - 8): 14 floats of one 64-byte row per request

@@ -94,6 +94,11 @@ __device__ __forceinline__ float gg_expf(float x) {
 // denormal or 0 where gg_expf returns 0 — the walks only use exp(-sigma) through alpha = opacity * exp >= 1/255,
 // so every pair they keep sees the same bits and every pair they drop is dropped by both.
 __device__ __forceinline__ float gg_expf_walk(float x) {
+#ifdef GG_EXP_PROBE
+    // TIMING PROBE ONLY (tools/pairbench.py on a variant build): the hardware's v_exp_f32 —
+    // 2 instructions instead of 14, values NOT the oracle's (alpha / stop decisions flip): never in the product library
+    return __builtin_amdgcn_exp2f(x * GG_EXP_LOG2E);
+#endif
     float t = x * GG_EXP_LOG2E;
     float n = __builtin_rintf(t);
     float r = __builtin_fmaf(n, -GG_EXP_LN2_HI, x);

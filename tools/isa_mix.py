@@ -18,7 +18,8 @@ KERNELS = {  # bench.py name -> mangled-name fragment
     "blend_fwd_kernel<3>": "blend2_fwd_kernelILi3ELb0",
     "blend_fwd_kernel<8>": "blend2_fwd_kernelILi8ELb0",
     "blend_fwd_kernel<32>": "blend2_fwd_kernelILi32ELb1ELb1ELb0E",
-    "blend_fwd_pair_kernel<40>": "blend2_fwd_kernelILi32ELb1ELb1ELb1E",
+    "blend_fwd_pair_kernel<40>": "blend2_fwd_batch_kernel",
+    "blend_fwd_pair_kernel<40> (exact order)": "blend2_fwd_kernelILi32ELb1ELb1ELb1E",
     "blend_bwd_kernel<3>": "blend2_bwd_narrow_kernelILi3ELi0ELb0E",
     "blend_bwd_kernel<8>": "blend2_bwd_narrow_kernelILi8ELi0ELb0E",
     "blend_bwd_kernel<32>": "blend2_bwd_wide_kernelILb1ELi0ELi32ELb0ELb0E",

@@ -32,3 +32,10 @@ for _ in range(2):
                                   [(feat, torch.zeros(32, device=dev)), (tail, torch.zeros(7, device=dev))])
     torch.autograd.backward(imgs, vo)
 torch.cuda.synchronize()
+# the exact-order pair forward (ops.set_exact_forward: the parity suite's kernel) beside the default one
+ops.set_exact_forward(True)
+with torch.no_grad():
+    for _ in range(2):
+        ops.rasterize_segments(x, depths, radii, conics.detach(), nth, opac.detach(), h, w,
+                               [(feat, torch.zeros(32, device=dev)), (tail, torch.zeros(7, device=dev))])
+torch.cuda.synchronize()

@@ -5,9 +5,10 @@ roofline.traffic / roofline.valu).  HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 
 counts half of a wide coalesced read; MI355X_MICROARCH.md)."""
 import csv, glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-NAMES = {"blend2_fwd_kernel<32, true, true, true": "blend_fwd_pair_kernel<40>",
+NAMES = {"blend2_fwd_batch_kernel": "blend_fwd_pair_kernel<40>",      # r04: the default pair forward (batched, fp16 pieces)
+         "blend2_fwd_kernel<32, true, true, true": "blend_fwd_pair_kernel<40> (exact order)",
          "blend2_fwd_kernel<3,": "blend_fwd_kernel<3>", "blend2_fwd_kernel<8,": "blend_fwd_kernel<8>",
          "blend2_fwd_kernel<32,": "blend_fwd_kernel<32>", "blend2_bwd_narrow_kernel<3,": "blend_bwd_kernel<3>",
          "blend2_bwd_narrow_kernel<8,": "blend_bwd_kernel<8>", "blend2_bwd_wide_kernel<true, 0, 32, false, false": "blend_bwd_kernel<32>",
@@ -70,7 +71,8 @@ for name in sorted({r[0] for r in rows}):
                      ("SQ_WAVE_CYCLES", "wave_cycles"), ("SQ_WAIT_ANY", "wait_any"), ("SQ_WAIT_INST_ANY", "wait_inst_any"),
                      ("SQ_ACTIVE_INST_ANY", "active_inst_any"), ("SQ_VALU_MFMA_BUSY_CYCLES", "mfma_busy_cycles"),
                      ("SQ_INSTS_LDS", "insts_lds"), ("SQ_LDS_BANK_CONFLICT", "lds_bank_conflict"),
-                     ("VALUBusy", "valu_busy_pct"),
+                     ("VALUBusy", "valu_busy_pct"), ("SQ_VALU_MFMA_COEXEC_CYCLES", "valu_mfma_coexec_cycles"),
+                     ("SQ_ACTIVE_INST_VALU", "active_inst_valu"), ("SQ_BUSY_CYCLES", "sq_busy_cycles"),
                      ("OccupancyPercent", "occupancy_pct"), ("TCC_EA0_ATOMIC_sum", "atomic_requests_64B"),
                      ("TCP_UTCL1_TRANSLATION_MISS_sum", "utcl1_misses")):
         if (name, ctr) in mean:

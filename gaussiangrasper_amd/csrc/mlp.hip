@@ -360,6 +360,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(long P, int out_dim, 
 #ifndef MLPF_ABL
 #define MLPF_ABL 0   // measurement builds: 1 no output stores, 2 no layer-2 MFMAs, 3 no stores and layer 2's A operands read once
 #endif
+#define GG_MLP_FAST_MAX_OUT 3968                 // (160 KB - 2 x 64 KB slices) / 4 B = 8192 floats = 2 x 128 + 2 x out_dim
 #define MLPF_SLICE_Q 4096                        // uint4 per 64 KB slice: 8 tiles x 4 k-steps x 2 pieces x 64 lanes
 __host__ __device__ __forceinline__ int mlpf_hidden_of(int ks, int q, int j) { return 16 * (2 * ks + (j >> 2)) + 4 * q + (j & 3); }
 
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(MLPF_THREADS) void mlp_fwd_f16_kernel(long P, int o
 }
 
 extern "C" size_t gg_mlp_fwd_fast_workspace(int in_dim, int hidden_dim, int out_dim) {
-    if (hidden_dim != MLP_HID || in_dim <= 0 || in_dim % 32 || out_dim <= 0 || out_dim % 16) return 0;
+    if (hidden_dim != MLP_HID || in_dim <= 0 || in_dim % 32 || out_dim <= 0 || out_dim % 16 || out_dim > GG_MLP_FAST_MAX_OUT) return 0;
     const size_t nsl = ((size_t)out_dim + 127) / 128;
     return sizeof(uint4) * ((size_t)8 * (in_dim / 32) * 2 * 64 + nsl * MLPF_SLICE_Q) + sizeof(float) * (size_t)(MLP_HID + out_dim);
 }
@@ -627,7 +628,9 @@ extern "C" int gg_mlp_fwd_fast(int64_t num_rows, int in_dim, int hidden_dim, int
     GG_REQUIRE(num_rows >= 0, "num_rows < 0");
     GG_REQUIRE(hidden_dim == MLP_HID, "hidden_dim must be 128 (the reference's fea_up)");
     GG_REQUIRE(in_dim == 32 || in_dim == 64 || in_dim == 128, "in_dim must be 32, 64 or 128 (gg_mlp_fwd takes 8 and 16)");
-    GG_REQUIRE(out_dim > 0 && out_dim % 16 == 0 && out_dim <= 4096, "out_dim must be a multiple of 16, at most 4096");
+    // two 64 KB slice buffers + [2 x 128 + 2 x out_dim] floats of biases must fit the CU's 160 KB of LDS
+    GG_REQUIRE(out_dim > 0 && out_dim % 16 == 0 && out_dim <= GG_MLP_FAST_MAX_OUT,
+               "out_dim must be a multiple of 16, at most 3968 (two weight slices and the biases share 160 KB of LDS)");
     if (num_rows == 0) return GG_OK;
     GG_REQUIRE(x && w1 && b1 && w2 && b2 && y, "null pointer");
     GG_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "x and y must be 16-byte aligned");

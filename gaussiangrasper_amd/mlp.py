@@ -25,6 +25,7 @@ HIDDEN = 128
 SUPPORTED_IN = (8, 16, 32, 64, 128)     # fused forward kernels (W1 in registers; 128: W1 in LDS, W2 slices streamed)
 SUPPORTED_IN_BWD = (8, 16, 32, 64, 128)
 NATIVE_BWD_MAX_ROWS = 1 << 16
+FAST_MAX_OUT = 3968        # gg_mlp_fwd_fast: two 64 KB weight slices + the biases share the CU's 160 KB of LDS
 FAST_IN = (32, 64, 128)     # gg_mlp_fwd_fast: fp16 two-piece operands on the 16x-rate matrix instruction (fp32-grade)
 # True: always the exact-order kernels (bit-identical to oracle.mlp_fwd's summation order; 4x the matrix cycles)
 EXACT_ORDER = False
@@ -42,7 +43,7 @@ class _MLPForward(Function):
             raise ValueError(f"x has {x.shape[-1]} features, the first layer takes {in_dim}")
         x2 = _f32(x).reshape(-1, in_dim)
         w1c, b1c, w2c, b2c = _f32(w1), _f32(b1), _f32(w2), _f32(b2)
-        if in_dim in FAST_IN and out_dim % 16 == 0 and out_dim <= 4096 and not EXACT_ORDER:
+        if in_dim in FAST_IN and out_dim % 16 == 0 and out_dim <= FAST_MAX_OUT and not EXACT_ORDER:
             lib = _lib.load()
             y = torch.empty(x2.shape[0], out_dim, dtype=torch.float32, device=dev)
             ws = torch.empty(lib.gg_mlp_fwd_fast_workspace(in_dim, HIDDEN, out_dim), dtype=torch.uint8, device=dev)

@@ -308,7 +308,7 @@ int gg_debug_set_fwd_blocks(int pair_blocks, int chunk_blocks);
 /* The same forward four times faster (round 3): both layers as products of fp16 two-piece operands scaled by powers of
  * two on v_mfma_f32_16x16x32_f16 — as accurate against a double-precision sum as the fp32 matrix instruction
  * (tools/check_f16split.hip), but not gg_mlp_fwd's summation order: the two agree to ~1e-6 of the largest output
- * (tests/test_gpu_parity.py), not bit for bit.  in_dim 32 / 64 / 128, out_dim a multiple of 16 (<= 4096); `ws`:
+ * (tests/test_gpu_parity.py), not bit for bit.  in_dim 32 / 64 / 128, out_dim a multiple of 16 (<= 3968: LDS); `ws`:
  * gg_mlp_fwd_fast_workspace(in_dim, 128, out_dim) bytes, 16-byte aligned, rewritten by every call (the packed
  * weights: 0.3 MB at out_dim 512).  What the reference runs here is cuBLAS behind nn.Linear
  * (gaussian_splatting.py:198-213): no summation order to match on that side. */

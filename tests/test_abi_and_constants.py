@@ -43,6 +43,13 @@ def test_workspace_queries_are_pure_host_calls():
     assert lib.gg_blend_workspace(0) > 0
     small, big = lib.gg_bin_sort_workspace(1000, 5000), lib.gg_bin_sort_workspace(1_000_000, 4_000_000)
     assert 0 < small < big < 200 * 2 ** 20   # 1M / 4M intersections needs < 200 MiB of scratch
+    # the fast MLP forward: widest out_dim its LDS holds is 3968 (two 64 KB weight slices + biases in 160 KB)
+    from gaussiangrasper_amd.mlp import FAST_MAX_OUT
+    assert FAST_MAX_OUT == 3968
+    assert lib.gg_mlp_fwd_fast_workspace(128, 128, 512) > 0 and lib.gg_mlp_fwd_fast_workspace(128, 128, FAST_MAX_OUT) > 0
+    assert lib.gg_mlp_fwd_fast_workspace(128, 128, FAST_MAX_OUT + 16) == 0
+    n = ctypes.c_void_p(0)
+    assert lib.gg_mlp_fwd_fast(1, 128, 128, 4096, n, n, n, n, n, n, n, 0, n) == -1 and b"3968" in lib.gg_last_error()
 
 
 def test_argument_validation_without_a_gpu():

@@ -708,12 +708,15 @@ def _mlp_ref64(x, w1, b1, w2, b2):
 
 @pytest.mark.parametrize("rows,in_dim,out_dim", [(1, 32, 512), (63, 32, 512), (257, 32, 512), (5000, 32, 512),
                                                  (777, 64, 32), (1000, 64, 272), (1, 128, 512), (300, 128, 512),
-                                                 (5000, 128, 512), (1000, 128, 96), (4099, 128, 1040)])
+                                                 (5000, 128, 512), (1000, 128, 96), (4099, 128, 1040),
+                                                 (200, 128, 3968), (200, 128, 4096), (200, 64, 4000)])
 def test_mlp_fwd_fast_is_fp32_grade(oracle, rows, in_dim, out_dim, monkeypatch):
     """gg_mlp_fwd_fast (the default behind mlp_forward: fp16 two-piece operands on the 16x-rate matrix instruction)
     against a float64 evaluation: max |err| <= 1e-6 of the largest output, and no worse than 1.5x the error of the
     exact-order fp32 kernel (gg_mlp_fwd) where that one takes the shape; ragged row counts, partial last slices of
-    W2 (out_dim 96, 272, 1040)."""
+    W2 (out_dim 96, 272, 1040); out_dim 3968 is the widest the fast kernel's LDS holds (two 64 KB weight slices + the
+    biases in 160 KB) — 4096 goes to gg_mlp_fwd and 4000 (not a multiple of 32) to the library GEMMs, silently
+    correct instead of a failed launch."""
     from gaussiangrasper_amd import mlp as mlp_mod
     from gaussiangrasper_amd.mlp import mlp_forward
     g = torch.Generator().manual_seed(3 * rows + in_dim + out_dim)

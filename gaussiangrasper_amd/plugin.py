@@ -230,8 +230,15 @@ def _nearest_columns(src_chw: torch.Tensor, size, pixels: torch.Tensor) -> torch
     return src_chw[:, iy, ix]
 
 
+def device_sampling_default() -> bool:
+    """GG_DEVICE_SAMPLING=1: the feature losses' pixel samples come from gaussiangrasper_amd.sampling (device generator)
+    instead of the reference's helpers (host `torch.randperm` over every label's pixel count: ~0.3 s per 1600x1200 view)."""
+    import os
+    return os.environ.get("GG_DEVICE_SAMPLING", "0") not in ("0", "false", "no", "")
+
+
 def make_fused_model_class(base, ops=_ops, background_override=lambda: None, fused_training: bool = False,
-                           loss_ops=None, mlp_class="default"):
+                           loss_ops=None, mlp_class="default", device_sampling: Optional[bool] = None):
     """Subclass of the reference's GaussianSplattingModel whose get_outputs uses `fused_view`.
     `base` is nerfstudio.models.gaussian_splatting.GaussianSplattingModel (or `stub.StubGaussianSplattingModel`,
     which restates the attributes used here, where nerfstudio is not installed).
@@ -241,7 +248,12 @@ def make_fused_model_class(base, ops=_ops, background_override=lambda: None, fus
     image-space terms with the fused loss kernels (`loss_ops`, default gaussiangrasper_amd.losses: main_loss,
     depth_normal_loss, cosine_similarity_loss, gather_pixels) and `fea_up` (:258) becomes `mlp_class` (default
     gaussiangrasper_amd.mlp.MLP: same sub-modules and state-dict keys, fused forward / backward kernels; None keeps the
-    reference's module)."""
+    reference's module).
+    device_sampling: draw the feature losses' pixel samples with gaussiangrasper_amd.sampling (same law, device
+    generator, ~1 ms) instead of the reference module's helpers (same draws as the reference, ~0.3 s per full-size view
+    of host `torch.randperm`); None: GG_DEVICE_SAMPLING (default off)."""
+    if device_sampling is None:
+        device_sampling = device_sampling_default()
 
     class FusedGaussianSplattingModel(base):
         """GaussianSplattingModel on the fused MI355X rasterizer call (gaussiangrasper_amd.plugin)."""
@@ -389,7 +401,10 @@ def make_fused_model_class(base, ops=_ops, background_override=lambda: None, fus
             F = torch.nn.functional
             L = loss_ops if loss_ops is not None else _default_loss_ops()
             mod = sys.modules.get(base.__module__)
-            sampling_pairs_in_mask, sampling_in_mask = mod.sampling_pairs_in_mask, mod.sampling_in_mask
+            if device_sampling:
+                from .sampling import sampling_in_mask, sampling_pairs_in_mask
+            else:
+                sampling_pairs_in_mask, sampling_in_mask = mod.sampling_pairs_in_mask, mod.sampling_in_mask
             d = self._get_downscale_factor()
             if d > 1:
                 newsize = [batch["image"].shape[0] // d, batch["image"].shape[1] // d]

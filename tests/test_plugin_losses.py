@@ -207,3 +207,63 @@ def test_fea_up_swap_keeps_the_reference_state_dict():
     fused.load_state_dict(ref.state_dict())
     for k, v in sd.items():
         assert torch.equal(fused.state_dict()[k], v)
+
+
+def test_device_sampling_draws_the_reference_law():
+    """gaussiangrasper_amd.sampling (the plugin's opt-in replacement for the reference's host-randperm helpers): same
+    shapes and counts as the helpers of :120-148 on the same mask, every sample inside its label, distinct within a
+    draw, the two members of a pair independent draws, all pixels of a label reachable"""
+    from gaussiangrasper_amd import sampling as S
+    g = torch.Generator().manual_seed(2)
+    mask = torch.randint(-1, 4, (37, 53), generator=g).float()
+    mask[:3] = 7.0                                              # a label value that is not consecutive
+    mask[30:, 40:] = -1.0
+    torch.manual_seed(1)
+    ref_pts, ref_pairs = sampling_in_mask(mask, 100), sampling_pairs_in_mask(mask, 60)
+    pts, pairs = S.sampling_in_mask(mask, 100), S.sampling_pairs_in_mask(mask, 60)
+    assert pts.shape == ref_pts.shape and pts.dtype == torch.int64
+    assert len(pairs) == len(ref_pairs) == 5
+    labels = [v for v in torch.unique(mask).tolist() if v > -1]
+    per = 100 // len(torch.unique(mask).tolist()[1:])
+    assert per == 100 // (len(torch.unique(mask)) - 1)
+    off = 0
+    for lab, (a, b), (ra, rb) in zip(labels, pairs, ref_pairs):
+        assert a.shape == ra.shape and b.shape == rb.shape
+        for s in (a, b, pts[off:off + min(per, int((mask == lab).sum()))]):
+            assert bool((mask[s[:, 0], s[:, 1]] == lab).all())
+            assert len({(int(r), int(c)) for r, c in s.tolist()}) == s.shape[0]      # without replacement
+        assert not torch.equal(a, b)
+        off += min(per, int((mask == lab).sum()))
+    assert off == pts.shape[0]
+    # a label with fewer pixels than asked for: all of them, each once
+    small = torch.full((6, 6), -1.0)
+    small[1, 2] = small[4, 5] = small[0, 0] = 0.0
+    small[3, 3] = 1.0
+    s = S.sampling_in_mask(small, 1000)
+    assert sorted(map(tuple, s.tolist())) == [(0, 0), (1, 2), (3, 3), (4, 5)]
+    hits = torch.zeros(6, 6)
+    for _ in range(40):
+        p = S.sampling_pairs_in_mask(small, 1)[0][0]
+        hits[p[0, 0], p[0, 1]] += 1
+    assert bool((hits[small == 0] > 0).all()) and float(hits[small != 0].sum()) == 0
+
+
+def test_plugin_get_loss_dict_with_device_sampling_on_cpu():
+    """device_sampling=True: same keys, finite losses, gradients everywhere the reference's sampling gives them"""
+    import oracle_ops
+    from gaussiangrasper_amd.plugin import make_fused_model_class
+    h, w = 64, 96
+    sc = make_scene(500, feature_dim=8, config_index=9)
+    sc.scales.add_(1.6)
+    Model = make_fused_model_class(StubGaussianSplattingModel, ops=oracle_ops, fused_training=True,
+                                   loss_ops=torch_loss_ops(), mlp_class=None, device_sampling=True)
+    torch.manual_seed(5)
+    m = Model(sc, config=default_config(), step=30000).train()
+    cam = StubCameras.from_view(ring_cameras(4, h, w)[1])
+    state = torch.random.get_rng_state()
+    got = m.get_loss_dict(m.get_outputs(cam), _batch(h, w, 3))
+    assert tuple(got) == KEYS and all(bool(torch.isfinite(v.detach()).all()) for v in got.values())
+    sum(got.values()).backward()
+    assert all(getattr(m, k).grad is not None and float(getattr(m, k).grad.abs().max()) > 0 for k in PARAMS)
+    assert float(got["feature_loss"].detach()) != 0.0 and float(got["up_loss"].detach()) != 0.0
+    del state

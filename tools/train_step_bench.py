@@ -65,14 +65,22 @@ def main():
     from gaussiangrasper_amd.plugin import make_fused_model_class
     from gaussiangrasper_amd.stub import StubCameras, StubGaussianSplattingModel
     torch.manual_seed(3)
-    model = make_fused_model_class(StubGaussianSplattingModel, fused_training=True)(scene).to(dev).train()
-    model_t = make_fused_model_class(StubGaussianSplattingModel, fused_training=True, loss_ops=torch_loss_ops(),
-                                     mlp_class=None)(scene).to(dev).train()
+    # three instances over the SAME six Parameters:
+    #   model    fused losses, fea_up on the MLP kernels, pixel samples from gaussiangrasper_amd.sampling (device generator)
+    #   model_r  the same with the reference module's sampling helpers (nine host torch.randperm per view: the default,
+    #            same draws as the reference)
+    #   model_t  loss namespace and fea_up plain torch, the reference's sampling helpers: the reference's own expressions
+    mk = lambda **kw: make_fused_model_class(StubGaussianSplattingModel, fused_training=True, **kw)(scene).to(dev).train()
+    model = mk(device_sampling=True)
+    model_r = mk(device_sampling=False)
+    model_t = mk(loss_ops=torch_loss_ops(), mlp_class=None, device_sampling=False)
     names = ("means", "scales", "quats", "opacities", "colors_all", "feature")
     for n_ in names:
         setattr(scene, n_, getattr(model, n_))
         setattr(model_t, n_, getattr(model, n_))
+        setattr(model_r, n_, getattr(model, n_))
     model_t.fea_up.load_state_dict(model.fea_up.state_dict())
+    model_r.fea_up = model.fea_up
     cams = [StubCameras.from_view(v, device=dev, cam_idx=i) for i, v in enumerate(views)]
     g = torch.Generator(device="cpu").manual_seed(7)
     # a synthetic batch of the shapes datasets/base_dataset.py:92-124 hands over, resident in HBM: side inputs at half
@@ -94,8 +102,8 @@ def main():
         return [cls([getattr(scene, n)], lr=LRS[n], eps=1e-15) for n in names] + \
                [cls(list((model if cls is FusedAdam else model_t).fea_up.parameters()), lr=1e-3, eps=1e-15)]
 
-    def iteration(fused: bool, opts):
-        m = model if fused else model_t
+    def iteration(fused, opts):
+        m = {True: model, "reference-sampling": model_r, False: model_t}[fused]
         bucket.zero_()
         opts[-1].zero_grad(set_to_none=True)        # fea_up's parameters (the Gaussians' gradients live in the bucket)
         for k in range(len(views)):
@@ -105,7 +113,7 @@ def main():
             loss_dict = m.get_loss_dict(out, batch)
             sum(loss_dict.values()).backward()
         bucket.finish()
-        if fused:
+        if fused is not False:
             fused_step(opts)
         else:
             for o in opts:
@@ -122,17 +130,24 @@ def main():
         return (time.perf_counter() - t0) / a.steps
 
     t_fused = timed(True, optimizers(FusedAdam))
+    t_fused_r = timed("reference-sampling", optimizers(FusedAdam)) if not a.skip_torch else float("nan")
     t_torch = timed(False, optimizers(torch.optim.Adam)) if not a.skip_torch else float("nan")
     print(json.dumps({
         "workload": "%d Gaussians, %dx%d, %d views per optimizer step: model(camera) + model.get_loss_dict(outputs, batch) "
                     "of the plugin's class (main / depth / normal / feature / up losses + regularisers) + backward, one "
                     "Adam step over 6 Gaussian groups + fea_up" % (a.points, w, h, a.views),
         "steps": a.steps, "views_per_step": a.views,
-        "fused_losses_and_adam": {"ms_per_step": round(1e3 * t_fused, 2), "views_per_s": round(a.views / t_fused, 1)},
+        "fused_losses_and_adam": {"ms_per_step": round(1e3 * t_fused, 2), "views_per_s": round(a.views / t_fused, 1),
+                                  "sampling": "gaussiangrasper_amd.sampling (device generator; GG_DEVICE_SAMPLING=1)"},
+        "fused_losses_and_adam_reference_sampling": {
+            "ms_per_step": round(1e3 * t_fused_r, 2), "views_per_s": round(a.views / t_fused_r, 1),
+            "sampling": "the reference's helpers (gaussian_splatting.py:120-148: nine host torch.randperm over a label's "
+                        "pixel count per view; the plugin's default — same draws as the reference)"},
         "torch_losses_and_adam": {"ms_per_step": round(1e3 * t_torch, 2), "views_per_s": round(a.views / t_torch, 1)},
         "note": "same HIP rasterizer and the same get_loss_dict in both; 'torch' = its loss namespace is plain torch (SSIM "
                 "main loss through grouped conv2d, boolean-index depth / normal losses, torch cosine losses, nn.Sequential "
-                "fea_up autograd) and the optimizers are seven torch.optim.Adam; bench.py's headline excludes the losses",
+                "fea_up autograd), its pixel samples come from the reference's helpers and the optimizers are seven "
+                "torch.optim.Adam; bench.py's headline excludes the losses",
     }))
 
 

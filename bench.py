@@ -95,6 +95,8 @@ def parse(argv=None):
                          "ends with reduced gradients, as the reference's DDP step would) or rs_ag = reduce-scatter, "
                          "fused Adam on this rank's shard, all-gather of the parameters (dist.ShardedAdamStep; the "
                          "timed step then INCLUDES the optimizer step)")
+    ap.add_argument("--pipe-priority", default="0,0",
+                    help="measurement: HIP stream priorities of the two view-pipeline streams (-1 = high)")
     ap.add_argument("--no-view-pipeline", action="store_true",
                     help="the views of a step strictly one after the other on one stream (default: backward of "
                          "view k beside forward of view k + 1 on two streams)")
@@ -480,7 +482,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
                                   adam_piece=torch_adam_piece if selftest else None)
     pipe_streams_box = [None]
     if torch.device(dev).type == "cuda" and not args.no_view_pipeline and not args.deterministic:
-        pipe_streams_box[0] = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        pipe_streams_box[0] = [torch.cuda.Stream(device=dev, priority=int(p)) for p in args.pipe_priority.split(",")]
 
     def one_step(fn):
         red = stepper is None

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgg_raster.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _P, _I, _F, _I64, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 
@@ -68,6 +68,7 @@ SIGNATURES = {
     "gg_blend_fwd_pair_fast": (_I, [_I, _I, _I, _I, _I] + [_P] * 14 + [_SZ, _P]),
     "gg_blend_bwd": (_I, [_I, _I, _I, _I] + [_P] * 14 + [_I, _I, _P, _SZ, _I, _P]),
     "gg_shade_tail_bwd_split": (_I, [_I, _P, _I, _P, _P, _P, _P, _P]),
+    "gg_view_bwd": (_I, [_I, _P, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gg_sh_bwd_multi": (_I, [_I, _I, _I, _I, C.POINTER(_P), C.POINTER(_P), _P, _I, _P]),
     "gg_image_loss_workspace": (_SZ, [_I, _I]),
     "gg_image_loss_fwd": (_I, [_I, _I, _P, _I, _P, _P, _F, _P, _P, _SZ, _P]),

@@ -1,23 +1,24 @@
 // binning.hip — tile binning and depth ordering.
 //
-// The reference builds I int64 keys (tile_id << 32 | depth bits), sorts them globally with
-// torch.sort (6+ radix passes over 12-byte pairs) and repeats that in each of its four rasterize
-// calls.  The per-tile lists it obtains are ordered by (tile, depth bits, Gaussian id).  This file
-// produces the SAME lists with far less HBM traffic by splitting the key:
+// The reference builds I int64 keys (tile_id << 32 | depth bits), sorts them globally with torch.sort (6+ radix
+// passes over 12-byte pairs) and repeats that in each of its four rasterize calls.  The per-tile lists it obtains are
+// ordered by (tile, depth bits, Gaussian id).  This file produces the SAME lists with far less HBM traffic by splitting
+// the key:
 //
-//   1. stable LSD radix sort of the N Gaussians by their 32 depth bits (4 byte-wide passes over
-//      N items; culled Gaussians get key 0xFFFFFFFF and sink to the end; the first pass forms the keys itself);
-//   2. exclusive scan of num_tiles_hit taken in that depth order (one launch, decoupled look-back);
+//   1. the N Gaussians are ordered by (depth bits, id) — round 4: by buckets of the depth range, one wave ordering each
+//      bucket (db_* below; 7 launches.  Rounds 1-3: a stable 4-pass LSD radix sort, 12 launches + 3 for the scan);
+//      culled Gaussians go behind the visible ones;
+//   2. the exclusive scan of num_tiles_hit in that order comes out of the same kernels (offset inside the bucket + the
+//      bucket's offset);
 //   3. every Gaussian, in depth order, emits (tile id, Gaussian id) for the tiles of its bbox;
-//   4. stable LSD radix sort of the I pairs by tile id only (ceil(log2 T)/8 = 2 passes).
+//   4. stable LSD radix sort of the I pairs by tile id only (two passes: 7 + 6 bits at 1600x1200).
 //
-// Stability of both sorts makes the result identical to the reference's global sort with ties
-// broken by ascending Gaussian id (the order SURVEY a7 fixes); tests compare it bit for bit with
-// the oracle's straightforward 64-bit sort.
+// Stability of the tile passes makes the result identical to the reference's global sort with ties broken by ascending
+// Gaussian id (the order SURVEY a7 fixes); tests compare it bit for bit with the oracle's straightforward 64-bit sort.
 //
-// Radix pass = 3 launches: per-block digit histogram -> per-digit column scan -> stable scatter.
-// Within the scatter a wave ranks its keys with ballot-based match-any (8 ballots per key), so
-// equal digits keep their input order without any LDS sorting network.
+// Radix pass = 3 launches: per-block digit histogram -> per-digit column scan -> stable scatter.  Within the scatter a
+// wave ranks its keys with ballot-based match-any (one ballot per digit bit), so equal digits keep their input order
+// without any LDS sorting network.
 #include "scan.h"
 
 // Device-side item count: the tile-sort kernels can take the number of intersections from device
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint32_t *__restrict__ G, const uint32_t *__restrict__ totals, DepthSrc dsrc) {
     constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
     n = dev_count(n, n_dev);
+    const int nbits = 32 - __builtin_clz(mask | 1u);   // ballots per key: the digit's bits (a 6-bit pass ranks with 6, not 8)
     __shared__ uint32_t whist[RS_WAVES][256];
     __shared__ uint32_t digit_base[256];
     __shared__ uint32_t wsum[4];
@@ -189,9 +191,11 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         uint64_t peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
-            bool bit = (d >> b) & 1u;
-            uint64_t m = __ballot(bit);
-            peers &= bit ? m : ~m;
+            if (b < nbits) {                              // (uniform)
+                bool bit = (d >> b) & 1u;
+                uint64_t m = __ballot(bit);
+                peers &= bit ? m : ~m;
+            }
         }
         uint32_t cnt = (uint32_t)__popcll(peers);
         uint32_t before = (uint32_t)__popcll(peers & lt_mask);
@@ -250,63 +254,461 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// exclusive scan of num_tiles_hit[order[r]]: block sums -> their scan -> offsets.  (r02-r03: ONE launch with a decoupled
-// look-back across workgroups; a look-back that gave up left every tile range empty and only gg_bin_sort_status, which
-// nothing called, said so — ADVICE r03.  Three plain launches have no wait that could give up; measured the same.)
-// ---------------------------------------------------------------------------------------------
-#define SC_THREADS 256
-#define SC_ITEMS 8
-#define SC_TILE (SC_THREADS * SC_ITEMS)
 
-__device__ __forceinline__ uint32_t scan_item(int N, const int32_t *__restrict__ nth, const uint32_t *__restrict__ order, int r) {
-    return (r < N) ? (uint32_t)nth[min(order[r], (uint32_t)(N - 1))] : 0u;   // (order: a permutation of 0..N-1)
+// ---------------------------------------------------------------------------------------------
+// Depth order of the Gaussians by buckets (round 4).  The stable 4-pass radix sort above is 12 launches of which every
+// one runs at launch latency (N = 1 M: 8-13 us each, 103 us of the 282 us binning of the bench view), and the offsets
+// scan behind it is three more (22 us).  Instead:
+//   db_range    min / max of the visible Gaussians' depth bits (256 partial pairs; every later kernel reduces them);
+//   db_count    bucket = floor((bits - min) NB / (max - min + 1)) — monotone in the bits, so ordering the buckets and
+//               then each bucket's members by (bits, id) IS the order by (bits, id); NB ~ N / 64; DB_BLOCKS workgroups
+//               count their contiguous share of the Gaussians per bucket in LDS -> G[block][bucket]; culled Gaussians
+//               (radius <= 0) go to one extra last bucket;
+//   db_prefix   G[block][bucket] -> the block's first position inside the bucket; bucket totals;
+//   db_starts   exclusive scan of the bucket totals (one workgroup) -> bucket starts; the visible count;
+//   db_scatter  the same walk as db_count; every Gaussian's (bits << 32 | id) goes to its bucket's run (position from
+//               an LDS cursor: the order inside a run is whatever the atomics gave);
+//   db_sort     ONE WAVE per bucket: a run of <= 256 entries (mean 64) is ordered by counting, for every word, the words
+//               below it (v_readlane broadcasts, no LDS, no dependent chain); up to 512 entries by stable LSD byte passes
+//               in LDS (depth bytes first, passes whose digit is constant skipped, the id bytes only if equal depths came
+//               out of order); then the wave writes the ids in order, each Gaussian's bucket, the
+//               exclusive scan of num_tiles_hit inside the bucket and the bucket's sum; longer runs (bit-identical depths
+//               en masse) go through a compare-exchange network in global memory first;
+//   db_offsets  exclusive scan of the bucket sums (one workgroup).
+// emit_kernel adds a Gaussian's in-bucket offset to its bucket's.  7 launches instead of 15; same order bit for bit
+// (tests/test_gpu_parity.py binning tests, incl. depth ties and runs beyond 512).
+// ---------------------------------------------------------------------------------------------
+typedef unsigned long long u64;
+#define DB_BLOCKS 64
+#define DB_THREADS 1024
+#define DB_CAP 512             // entries one wave sorts in LDS (8 per lane)
+#define DB_MAX_BUCKETS 32768   // LDS histogram of db_walk_kernel: 128 KB of the CU's 160
+static inline int db_buckets(int N) {
+    int nb = 256;
+    while (nb < DB_MAX_BUCKETS && nb * 64 < N) nb <<= 1;
+    return nb;
 }
-__global__ __launch_bounds__(SC_THREADS) void scan_blocksum_kernel(int N, const int32_t *__restrict__ nth,
-                                                                  const uint32_t *__restrict__ order,
-                                                                  uint32_t *__restrict__ bsum) {
-    __shared__ unsigned int wsum[4];
-    const int base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
-    uint32_t acc = 0;
+struct DbRange {
+    uint32_t kmin;
+    u64 mul;   // bucket = ((bits - kmin) * mul) >> 32
+};
+// (every workgroup reduces the 256 partial pairs itself: 2 KB from L2)
+__device__ __forceinline__ DbRange db_range_of(const uint32_t *__restrict__ mm, int nb, uint32_t *s_mm /*[2]*/) {
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+        for (int i = tid; i < 256; i += 64) {
+            lo = min(lo, mm[2 * i]);
+            hi = max(hi, mm[2 * i + 1]);
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
+            hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
+        }
+        if (tid == 0) { s_mm[0] = lo; s_mm[1] = hi; }
+    }
+    __syncthreads();
+    DbRange r;
+    const uint32_t lo = s_mm[0], hi = s_mm[1];
+    r.kmin = lo;
+    const u64 span = hi >= lo ? (u64)(hi - lo) + 1ull : 1ull;     // (nothing visible: every Gaussian is in the last bucket)
+    r.mul = (((u64)nb) << 32) / span;                              // (key - kmin) * mul < nb * 2^32
+    return r;
+}
+__device__ __forceinline__ uint32_t db_bucket(const DbRange r, uint32_t key, int nb) {
+    if (key == 0xFFFFFFFFu) return (uint32_t)nb;                   // culled
+    return min((uint32_t)(((u64)(key - r.kmin) * r.mul) >> 32), (uint32_t)(nb - 1));
+}
+__global__ __launch_bounds__(256) void db_range_kernel(int N, DepthSrc dsrc, uint32_t *__restrict__ mm) {
+    __shared__ uint32_t s_lo[4], s_hi[4];
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    const int stride = 256 * gridDim.x;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += 4 * stride) {      // four loads in flight per thread
+        uint32_t k[4];
 #pragma unroll
-    for (int k = 0; k < SC_ITEMS; ++k) acc += scan_item(N, nth, order, base + k);
-    unsigned int total;
-    (void)scan_block256(acc, wsum, total);
-    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+        for (int u = 0; u < 4; ++u) k[u] = (i + u * stride < N) ? depth_key(dsrc, i + u * stride) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k[u] != 0xFFFFFFFFu) { lo = min(lo, k[u]); hi = max(hi, k[u]); }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mm[2 * blockIdx.x] = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
+        mm[2 * blockIdx.x + 1] = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+    }
 }
-// one workgroup: exclusive scan of the block sums in place
-__global__ __launch_bounds__(256) void scan_bsum_kernel(int nblocks, uint32_t *__restrict__ bsum) {
-    __shared__ unsigned int wsum[4];
+// SCATTER false: G[block][bucket] = the block's count; true: G holds the block's first position in each bucket
+template <bool SCATTER>
+__global__ __launch_bounds__(DB_THREADS) void db_walk_kernel(int N, int nb, DepthSrc dsrc, const uint32_t *__restrict__ mm,
+                                                             uint32_t *__restrict__ G, const uint32_t *__restrict__ start,
+                                                             u64 *__restrict__ pairs) {
+    extern __shared__ uint32_t s_hist[];   // nb + 1 counters (SCATTER: cursors), then the range
+    uint32_t *s_mm = s_hist + nb + 1;
+    const DbRange r = db_range_of(mm, nb, s_mm);
+    const int per = (N + DB_BLOCKS - 1) / DB_BLOCKS;
+    const int lo = blockIdx.x * per, hi = min(N, lo + per);
+    uint32_t *row = G + (size_t)blockIdx.x * (nb + 1);
+    for (int b = threadIdx.x; b <= nb; b += DB_THREADS) s_hist[b] = SCATTER ? start[b] + row[b] : 0u;
+    __syncthreads();
+    for (int i = lo + threadIdx.x; i < hi; i += 4 * DB_THREADS) {                 // four loads in flight per thread
+        uint32_t k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k[u] = (i + u * DB_THREADS < hi) ? depth_key(dsrc, i + u * DB_THREADS) : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i + u * DB_THREADS < hi) {
+                const uint32_t pos = atomicAdd(&s_hist[db_bucket(r, k[u], nb)], 1u);
+                if (SCATTER && k[u] != 0xFFFFFFFFu)                            // (nothing reads the culled run)
+                    pairs[pos] = ((u64)k[u] << 32) | (uint32_t)(i + u * DB_THREADS);
+            }
+        }
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (int b = threadIdx.x; b <= nb; b += DB_THREADS) row[b] = s_hist[b];
+    }
+}
+// one thread per bucket: counts of the blocks -> exclusive over the blocks, in place; the bucket's total
+__global__ __launch_bounds__(256) void db_prefix_kernel(int nb, uint32_t *__restrict__ G, uint32_t *__restrict__ total) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b > nb) return;
+    uint32_t run = 0;
+    uint32_t c[DB_BLOCKS];
+#pragma unroll
+    for (int k = 0; k < DB_BLOCKS; ++k) c[k] = G[(size_t)k * (nb + 1) + b];     // (all in flight)
+#pragma unroll
+    for (int k = 0; k < DB_BLOCKS; ++k) {
+        G[(size_t)k * (nb + 1) + b] = run;
+        run += c[k];
+    }
+    total[b] = run;
+}
+// one workgroup: v[0 .. n) -> exclusive scan in place, v[n] = total (n <= DB_MAX_BUCKETS + 1)
+__global__ __launch_bounds__(1024) void db_scan_kernel(int n, uint32_t *__restrict__ v) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0u;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024 * 4) {
+        const int i0 = base + 4 * tid;
+        uint32_t x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = i0 + k < n ? v[i0 + k] : 0u;
+        const uint32_t mine = x[0] + x[1] + x[2] + x[3];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        uint32_t ex = s_carry + incl - mine, all = 0u;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t t = s_w[w];
+            if (w < wave) ex += t;
+            all += t;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k < n) v[i0 + k] = ex;
+            ex += x[k];
+        }
+        __syncthreads();
+        if (tid == 0) s_carry += all;
+        __syncthreads();
+    }
+    if (tid == 0) v[n] = s_carry;
+}
+
+// compare-exchange network over u64 keys in global memory by ONE WAVE (its own stores are visible to its later loads behind
+// a workgroup-scope fence: one CU, one L1).  Every exchange puts the smaller key at the lower index (the "flip" form: the
+// first step of a merge of size k compares i with k - 1 - i), so keys at indices >= n can be VIRTUAL +inf: nothing is ever
+// stored there — no padding, any n.  Blocks of 8 consecutive keys are handled in registers.
+__device__ __forceinline__ void db_ce(u64 &a, u64 &b) {
+    const bool sw = b < a;
+    const u64 lo = sw ? b : a, hi = sw ? a : b;
+    a = lo;
+    b = hi;
+}
+__device__ __forceinline__ void db_bitonic64(u64 *buf, const int n) {
+    constexpr int NB = 8, LNB = 3, THREADS = 64;
+    const int tid = threadIdx.x & 63;
+    int P = NB;
+    while (P < n) P <<= 1;
+    const u64 INF = ~0ull;
+    for (int blk = tid; blk * NB < n; blk += THREADS) {   // every aligned block of NB keys: sorted
+        u64 v[NB];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) v[r] = (NB * blk + r < n) ? buf[NB * blk + r] : INF;
+#pragma unroll
+        for (int k = 2; k <= NB; k <<= 1) {
+#pragma unroll
+            for (int i = 0; i < NB / 2; ++i) {
+                const int b2 = i / (k / 2), off = i % (k / 2);
+                db_ce(v[b2 * k + off], v[b2 * k + k - 1 - off]);
+            }
+#pragma unroll
+            for (int j = k >> 2; j >= 1; j >>= 1)
+#pragma unroll
+                for (int i = 0; i < NB / 2; ++i) {
+                    const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                    db_ce(v[lo], v[lo + j]);
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < NB; ++r)
+            if (NB * blk + r < n) buf[NB * blk + r] = v[r];
+    }
+    { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+    for (int k = 2 * NB, lk = LNB + 1; k <= P; k <<= 1, ++lk) {
+        const int hk = k >> 1;
+        for (int i = tid; i < (P >> 1); i += THREADS) {   // flip: i-th key of a block's lower half with its mirror
+            const int blk = i >> (lk - 1), off = i & (hk - 1);
+            const int lo = blk * k + off, hi = blk * k + k - 1 - off;
+            if (hi < n) {
+                const u64 a = buf[lo], b = buf[hi];
+                if (b < a) { buf[lo] = b; buf[hi] = a; }
+            }
+        }
+        { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+        for (int j = k >> 2; j >= NB; j >>= 1) {
+            for (int i = tid; i < (P >> 1); i += THREADS) {
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo + j;
+                if (hi < n) {
+                    const u64 a = buf[lo], b = buf[hi];
+                    if (b < a) { buf[lo] = b; buf[hi] = a; }
+                }
+            }
+            { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+        }
+        for (int blk = tid; blk * NB < n; blk += THREADS) {   // strides NB / 2 .. 1
+            u64 v[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) v[r] = (NB * blk + r < n) ? buf[NB * blk + r] : INF;
+#pragma unroll
+            for (int j = NB >> 1; j >= 1; j >>= 1)
+#pragma unroll
+                for (int i = 0; i < NB / 2; ++i) {
+                    const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                    db_ce(v[lo], v[lo + j]);
+                }
+#pragma unroll
+            for (int r = 0; r < NB; ++r)
+                if (NB * blk + r < n) buf[NB * blk + r] = v[r];
+        }
+        { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+    }
+}
+
+// one WAVE per bucket, four buckets per workgroup; the waves never synchronise with each other
+#define DB_ITEMS (DB_CAP / 64)
+#define DB_RANK_CAP 256        // runs up to this length are ordered by counting, for every key, the keys below it
+#define DB_WPB 4
+__device__ __forceinline__ void db_wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+__global__ __launch_bounds__(64 * DB_WPB) void db_sort_kernel(int N, int nb, const uint32_t *__restrict__ start,
+                                                              u64 *__restrict__ pairs, const int32_t *__restrict__ nth,
+                                                              uint32_t *__restrict__ order, uint32_t *__restrict__ bucket_of,
+                                                              uint32_t *__restrict__ off_in, uint32_t *__restrict__ bucket_sum) {
+    __shared__ u64 s_buf[DB_WPB][DB_CAP];
+    __shared__ uint32_t s_hist[DB_WPB][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * DB_WPB + wave;
+    if (b >= nb) return;          // (bucket nb holds the culled Gaussians: they emit nothing and nothing reads their order)
+    u64 *buf = s_buf[wave];
+    uint32_t *hist = s_hist[wave];
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int s0 = (int)start[b], n = (int)start[b + 1] - s0;
+    if (n <= 0) {
+        if (lane == 0) bucket_sum[b] = 0u;
+        return;
+    }
+    uint32_t gid[DB_ITEMS];       // the ids of positions 64 r + lane of the sorted run (runs <= DB_CAP)
+    if (n <= DB_RANK_CAP) {
+        // every key's place = the number of keys below it (the words are distinct: they end in the id).  Key j comes to all
+        // lanes by v_readlane, no LDS, no dependent chain: ~n^2 / 64 compare-and-add per lane (mean run: 128 entries)
+        constexpr int RS = DB_RANK_CAP / 64;
+        u64 key[RS];
+        uint32_t rank[RS];
+#pragma unroll
+        for (int t = 0; t < RS; ++t) {
+            key[t] = (64 * t + lane < n) ? pairs[s0 + 64 * t + lane] : ~0ull;
+            rank[t] = 0u;
+        }
+        const int nslots = (n + 63) >> 6;
+#pragma unroll
+        for (int sl = 0; sl < RS; ++sl) {
+            if (sl < nslots) {                                           // (wave-uniform)
+                const uint32_t lo = (uint32_t)key[sl], hi = (uint32_t)(key[sl] >> 32);
+                const int cnt = min(64, n - 64 * sl);
+                for (int l = 0; l < cnt; ++l) {
+                    const u64 kj = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)hi, l) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readlane((int)lo, l);
+#pragma unroll
+                    for (int t = 0; t < RS; ++t)
+                        if (t < nslots) rank[t] += (kj < key[t]) ? 1u : 0u;
+                }
+            }
+        }
+        uint32_t *ids = reinterpret_cast<uint32_t *>(buf);
+#pragma unroll
+        for (int t = 0; t < RS; ++t)
+            if (64 * t + lane < n) ids[rank[t]] = (uint32_t)key[t];
+        db_wsync();
+#pragma unroll
+        for (int r = 0; r < DB_ITEMS; ++r) gid[r] = (r < RS && 64 * r + lane < n) ? ids[64 * r + lane] : 0u;
+    } else if (n <= DB_CAP) {
+        // stable LSD byte passes in LDS (round 4's per-tile sort, profiles/r04_counting_sort_binning_experiment.patch)
+        // (validity of a slot is recomputed from a laundered n - lane wherever it is needed: as loop invariants the lane
+        //  masks of `64 r + lane < n` took 2 SGPRs each for the whole kernel)
+#define DB_LIM(nv) int nv = n - lane; asm volatile("" : "+v"(nv))
+        u64 key[DB_ITEMS];
+        {
+            DB_LIM(nv);
+#pragma unroll
+            for (int r = 0; r < DB_ITEMS; ++r) key[r] = (64 * r < nv) ? pairs[s0 + 64 * r + lane] : ~0ull;
+        }
+        // one stable pass on bits [shift, shift + 8); nothing moves if the digit is the same for every key
+        auto pass = [&](const int shift) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hist[lane + 64 * k] = 0u;
+            db_wsync();
+            {
+                DB_LIM(nv);
+#pragma unroll
+                for (int r = 0; r < DB_ITEMS; ++r)
+                    if (64 * r < nv) atomicAdd(&hist[(uint32_t)(key[r] >> shift) & 255u], 1u);
+            }
+            db_wsync();
+            // digits [4 lane, 4 lane + 4): totals -> exclusive starts
+            uint32_t tot[4], mine = 0;
+            bool constant = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                tot[k] = hist[4 * lane + k];
+                constant = constant || tot[k] == (uint32_t)n;
+                mine += tot[k];
+            }
+            if (__ballot(constant) != 0ull) {
+                db_wsync();
+                return;
+            }
+            uint32_t incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t u = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += u;
+            }
+            uint32_t ex = incl - mine;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                hist[4 * lane + k] = ex;
+                ex += tot[k];
+            }
+            db_wsync();
+            volatile uint32_t *wh = hist;
+            DB_LIM(nv_s);
+#pragma unroll
+            for (int r = 0; r < DB_ITEMS; ++r) {
+                if (64 * r < n) {                                          // (wave-uniform)
+                    const bool valid = 64 * r < nv_s;
+                    const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+                    uint64_t peers = __ballot(valid);
+#pragma unroll
+                    for (int bit = 0; bit < 8; ++bit) {
+                        const bool on = (d >> bit) & 1u;
+                        const uint64_t m = __ballot(on);
+                        peers &= on ? m : ~m;
+                    }
+                    const uint32_t cnt = (uint32_t)__popcll(peers);
+                    const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
+                    if (valid && before == 0) wh[d] = wh[d] + cnt;       // the group's first lane moves the digit's cursor
+                    db_wsync();
+                    if (valid) buf[wh[d] - cnt + before] = key[r];
+                    db_wsync();
+                    __builtin_amdgcn_sched_barrier(0);   // (or the ballots of all rounds are formed up front: 270 SGPRs)
+                }
+            }
+            {
+                DB_LIM(nv);
+#pragma unroll
+                for (int r = 0; r < DB_ITEMS; ++r) key[r] = (64 * r < nv) ? buf[64 * r + lane] : ~0ull;
+            }
+            db_wsync();
+        };
+        // byte p of the word: 0..3 the id, 4..7 the depth bits.  The depth bytes first; a second round with the id bytes in
+        // front only if that left equal depths out of order.  (ONE copy of the pass body: runtime loops.)
+#pragma nounroll
+        for (int round = 0; round < 2; ++round) {
+#pragma nounroll
+            for (int pb = round == 0 ? 4 : 0; pb < 8; ++pb) pass(8 * pb);
+            if (round == 1) break;
+            {
+                DB_LIM(nv);
+#pragma unroll
+                for (int r = 0; r < DB_ITEMS; ++r)
+                    if (64 * r < nv) buf[64 * r + lane] = key[r];
+            }
+            db_wsync();
+            bool bad = false;
+            {
+                DB_LIM(nv);
+#pragma unroll
+                for (int r = 0; r < DB_ITEMS; ++r)
+                    if (64 * r + 1 < nv) {
+                        const u64 nx = buf[64 * r + lane + 1];
+                        bad = bad || ((uint32_t)(nx >> 32) == (uint32_t)(key[r] >> 32) && (uint32_t)nx < (uint32_t)key[r]);
+                    }
+            }
+            db_wsync();
+            if (__ballot(bad) == 0ull) break;
+        }
+#undef DB_LIM
+#pragma unroll
+        for (int r = 0; r < DB_ITEMS; ++r) gid[r] = (uint32_t)key[r];
+    } else {
+        db_bitonic64(pairs + s0, n);     // (rare: more than 512 Gaussians in 1 / nb of the depth range)
+    }
+    // output: ids in order, the bucket of every position, the exclusive scan of num_tiles_hit inside the bucket
     uint32_t carry = 0;
-    for (int start = 0; start < nblocks; start += 256) {
-        const int i = start + threadIdx.x;
-        const uint32_t v = i < nblocks ? bsum[i] : 0u;
-        unsigned int total;
-        const uint32_t ex = scan_block256(v, wsum, total);
-        if (i < nblocks) bsum[i] = carry + ex;
-        carry += total;
-    }
-}
-__global__ __launch_bounds__(SC_THREADS) void scan_offsets_kernel(
-    int N, const int32_t *__restrict__ nth, const uint32_t *__restrict__ order,
-    uint32_t *__restrict__ offsets, const uint32_t *__restrict__ bsum) {
-    __shared__ unsigned int wsum[4];
-    const int base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
-    uint32_t v[SC_ITEMS];
-    uint32_t acc = 0;
+    for (int c0 = 0; c0 < n; c0 += DB_CAP) {
+        if (n > DB_CAP) {
 #pragma unroll
-    for (int k = 0; k < SC_ITEMS; ++k) {
-        v[k] = scan_item(N, nth, order, base + k);
-        acc += v[k];
-    }
-    unsigned int total;
-    uint32_t ex = scan_block256(acc, wsum, total) + bsum[blockIdx.x];
+            for (int r = 0; r < DB_ITEMS; ++r) gid[r] = (c0 + 64 * r + lane < n) ? (uint32_t)pairs[s0 + c0 + 64 * r + lane] : 0u;
+        }
 #pragma unroll
-    for (int k = 0; k < SC_ITEMS; ++k) {
-        const int r = base + k;
-        if (r < N) offsets[r] = ex;
-        ex += v[k];
+        for (int r = 0; r < DB_ITEMS; ++r) {
+            const int p = c0 + 64 * r + lane;
+            if (c0 + 64 * r < n) {                                        // (wave-uniform)
+                const bool valid = p < n;
+                const uint32_t g = min(gid[r], (uint32_t)(N - 1));
+                const uint32_t c = valid ? (uint32_t)nth[g] : 0u;
+                uint32_t incl = c;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t u = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += u;
+                }
+                if (valid) {
+                    order[s0 + p] = g;
+                    bucket_of[s0 + p] = (uint32_t)b;
+                    off_in[s0 + p] = carry + incl - c;
+                }
+                carry += __shfl(incl, 63, 64);
+            }
+        }
     }
+    if (lane == 0) bucket_sum[b] = carry;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -318,8 +720,13 @@ __global__ __launch_bounds__(SC_THREADS) void scan_offsets_kernel(
 // lane j of an iteration finds its source Gaussian by binary search over the 64 start offsets — so
 // every store instruction writes 64 consecutive entries.  (The first version looped per Gaussian over
 // its own tiles: 64 short runs per instruction and as many iterations as the largest box of the wave.)
+// offsets[r]: the Gaussian's offset inside its bucket; bucket_of[r] / bucket_base: its bucket and that bucket's offset
+// (db_sort_kernel / db_scan_kernel); only the first *visible positions of the order carry them
 __global__ __launch_bounds__(256) void emit_kernel(int N, const uint32_t *__restrict__ order,
                                                    const uint32_t *__restrict__ offsets,
+                                                   const uint32_t *__restrict__ bucket_of,
+                                                   const uint32_t *__restrict__ bucket_base,
+                                                   const uint32_t *__restrict__ visible,
                                                    const float *__restrict__ xys,
                                                    const int32_t *__restrict__ radii, int tiles_x,
                                                    int tiles_y, int64_t I,
@@ -333,9 +740,9 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, const uint32_t *__rest
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t g = 0, cnt = 0, off = 0;
     int x0 = 0, y0 = 0, bw = 1;
-    if (r < N) {
+    if (r < N && (uint32_t)r < *visible) {
         g = min(order[r], (uint32_t)(N - 1));
-        off = offsets[r];
+        off = offsets[r] + bucket_base[bucket_of[r]];
         const int rad = radii[g];
         if (rad > 0) {
             int x1, y1;
@@ -408,12 +815,18 @@ static int radix_nblocks(int64_t n) {
 }
 
 struct BinWs {
-    uint32_t *dkeyA, *dkeyB, *dvalA, *dvalB;  // N each
-    uint32_t *offsets;                        // N
-    uint32_t *block_sums;                     // scan
+    uint32_t *order;                          // N: Gaussian ids in depth order (the visible ones first)
+    uint32_t *offsets;                        // N: offset of a Gaussian's entries inside its bucket
     uint32_t *G;                              // 256 * max nblocks
     uint32_t *totals;                         // 256
     uint32_t *tkeyA, *tkeyB, *tvalTmp;        // I each
+    // depth order by buckets (db_*)
+    u64 *pairs;                               // N: (depth bits << 32 | id), grouped by bucket
+    uint32_t *bucket_of;                      // N
+    uint32_t *dbG;                            // DB_BLOCKS x (buckets + 1)
+    uint32_t *dbStart;                        // buckets + 2: bucket totals -> starts; [buckets] = visible count, [buckets + 1] = N
+    uint32_t *dbBase;                         // buckets + 1: bucket sums of num_tiles_hit -> offsets
+    uint32_t *dbmm;                           // 2 x 256: partial min / max of the depth bits
     size_t bytes;
 };
 static BinWs bin_ws_layout(void *ws, int N, int64_t I) {
@@ -425,18 +838,21 @@ static BinWs bin_ws_layout(void *ws, int N, int64_t I) {
         return (uint32_t *)p;
     };
     size_t n = (size_t)(N > 0 ? N : 1), i = (size_t)(I > 0 ? I : 1);
-    w.dkeyA = take(4 * n);
-    w.dkeyB = take(4 * n);
-    w.dvalA = take(4 * n);
-    w.dvalB = take(4 * n);
+    w.order = take(4 * n);
     w.offsets = take(4 * n);
-    w.block_sums = take(4 * ((n + SC_TILE - 1) / SC_TILE));   // block sums of the offsets scan
     int nb = max(radix_nblocks(N), radix_nblocks(I));
     w.G = take(4 * 256 * (size_t)(nb + 1));
     w.totals = take(4 * 256);
     w.tkeyA = take(4 * i);
     w.tkeyB = take(4 * i);
     w.tvalTmp = take(4 * i);
+    const size_t nbk = (size_t)db_buckets(N);
+    w.pairs = (u64 *)take(8 * n);
+    w.bucket_of = take(4 * n);
+    w.dbG = take(4 * DB_BLOCKS * (nbk + 1));
+    w.dbStart = take(4 * (nbk + 2));
+    w.dbBase = take(4 * (nbk + 1));
+    w.dbmm = take(4 * 2 * 256);
     w.bytes = off;
     return w;
 }
@@ -485,21 +901,25 @@ static int bin_sort_impl(int N, int64_t I, const int64_t *I_dev, const float *xy
         return GG_ERR_WORKSPACE;
     }
     gg_prof_begin(GG_K_BIN_SORT, s);
-    // 1. depth order of the Gaussians
-    uint32_t *ka = w.dkeyA, *kb = w.dkeyB, *va = w.dvalA, *vb = w.dvalB;
-    for (int pass = 0; pass < 4; ++pass) {
-        radix_pass(N, nullptr, ka, va, kb, vb, 8 * pass, 0xFFu, w, s,
-                   pass == 0 ? DepthSrc{depths, radii} : DepthSrc{nullptr, nullptr});
-        uint32_t *t = ka; ka = kb; kb = t;
-        t = va; va = vb; vb = t;
+    // 1. depth order of the Gaussians, 2. their offsets in that order: by buckets (db_* above)
+    const int nbk = db_buckets(N);
+    const DepthSrc dsrc{depths, radii};
+    const size_t walk_lds = sizeof(uint32_t) * ((size_t)nbk + 1 + 2);
+    if (walk_lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void *)db_walk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds);
+        (void)hipFuncSetAttribute((const void *)db_walk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds);
     }
-    const uint32_t *order = va;
-    // 2. offsets in depth order
-    int nsb = (N + SC_TILE - 1) / SC_TILE;
-    hipLaunchKernelGGL(scan_blocksum_kernel, dim3(nsb), dim3(SC_THREADS), 0, s, N, num_tiles_hit, order, w.block_sums);
-    hipLaunchKernelGGL(scan_bsum_kernel, dim3(1), dim3(256), 0, s, nsb, w.block_sums);
-    hipLaunchKernelGGL(scan_offsets_kernel, dim3(nsb), dim3(SC_THREADS), 0, s, N, num_tiles_hit, order,
-                       w.offsets, w.block_sums);
+    uint32_t *order = w.order;
+    hipLaunchKernelGGL(db_range_kernel, dim3(256), dim3(256), 0, s, N, dsrc, w.dbmm);
+    hipLaunchKernelGGL(db_walk_kernel<false>, dim3(DB_BLOCKS), dim3(DB_THREADS), walk_lds, s, N, nbk, dsrc, w.dbmm, w.dbG,
+                       (const uint32_t *)nullptr, (u64 *)nullptr);
+    hipLaunchKernelGGL(db_prefix_kernel, dim3((nbk + 1 + 255) / 256), dim3(256), 0, s, nbk, w.dbG, w.dbStart);
+    hipLaunchKernelGGL(db_scan_kernel, dim3(1), dim3(1024), 0, s, nbk + 1, w.dbStart);
+    hipLaunchKernelGGL(db_walk_kernel<true>, dim3(DB_BLOCKS), dim3(DB_THREADS), walk_lds, s, N, nbk, dsrc, w.dbmm, w.dbG,
+                       (const uint32_t *)w.dbStart, w.pairs);
+    hipLaunchKernelGGL(db_sort_kernel, dim3((nbk + DB_WPB - 1) / DB_WPB), dim3(64 * DB_WPB), 0, s, N, nbk, (const uint32_t *)w.dbStart, w.pairs,
+                       num_tiles_hit, order, w.bucket_of, w.offsets, w.dbBase);
+    hipLaunchKernelGGL(db_scan_kernel, dim3(1), dim3(1024), 0, s, nbk, w.dbBase);
     // 3./4. emit + sort by tile id; ping-pong so the last pass lands in gaussian_ids_sorted
     int tile_bits = 1;
     while ((1 << tile_bits) < T) ++tile_bits;
@@ -515,11 +935,15 @@ static int bin_sort_impl(int N, int64_t I, const int64_t *I_dev, const float *xy
         (void)gg_fill_async(kcur, 0xFF, sizeof(uint32_t) * (size_t)I, s);
         (void)gg_fill_async(vcur, 0, sizeof(uint32_t) * (size_t)I, s);
     }
-    hipLaunchKernelGGL(emit_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, order, w.offsets,
-                       xys, radii, tiles_x, tiles_y, I, I_dev, kcur, vcur);
+    hipLaunchKernelGGL(emit_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, (const uint32_t *)order,
+                       (const uint32_t *)w.offsets, (const uint32_t *)w.bucket_of, (const uint32_t *)w.dbBase,
+                       (const uint32_t *)(w.dbStart + nbk), xys, radii, tiles_x, tiles_y, I, I_dev, kcur, vcur);
+    // the tile id's bits are split evenly over the passes (13 bits: 7 + 6, not 8 + 5): a pass ranks its keys with one
+    // ballot per digit bit, and the scatter kernels are bound by that ranking
+    const int per_pass = (tile_bits + passes - 1) / passes;
     for (int pass = 0; pass < passes; ++pass) {
-        int bits = min(8, tile_bits - 8 * pass);
-        radix_pass(I, I_dev, kcur, vcur, kalt, valt, 8 * pass, (1u << bits) - 1u, w, s);
+        int bits = min(per_pass, tile_bits - per_pass * pass);
+        radix_pass(I, I_dev, kcur, vcur, kalt, valt, per_pass * pass, (1u << bits) - 1u, w, s);
         uint32_t *t = kcur; kcur = kalt; kalt = t;
         t = vcur; vcur = valt; valt = t;
     }

@@ -20,7 +20,7 @@ void gg_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 extern "C" const char *gg_last_error(void) { return g_err; }
-extern "C" int gg_abi_version(void) { return 3; }
+extern "C" int gg_abi_version(void) { return 4; }
 
 __device__ __forceinline__ void quat_to_R(const float4 q, float *R, float *qn, float &inv) {
     float nn = ((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w;  // (w,x,y,z) stored in .x.y.z.w
@@ -147,20 +147,15 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     num_tiles_hit[i] = o_n;
 }
 
-__global__ __launch_bounds__(256) void project_bwd_kernel(
-    int N, const float *__restrict__ means, const float *__restrict__ scales, float glob_scale,
-    const float *__restrict__ quats, const float *__restrict__ viewmat,
-    const float *__restrict__ projmat, float fx, float fy, int img_h, int img_w,
-    const int32_t *__restrict__ radii, const float *__restrict__ conics,
-    const float *__restrict__ v_xy, const float *__restrict__ v_depth,
-    const float *__restrict__ v_conic, float *__restrict__ v_mean3d, float *__restrict__ v_scale,
-    float *__restrict__ v_quat, int xy_stride = 2, int conic_stride = 3, int acc_means = 0) {
-    // xy_stride / conic_stride: floats between the rows of v_xy / v_conic (gg_project_bwd_ex: the blend backward's
-    // interleaved gradient record is read in place); acc_means: v_mean3d += (a registered gradient buffer)
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    float vm[3] = {0, 0, 0}, vs[3] = {0, 0, 0}, vq4[4] = {0, 0, 0, 0};
-    if (radii[i] > 0) {
+// the backward of one visible Gaussian: cotangents (v_xy, v_depth, v_conic) -> vm += d/d mean, vs = d/d scale,
+// vq4 = d/d quat.  Shared by project_bwd_kernel and view_bwd_kernel (one operation sequence, one result)
+__device__ __forceinline__ void project_bwd_point(
+    const int i, const float *__restrict__ means, const float *__restrict__ scales, const float glob_scale,
+    const float *__restrict__ quats, const float *__restrict__ viewmat, const float *__restrict__ projmat,
+    const float fx, const float fy, const int img_h, const int img_w, const float *__restrict__ conics,
+    const float vxy0, const float vxy1, const float vdepth, const float ga, const float gb, const float gc,
+    float (&vm)[3], float (&vs)[3], float (&vq4)[4]) {
+    {
         float V[12], P[16];
 #pragma unroll
         for (int k = 0; k < 12; ++k) V[k] = viewmat[k];
@@ -173,8 +168,8 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
         float hy = ((P[4] * px + P[5] * py) + P[6] * pz) + P[7];
         float hw = ((P[12] * px + P[13] * py) + P[14] * pz) + P[15];
         float rw = 1.0f / (hw + GG_W_EPS);
-        float vnx = (0.5f * (float)img_w) * v_xy[(size_t)xy_stride * i];
-        float vny = (0.5f * (float)img_h) * v_xy[(size_t)xy_stride * i + 1];
+        float vnx = (0.5f * (float)img_w) * vxy0;
+        float vny = (0.5f * (float)img_h) * vxy1;
         float vhx = vnx * rw, vhy = vny * rw;
 #if GG_VJP_GSPLAT_COMPAT
         float vhw = 0.0f * hx * hy;   // compat: the homogeneous-w path is dropped
@@ -184,13 +179,11 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
 #pragma unroll
         for (int j = 0; j < 3; ++j) vm[j] += (P[j] * vhx + P[4 + j] * vhy) + P[12 + j] * vhw;
         // (2) depth
-        float vz = v_depth[i];
+        float vz = vdepth;
 #pragma unroll
         for (int j = 0; j < 3; ++j) vm[j] += V[8 + j] * vz;
         // (3) conic -> cov2d
         float ca = conics[3 * i], cb = conics[3 * i + 1], cc = conics[3 * i + 2];
-        const float *vcn = v_conic + (size_t)conic_stride * i;
-        float ga = vcn[0], gb = vcn[1], gc = vcn[2];
         float xg00 = ca * ga + cb * gb, xg01 = ca * gb + cb * gc;
         float xg10 = cb * ga + cc * gb, xg11 = cb * gb + cc * gc;
         float s00 = -(xg00 * ca + xg01 * cb), s01 = -(xg00 * cb + xg01 * cc);
@@ -300,6 +293,26 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
 #else
         for (int k = 0; k < 4; ++k) vq4[k] = (vq[k] - qn[k] * dotp) * inv_norm;
 #endif
+    }
+}
+__global__ __launch_bounds__(256) void project_bwd_kernel(
+    int N, const float *__restrict__ means, const float *__restrict__ scales, float glob_scale,
+    const float *__restrict__ quats, const float *__restrict__ viewmat,
+    const float *__restrict__ projmat, float fx, float fy, int img_h, int img_w,
+    const int32_t *__restrict__ radii, const float *__restrict__ conics,
+    const float *__restrict__ v_xy, const float *__restrict__ v_depth,
+    const float *__restrict__ v_conic, float *__restrict__ v_mean3d, float *__restrict__ v_scale,
+    float *__restrict__ v_quat, int xy_stride = 2, int conic_stride = 3, int acc_means = 0) {
+    // xy_stride / conic_stride: floats between the rows of v_xy / v_conic (gg_project_bwd_ex: the blend backward's
+    // interleaved gradient record is read in place); acc_means: v_mean3d += (a registered gradient buffer)
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float vm[3] = {0, 0, 0}, vs[3] = {0, 0, 0}, vq4[4] = {0, 0, 0, 0};
+    if (radii[i] > 0) {
+        const float *vcn = v_conic + (size_t)conic_stride * i;
+        project_bwd_point(i, means, scales, glob_scale, quats, viewmat, projmat, fx, fy, img_h, img_w, conics,
+                          v_xy[(size_t)xy_stride * i], v_xy[(size_t)xy_stride * i + 1], v_depth[i], vcn[0], vcn[1], vcn[2],
+                          vm, vs, vq4);
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -902,38 +915,23 @@ __global__ __launch_bounds__(256) void activate_fwd_kernel(
     }
 }
 
-__global__ __launch_bounds__(256) void activate_bwd_kernel(
-    int N, const float4 *__restrict__ quats, const float *__restrict__ scales, const float *__restrict__ opac,
-    const int32_t *__restrict__ axis, const float *__restrict__ v_scales, const float4 *__restrict__ v_quats_n,
-    const float *__restrict__ v_opac, const float *__restrict__ v_normals, float *__restrict__ v_log_scales,
-    float4 *__restrict__ v_quats, float *__restrict__ v_opacities, int opac_stride = 1, int acc = 0) {
-    // opac_stride: floats between the entries of v_opac (read in place from the blend backward's record);
-    // acc: the three outputs are added to (registered gradient buffers) instead of written
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+// the backward of one Gaussian's activations: (v_scales, v_quats_n, v_opac, v_normals) -> gradients of the log
+// scales, the raw quaternion and the opacity logit.  Shared by activate_bwd_kernel and view_bwd_kernel.
+__device__ __forceinline__ void activate_bwd_point(const float4 q, const float (&sc)[3], const float s, const int ax,
+                                                   const float (&vsc)[3], const float4 g, const float vop,
+                                                   const float n0, const float n1, const float n2, float (&g_ls)[3],
+                                                   float &g_op, float4 &out) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float g = v_scales[3 * (size_t)i + k] * scales[3 * (size_t)i + k];
-        v_log_scales[3 * (size_t)i + k] = acc ? v_log_scales[3 * (size_t)i + k] + g : g;
-    }
-    const float s = opac[i];
-    {
-        const float g = v_opac[(size_t)i * opac_stride] * (s * (1.0f - s));
-        v_opacities[i] = acc ? v_opacities[i] + g : g;
-    }
+    for (int k = 0; k < 3; ++k) g_ls[k] = vsc[k] * sc[k];
+    g_op = vop * (s * (1.0f - s));
     // q / |q|
-    const float4 q = quats[i];
     const float n = sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
     const float4 qh = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
-    const float4 g = v_quats_n[i];
     const float dot = ((qh.x * g.x + qh.y * g.y) + qh.z * g.z) + qh.w * g.w;
-    float4 out = make_float4((g.x - qh.x * dot) / n, (g.y - qh.y * dot) / n, (g.z - qh.z * dot) / n,
-                             (g.w - qh.w * dot) / n);
+    out = make_float4((g.x - qh.x * dot) / n, (g.y - qh.y * dot) / n, (g.z - qh.z * dot) / n, (g.w - qh.w * dot) / n);
     // the normal: one column of R(q / max(|q|, eps))
     float w, x, y, z;
     const float d = quat_normalise(q, w, x, y, z);
-    const int ax = axis[i];
-    const float n0 = v_normals[3 * (size_t)i], n1 = v_normals[3 * (size_t)i + 1], n2 = v_normals[3 * (size_t)i + 2];
     float G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // v_R: only column `ax`
     G[ax] = n0;
     G[3 + ax] = n1;
@@ -954,11 +952,102 @@ __global__ __launch_bounds__(256) void activate_bwd_kernel(
         out.z += vy / d;
         out.w += vz / d;
     }
+}
+__global__ __launch_bounds__(256) void activate_bwd_kernel(
+    int N, const float4 *__restrict__ quats, const float *__restrict__ scales, const float *__restrict__ opac,
+    const int32_t *__restrict__ axis, const float *__restrict__ v_scales, const float4 *__restrict__ v_quats_n,
+    const float *__restrict__ v_opac, const float *__restrict__ v_normals, float *__restrict__ v_log_scales,
+    float4 *__restrict__ v_quats, float *__restrict__ v_opacities, int opac_stride = 1, int acc = 0) {
+    // opac_stride: floats between the entries of v_opac (read in place from the blend backward's record);
+    // acc: the three outputs are added to (registered gradient buffers) instead of written
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float sc[3] = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
+    const float vsc[3] = {v_scales[3 * (size_t)i], v_scales[3 * (size_t)i + 1], v_scales[3 * (size_t)i + 2]};
+    float g_ls[3], g_op;
+    float4 out;
+    activate_bwd_point(quats[i], sc, opac[i], axis[i], vsc, v_quats_n[i], v_opac[(size_t)i * opac_stride],
+                       v_normals[3 * (size_t)i], v_normals[3 * (size_t)i + 1], v_normals[3 * (size_t)i + 2], g_ls, g_op, out);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v_log_scales[3 * (size_t)i + k] = acc ? v_log_scales[3 * (size_t)i + k] + g_ls[k] : g_ls[k];
+    v_opacities[i] = acc ? v_opacities[i] + g_op : g_op;
     if (acc) {
         const float4 p = v_quats[i];
         out = make_float4(p.x + out.x, p.y + out.y, p.z + out.z, p.w + out.w);
     }
     v_quats[i] = out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// One backward pass over the Gaussians of a view (round 4; SURVEY rows a2-a4, the plugin's ops.ViewGeometry): what
+// tail_split_kernel, project_bwd_kernel and activate_bwd_kernel did in three launches (26 + 36 + 40 us per view at 1 M
+// Gaussians, each re-reading the blend backward's 64-byte record or the previous kernel's output).  Reads the record
+// [v_xy 0..1 | v_conic 2..4 | v_opacity 5 | v_rgb 6..8 | v_depth 9 | v_normal 10..12] once, keeps the clamp-masked colour
+// cotangent for the SH expansion (12 B), and adds the gradients of means, log scales, quaternions and opacity logits into
+// the step's gradient buffers.  The per-Gaussian arithmetic is project_bwd_point and activate_bwd_point above: same
+// operation sequence, same bits as the three kernels.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void view_bwd_kernel(
+    int N, const float *__restrict__ rec, int rec_stride, const uint8_t *__restrict__ clamp_mask,
+    const float *__restrict__ means, const float *__restrict__ scales, float glob_scale,
+    const float4 *__restrict__ quats_raw, const float4 *__restrict__ quats_n, const float *__restrict__ opac,
+    const int32_t *__restrict__ axis,
+    const float *__restrict__ viewmat, const float *__restrict__ projmat, float fx, float fy, int img_h, int img_w,
+    const int32_t *__restrict__ radii, const float *__restrict__ conics, float *__restrict__ v_rgb,
+    float *__restrict__ v_means, float *__restrict__ v_log_scales, float4 *__restrict__ v_quats,
+    float *__restrict__ v_opacities) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float *r = rec + (size_t)i * rec_stride;
+    float t[13];
+    if ((rec_stride & 3) == 0) {   // 16-byte aligned rows (the pair backward's 16-float records): four loads
+        const float4 a = reinterpret_cast<const float4 *>(r)[0], b = reinterpret_cast<const float4 *>(r)[1],
+                     c = reinterpret_cast<const float4 *>(r)[2];
+        t[0] = a.x; t[1] = a.y; t[2] = a.z; t[3] = a.w; t[4] = b.x; t[5] = b.y; t[6] = b.z; t[7] = b.w;
+        t[8] = c.x; t[9] = c.y; t[10] = c.z; t[11] = c.w; t[12] = r[12];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 13; ++k) t[k] = r[k];
+    }
+    const unsigned m = clamp_mask[i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v_rgb[3 * (size_t)i + c] = ((m >> c) & 1u) ? t[6 + c] : 0.0f;
+    float vm[3] = {0, 0, 0}, vs[3] = {0, 0, 0}, vq4[4] = {0, 0, 0, 0};
+    if (radii[i] > 0)
+        project_bwd_point(i, means, scales, glob_scale, reinterpret_cast<const float *>(quats_n), viewmat, projmat, fx, fy, img_h,
+                          img_w, conics, t[0], t[1], t[9], t[2], t[3], t[4], vm, vs, vq4);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v_means[3 * (size_t)i + k] += vm[k];
+    const float sc[3] = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
+    float g_ls[3], g_op;
+    float4 out;
+    activate_bwd_point(quats_raw[i], sc, opac[i], axis[i], vs, make_float4(vq4[0], vq4[1], vq4[2], vq4[3]), t[5], t[10],
+                       t[11], t[12], g_ls, g_op, out);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v_log_scales[3 * (size_t)i + k] += g_ls[k];
+    v_opacities[i] += g_op;
+    const float4 p = v_quats[i];
+    v_quats[i] = make_float4(p.x + out.x, p.y + out.y, p.z + out.z, p.w + out.w);
+}
+extern "C" int gg_view_bwd(int N, const float *rec, int rec_stride, const uint8_t *clamp_mask, const float *means,
+                           const float *scales, float glob_scale, const float *quats_raw, const float *quats_n, const float *opac,
+                           const int32_t *axis, const float *viewmat, const float *projmat, float fx, float fy,
+                           int img_height, int img_width, const int32_t *radii, const float *conics, float *v_rgb,
+                           float *v_means, float *v_log_scales, float *v_quats, float *v_opacities, gg_stream_t stream) {
+    GG_REQUIRE(N >= 0, "num_points < 0");
+    GG_REQUIRE(rec_stride >= 13, "a record holds 13 values");
+    if (N == 0) return GG_OK;
+    GG_REQUIRE(rec && clamp_mask && means && scales && quats_raw && quats_n && opac && axis && viewmat && projmat && radii &&
+                   conics && v_rgb && v_means && v_log_scales && v_quats && v_opacities, "null pointer");
+    GG_REQUIRE((((uintptr_t)quats_raw | (uintptr_t)quats_n | (uintptr_t)v_quats) & 15) == 0,
+               "quaternion arrays must be 16-byte aligned");
+    GG_REQUIRE((rec_stride & 3) != 0 || ((uintptr_t)rec & 15) == 0, "records of a multiple of 4 floats must be 16-byte aligned");
+    hipLaunchKernelGGL(view_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, rec, rec_stride,
+                       clamp_mask, means, scales, glob_scale, (const float4 *)quats_raw, (const float4 *)quats_n, opac, axis, viewmat,
+                       projmat, fx, fy, img_height, img_width, radii, conics, v_rgb, v_means, v_log_scales,
+                       (float4 *)v_quats, v_opacities);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
 }
 
 extern "C" int gg_activate_fwd(int N, const float *means, const float *log_scales, const float *quats,

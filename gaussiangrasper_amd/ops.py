@@ -778,6 +778,115 @@ class ActivateGaussians(Function):
 
 
 # ------------------------------------------------------------------------------------------------
+# the per-Gaussian chain of a view as ONE autograd node (round 4; what the plugin's fused model calls)
+# ------------------------------------------------------------------------------------------------
+class _PartCtx:
+    """The `ctx` of a Function whose forward / backward run INSIDE another Function (ViewGeometry): attributes are kept,
+    saved tensors are handed to the outer ctx.save_for_backward (a tensor held as a plain attribute of a node that
+    produced it would be a reference cycle)."""
+
+    def __init__(self):
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, value):
+        pass
+
+
+def _is_record_view(t: Optional[Tensor], base: int, offset: int, width: int, stride: int, n: int) -> bool:
+    return (t is not None and t.dtype == torch.float32 and t.dim() == 2 and tuple(t.shape) == (n, width)
+            and t.stride(1) == 1 and t.stride(0) == stride and t.data_ptr() == base + 4 * offset)
+
+
+class ViewGeometry(Function):
+    """apply(means, log_scales, quats, opacities, colors_all, cam_pos, viewmat, full_proj, fx, fy, cx, cy,
+             img_height, img_width, tile_bounds, degrees_to_use)
+       -> (xys, depths, radii, conics, num_tiles_hit, opac, tail (N, 7), normals)
+
+    ActivateGaussians -> ProjectGaussians -> ShadeTail (reference :699-731, :742, :605-619) as one node: the forward is
+    those three operators' forwards, the backward — when every parameter has a gradient buffer (register_grad_sink) and
+    the cotangents arrive as the columns of the blend backward's per-Gaussian record, i.e. in the plugin's training
+    step — is ONE kernel (gg_view_bwd) instead of three that hand (N, k) arrays to each other; the SH gradient is kept
+    or expanded exactly as ShadeTail does.  Anything else (no sinks, dense cotangents, extra cotangents for depths /
+    normals) runs the three operators' backwards in order: same values either way (shared device code)."""
+
+    @staticmethod
+    def forward(ctx, means, log_scales, quats, opacities, colors_all, cam_pos, viewmat, full_proj, fx, fy, cx, cy,
+                img_height, img_width, tile_bounds, degrees_to_use):
+        ctx.set_materialize_grads(False)
+        a, p, t = _PartCtx(), _PartCtx(), _PartCtx()
+        scales_e, quats_n, opac, viewdirs, normals = ActivateGaussians.forward(a, means, log_scales, quats, opacities,
+                                                                              cam_pos)
+        xys, depths, radii, conics, num_tiles_hit, _cov3d = ProjectGaussians.forward(
+            p, means, scales_e, 1, quats_n, viewmat, full_proj, fx, fy, cx, cy, img_height, img_width, tile_bounds)
+        tail = ShadeTail.forward(t, degrees_to_use, viewdirs, colors_all, depths, normals)
+        ctx.parts = (a, p, t)
+        ctx.counts = tuple(len(c.saved_tensors) for c in ctx.parts)
+        ctx.save_for_backward(*a.saved_tensors, *p.saved_tensors, *t.saved_tensors)
+        for c in ctx.parts:
+            c.saved_tensors = ()
+        ctx.mark_non_differentiable(radii, num_tiles_hit)
+        return xys, depths, radii, conics, num_tiles_hit, opac, tail, normals
+
+    @staticmethod
+    def backward(ctx, v_xys, v_depths, v_radii, v_conics, v_nth, v_opac, v_tail, v_normals):
+        a, p, t = ctx.parts
+        saved, k = ctx.saved_tensors, 0
+        for c, cnt in zip(ctx.parts, ctx.counts):
+            c.saved_tensors = saved[k:k + cnt]
+            k += cnt
+        q_raw, scales_e, opac, axis = a.saved_tensors
+        means, _scales, quats_n, viewmat, projmat, radii, conics = p.saved_tensors
+        viewdirs, mask = t.saved_tensors
+        dev, n = means.device, means.shape[0]
+        sinks_ok = a.sinks is not None and p.sink is not None and t.sink is not None
+        fast = sinks_ok and v_depths is None and v_normals is None and v_xys is not None
+        if fast:
+            base, stride = v_xys.data_ptr(), v_xys.stride(0)
+            fast = (stride >= 13 and _is_record_view(v_xys, base, 0, 2, stride, n)
+                    and _is_record_view(v_conics, base, 2, 3, stride, n)
+                    and _is_record_view(v_opac.reshape(n, 1) if v_opac is not None and v_opac.numel() == n else None,
+                                        base, 5, 1, stride, n)
+                    and _is_record_view(v_tail, base, 6, 7, stride, n)
+                    and (stride % 4 != 0 or base % 16 == 0))
+        if not fast:
+            g_t = ShadeTail.backward(t, v_tail if v_tail is not None else torch.zeros(n, 7, device=dev))
+            vd = g_t[3] if v_depths is None else g_t[3] + _f32(v_depths)
+            vn = g_t[4] if v_normals is None else g_t[4] + _f32(v_normals)
+            g_p = ProjectGaussians.backward(p, v_xys, vd, None, v_conics, None, None)
+            g_a = ActivateGaussians.backward(a, g_p[1], g_p[3], v_opac, None, vn)
+            return (g_p[0], g_a[1], g_a[2], g_a[3], g_t[2], None, None, None, None, None, None, None, None, None,
+                    None, None)
+        lib = _lib.load()
+        glob_scale, fx, fy, _cx, _cy, img_height, img_width = p.scalars
+        v_rgb = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        v_ls, v_q, v_o = (s_[1] for s_ in a.sinks)
+        _lib.check(lib.gg_view_bwd(
+            n, C.c_void_p(base), stride, _ptr(mask), _ptr(means), _ptr(scales_e), glob_scale, _ptr(q_raw), _ptr(quats_n),
+            _ptr(opac), _ptr(axis), _ptr(viewmat), _ptr(projmat), fx, fy, img_height, img_width, _ptr(radii),
+            _ptr(conics), _ptr(v_rgb), _ptr(p.sink[1]), _ptr(v_ls), _ptr(v_q), _ptr(v_o), _stream(dev)), "gg_view_bwd")
+        # the SH gradient: kept as its factors over the views of a step, or expanded now — ShadeTail.backward's rules
+        param, buf, notify, defer = t.sink
+        pending = _deferred_sh.get(id(param))
+        if pending and (pending[0][0], pending[0][1]) != (t.degrees_to_use, t.num_bases):
+            flush_grad_sinks()
+        _deferred_sh.setdefault(id(param), []).append((t.degrees_to_use, t.num_bases, viewdirs, v_rgb))
+        if defer is None or not defer():
+            flush_grad_sinks()              # (expands what is kept — this view included — and notifies the sink)
+        if p.sink[2] is not None:
+            p.sink[2](p.sink[0])
+        for param_, _buf, notify_, _defer in a.sinks:
+            if notify_ is not None:
+                notify_(param_)
+        return (None,) * 16
+
+
+# ------------------------------------------------------------------------------------------------
 # several colour arrays from one binning (SURVEY 8f-1: what the plugin's fused model calls)
 # ------------------------------------------------------------------------------------------------
 class RasterizeSegments(Function):

@@ -42,6 +42,23 @@ def fused_view(model, means, log_scales, quats, opacities, colors_all, feature, 
     """Operator part of `get_outputs` (reference :699-784) with the four rasterize calls fused.
     Sets model.xys / model.radii / model.normals as the reference does.  None if nothing is visible.
     full_proj: `projmat @ viewmat` (:707) if the caller has it already (cached per dataset camera)."""
+    if hasattr(ops, "ViewGeometry") and hasattr(ops, "rasterize_segments") and model.config.sh_degree > 0:
+        # activations, projection, SH + clamp + the rgb | depth | normal array: ONE autograd node (ops.ViewGeometry: three
+        # forward kernels; in the training step one backward kernel over the Gaussians instead of three)
+        if full_proj is None:
+            full_proj = projmat @ viewmat                                # :707
+        model._gg_last_view = (viewmat, full_proj)
+        model.xys, depths, model.radii, conics, num_tiles_hit, opac, tail, model.normals = ops.ViewGeometry.apply(
+            means, log_scales, quats, opacities, colors_all, cam_pos.reshape(-1)[:3], viewmat[:3, :], full_proj,
+            fx, fy, cx, cy, H, W, tile_bounds, sh_degree_to_use)
+        if model.training:
+            model.xys.retain_grad()                                    # :724-725
+        feat_im, rgb, depth_im, normal_im = fused_images(ops, model.xys, depths, model.radii, conics, num_tiles_hit,
+                                                         opac, H, W, feature, None, model.normals, tail=tail)
+        count = ops.last_num_intersects(model.radii)     # None: the lists binned last are not this call's
+        if count == 0 or (count is None and (model.radii).sum() == 0):   # :714, answered after the render (see below)
+            return None
+        return {"rgb": rgb, "feature": feat_im, "depth": depth_im, "normal": normal_im}
     fused_act = hasattr(ops, "ActivateGaussians")
     if fused_act:      # exp / normalise / sigmoid / view directions / normals: one kernel each way
         scales_e, quats_n, opac, viewdirs, model.normals = ops.ActivateGaussians.apply(

@@ -117,6 +117,21 @@ int gg_shade_tail_bwd_split(int num_points, const float *v_tail, int v_tail_stri
 int gg_sh_bwd_multi(int num_points, int num_bases, int degrees_to_use, int num_views, const float *const *viewdirs,
                     const float *const *v_colors, float *v_coeffs, int accumulate, gg_stream_t stream);
 
+/* ---- one backward pass over the Gaussians of a view (round 4; ops.ViewGeometry of the plugin route) ------------
+ * gg_shade_tail_bwd_split + gg_project_bwd_ex + gg_activate_bwd_ex in ONE kernel, for the case where every parameter has a
+ * gradient buffer to add into: reads the blend backward's record of a Gaussian once — rec_stride floats apart,
+ * [v_xy 0..1 | v_conic 2..4 | v_opacity 5 | v_rgb 6..8 | v_depth 9 | v_normal 10..12] — keeps the clamp-masked colour
+ * cotangent v_rgb (N, 3) for gg_sh_bwd_multi and ADDS the gradients of the means (N, 3), log scales (N, 3), raw
+ * quaternions (N, 4) and opacity logits (N) to v_means / v_log_scales / v_quats / v_opacities.  `scales`, `quats_n`,
+ * `opac`, `axis` are gg_activate_fwd's outputs, `quats_raw` its input, `radii` / `conics` gg_project_fwd's.  The
+ * per-Gaussian operation sequence is the three kernels' (shared device functions): the same bits.
+ * Reference: what autograd does behind gaussian_splatting.py:699-731 in ~60 launches per view. */
+int gg_view_bwd(int num_points, const float *rec, int rec_stride, const uint8_t *clamp_mask, const float *means,
+                const float *scales, float glob_scale, const float *quats_raw, const float *quats_n, const float *opac,
+                const int32_t *axis, const float *viewmat, const float *projmat, float fx, float fy, int img_height,
+                int img_width, const int32_t *radii, const float *conics, float *v_rgb, float *v_means,
+                float *v_log_scales, float *v_quats, float *v_opacities, gg_stream_t stream);
+
 /* ---- quat_to_rotmat ------------------------------------------------------------------------
  * Replace gsplat `_torch_impl.quat_to_rotmat` (differentiable torch code there: ~35 elementwise
  * launches forward, ~70 backward; reference call sites gaussian_splatting.py:516,614 — the

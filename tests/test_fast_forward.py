@@ -205,3 +205,4 @@ def test_fast_forward_through_the_plugin_class_at_full_size(oracle):
         P.set_exact_forward(prev)
     worst = {k: _close(_np(fa[k]), _np(ex[k]), k) for k in ex}
     print("plugin class at 1600x1200, fast vs exact forward, max |diff|:", worst)
+

@@ -357,3 +357,77 @@ def test_training_cameras_reuse_their_pose_matrices_and_an_unbinned_view_is_not_
         assert P.last_num_intersects(torch.ones(2, dtype=torch.int32)) is None
     finally:
         P._bin_cache = prev
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("deterministic", [True, False])
+def test_view_geometry_one_kernel_backward_equals_the_three_operator_chain(deterministic, monkeypatch):
+    """ops.ViewGeometry (round 4: activations -> projection -> SH / tail as ONE autograd node whose training-step
+    backward is the single kernel gg_view_bwd) against the chain ActivateGaussians -> ProjectGaussians -> ShadeTail
+    on the same inputs, gradient sinks registered for all six parameters, two views per step (the SH gradient kept and
+    expanded once).  With the deterministic blend backward both get the same per-Gaussian records (dense 13-float rows),
+    so the six gradients must agree BIT FOR BIT (the kernels share their per-Gaussian device code); with the default
+    backward (16-float records, float atomics) to the order of the atomics."""
+    from gaussiangrasper_amd import _lib, ops as P
+    from gaussiangrasper_amd.dist import GradBucket
+    from gaussiangrasper_amd.pipeline import fused_images
+    from test_gpu_parity import assert_close
+    dev = "cuda:0"
+    n, h, w = 40000, 208, 304
+    views = ring_cameras(3, h, w, device=dev)
+    lib = _lib.load()
+    calls = {"view_bwd": 0}
+    real = lib.gg_view_bwd
+
+    def counted(*a):
+        calls["view_bwd"] += 1
+        return real(*a)
+    monkeypatch.setattr(lib, "gg_view_bwd", counted, raising=False)
+    res, imgs = {}, {}
+    prev = P.set_deterministic_backward(deterministic)
+    try:
+        for route in ("node", "chain"):
+            sc = make_scene(n, feature_dim=32, config_index=5).to(dev)
+            sc.scales.data.add_(0.8)
+            for p_ in sc.params():
+                p_.requires_grad_(True)
+            bucket = GradBucket(sc.params())
+            bucket.enable_direct(P, defer_sh=True)
+            bucket.zero_()
+            calls["view_bwd"] = 0
+            for k, v in enumerate(views[:2]):
+                if k == 1:
+                    bucket.arm()
+                P.clear_bin_cache()
+                cam = v.cam_pos.to(dev).reshape(-1)[:3]
+                if route == "node":
+                    xys, depths, radii, conics, nth, opac, tail, normals = P.ViewGeometry.apply(
+                        sc.means, sc.scales, sc.quats, sc.opacities, sc.colors_all, cam, v.viewmat[:3, :], v.projmat,
+                        v.fx, v.fy, v.cx, v.cy, h, w, v.tile_bounds, 4)
+                else:
+                    scales_e, quats_n, opac, viewdirs, normals = P.ActivateGaussians.apply(
+                        sc.means, sc.scales, sc.quats, sc.opacities, cam)
+                    xys, depths, radii, conics, nth, _ = P.ProjectGaussians.apply(
+                        sc.means, scales_e, 1, quats_n, v.viewmat[:3, :], v.projmat, v.fx, v.fy, v.cx, v.cy, h, w,
+                        v.tile_bounds)
+                    tail = P.ShadeTail.apply(4, viewdirs, sc.colors_all, depths, normals)
+                out = fused_images(P, xys, depths, radii, conics, nth, opac, h, w, sc.feature, None, normals, tail=tail)
+                g = torch.Generator(device="cpu").manual_seed(5 + k)
+                cots = [torch.randn(o.shape, generator=g).to(dev) for o in out]
+                torch.autograd.backward(list(out), cots)
+                imgs[(route, k)] = [o.detach().clone() for o in out]
+            bucket.finish()
+            torch.cuda.synchronize()
+            assert calls["view_bwd"] == (2 if route == "node" else 0), (route, calls)
+            res[route] = bucket.gathered().detach().cpu().numpy().copy()
+            P.clear_grad_sinks()
+    finally:
+        P.set_deterministic_backward(prev)
+    for k in range(2):
+        for a, b in zip(imgs[("node", k)], imgs[("chain", k)]):
+            assert torch.equal(a, b)
+    assert np.abs(res["chain"]).sum() > 0
+    if deterministic:
+        assert np.array_equal(res["node"], res["chain"])
+    else:
+        assert_close(res["node"], res["chain"], "one-kernel backward vs chain", rtol=1e-4, atol_frac=2e-6)

@@ -72,8 +72,10 @@ extern "C" int gg_count_intersects(int N, const int32_t *num_tiles_hit, int64_t 
     if (N == 0) return GG_OK;
     GG_REQUIRE(num_tiles_hit != nullptr, "null pointer");
     int blocks = min((N + 255) / 256, 128);   // one same-address atomic per block: keep them few
+    gg_prof_begin(GG_K_COUNT, s);
     hipLaunchKernelGGL(count_kernel, dim3(blocks), dim3(256), 0, s, N, num_tiles_hit,
                        (unsigned long long *)out);
+    gg_prof_end(GG_K_COUNT, s);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
@@ -266,16 +268,18 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
 //               (radius <= 0) go to one extra last bucket;
 //   db_prefix   G[block][bucket] -> the block's first position inside the bucket; bucket totals;
 //   db_starts   exclusive scan of the bucket totals (one workgroup) -> bucket starts; the visible count;
-//   db_scatter  the same walk as db_count; every Gaussian's (bits << 32 | id) goes to its bucket's run (position from
-//               an LDS cursor: the order inside a run is whatever the atomics gave);
+//   db_scatter  the same walk as db_count; every Gaussian's record {bits, id, tiles hit, tile box} — 16 bytes, one store
+//               request — goes to its bucket's run (position from an LDS cursor: the order inside a run is whatever the
+//               atomics gave);
 //   db_sort     ONE WAVE per bucket: a run of <= 256 entries (mean 64) is ordered by counting, for every word, the words
 //               below it (v_readlane broadcasts, no LDS, no dependent chain); up to 512 entries by stable LSD byte passes
 //               in LDS (depth bytes first, passes whose digit is constant skipped, the id bytes only if equal depths came
-//               out of order); then the wave writes the ids in order, each Gaussian's bucket, the
-//               exclusive scan of num_tiles_hit inside the bucket and the bucket's sum; longer runs (bit-identical depths
+//               out of order); then the wave writes the ids in order and, per position, {the exclusive
+//               scan of the tile counts inside the bucket, the bucket, the tile box, the count}, and the bucket's sum; longer runs (bit-identical depths
 //               en masse) go through a compare-exchange network in global memory first;
 //   db_offsets  exclusive scan of the bucket sums (one workgroup).
-// emit_kernel adds a Gaussian's in-bucket offset to its bucket's.  7 launches instead of 15; same order bit for bit
+// emit_kernel adds a Gaussian's in-bucket offset to its bucket's and reads nothing by Gaussian id.  7 launches instead of
+// 15; same order bit for bit
 // (tests/test_gpu_parity.py binning tests, incl. depth ties and runs beyond 512).
 // ---------------------------------------------------------------------------------------------
 typedef unsigned long long u64;
@@ -342,11 +346,34 @@ __global__ __launch_bounds__(256) void db_range_kernel(int N, DepthSrc dsrc, uin
         mm[2 * blockIdx.x + 1] = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
     }
 }
+// What travels with a Gaussian through the bucket sort: {depth bits, id, tiles hit, tile box}.  The box — x0 | y0 << 10 |
+// width << 20 of gg_tile_bbox — and the count are formed where the Gaussians are still walked in index order (coalesced
+// reads of xys / radii), so that neither the sort's scan of the counts nor the emission gathers per-Gaussian data by id
+// (1 M scattered reads each: 16 and 35 us of the first version of this path).  Tile grids up to 1023 x 1023.
+#define DB_BOX_MAX 1023
+struct DbGeom {
+    const float *xys;
+    int tiles_x, tiles_y;
+};
+__device__ __forceinline__ void db_box(const DbGeom g, const DepthSrc d, int i, uint32_t &cnt, uint32_t &box) {
+    const int rad = d.radii[i];
+    cnt = 0u;
+    box = 1u << 20;
+    if (rad > 0) {
+        int x0, y0, x1, y1;
+        gg_tile_bbox(g.xys[2 * (size_t)i], g.xys[2 * (size_t)i + 1], (float)rad, g.tiles_x, g.tiles_y, x0, y0, x1, y1);
+        const int bw = x1 - x0;
+        if (bw > 0 && y1 > y0) {
+            cnt = (uint32_t)(bw * (y1 - y0));
+            box = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)bw << 20);
+        }
+    }
+}
 // SCATTER false: G[block][bucket] = the block's count; true: G holds the block's first position in each bucket
 template <bool SCATTER>
-__global__ __launch_bounds__(DB_THREADS) void db_walk_kernel(int N, int nb, DepthSrc dsrc, const uint32_t *__restrict__ mm,
-                                                             uint32_t *__restrict__ G, const uint32_t *__restrict__ start,
-                                                             u64 *__restrict__ pairs) {
+__global__ __launch_bounds__(DB_THREADS) void db_walk_kernel(int N, int nb, DepthSrc dsrc, DbGeom geom,
+                                                             const uint32_t *__restrict__ mm, uint32_t *__restrict__ G,
+                                                             const uint32_t *__restrict__ start, uint4 *__restrict__ recs) {
     extern __shared__ uint32_t s_hist[];   // nb + 1 counters (SCATTER: cursors), then the range
     uint32_t *s_mm = s_hist + nb + 1;
     const DbRange r = db_range_of(mm, nb, s_mm);
@@ -356,15 +383,20 @@ __global__ __launch_bounds__(DB_THREADS) void db_walk_kernel(int N, int nb, Dept
     for (int b = threadIdx.x; b <= nb; b += DB_THREADS) s_hist[b] = SCATTER ? start[b] + row[b] : 0u;
     __syncthreads();
     for (int i = lo + threadIdx.x; i < hi; i += 4 * DB_THREADS) {                 // four loads in flight per thread
-        uint32_t k[4];
+        uint32_t k[4], cnt[4], box[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) k[u] = (i + u * DB_THREADS < hi) ? depth_key(dsrc, i + u * DB_THREADS) : 0u;
+        for (int u = 0; u < 4; ++u) {
+            const int iu = i + u * DB_THREADS;
+            k[u] = iu < hi ? depth_key(dsrc, iu) : 0u;
+            cnt[u] = box[u] = 0u;
+            if (SCATTER && iu < hi) db_box(geom, dsrc, iu, cnt[u], box[u]);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (i + u * DB_THREADS < hi) {
                 const uint32_t pos = atomicAdd(&s_hist[db_bucket(r, k[u], nb)], 1u);
                 if (SCATTER && k[u] != 0xFFFFFFFFu)                            // (nothing reads the culled run)
-                    pairs[pos] = ((u64)k[u] << 32) | (uint32_t)(i + u * DB_THREADS);
+                    recs[pos] = make_uint4(k[u], (uint32_t)(i + u * DB_THREADS), cnt[u], box[u]);
             }
         }
     }
@@ -388,44 +420,53 @@ __global__ __launch_bounds__(256) void db_prefix_kernel(int nb, uint32_t *__rest
     }
     total[b] = run;
 }
-// one workgroup: v[0 .. n) -> exclusive scan in place, v[n] = total (n <= DB_MAX_BUCKETS + 1)
+// one workgroup: v[0 .. n) -> exclusive scan in place, v[n] = total.  A round covers 4 096 consecutive values (four per
+// thread: coalesced 16-byte accesses); the values of four rounds are requested before the first is scanned, and a round
+// costs one barrier (the wave sums alternate between two LDS rows, the carry is the same number in every thread)
 __global__ __launch_bounds__(1024) void db_scan_kernel(int n, uint32_t *__restrict__ v) {
-    __shared__ uint32_t s_w[16];
-    __shared__ uint32_t s_carry;
+    __shared__ uint32_t s_w[2][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_carry = 0u;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024 * 4) {
-        const int i0 = base + 4 * tid;
-        uint32_t x[4];
+    uint32_t carry = 0u;
+    int round = 0;
+    for (int base = 0; base < n; base += 4 * 4096) {
+        uint32_t x[4][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) x[k] = i0 + k < n ? v[i0 + k] : 0u;
-        const uint32_t mine = x[0] + x[1] + x[2] + x[3];
-        uint32_t incl = mine;
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
+            for (int k = 0; k < 4; ++k) {
+                const int i = base + 4096 * q + 4 * tid + k;
+                x[q][k] = i < n ? v[i] : 0u;
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q, ++round) {
+            if (base + 4096 * q >= n) break;
+            const uint32_t mine = x[q][0] + x[q][1] + x[q][2] + x[q][3];
+            uint32_t incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            uint32_t *sw = s_w[round & 1];
+            if (lane == 63) sw[wave] = incl;
+            __syncthreads();
+            uint32_t ex = carry + incl - mine, all = 0u;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                const uint32_t t = sw[w];
+                if (w < wave) ex += t;
+                all += t;
+            }
+            carry += all;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = base + 4096 * q + 4 * tid + k;
+                if (i < n) v[i] = ex;
+                ex += x[q][k];
+            }
         }
-        if (lane == 63) s_w[wave] = incl;
-        __syncthreads();
-        uint32_t ex = s_carry + incl - mine, all = 0u;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const uint32_t t = s_w[w];
-            if (w < wave) ex += t;
-            all += t;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (i0 + k < n) v[i0 + k] = ex;
-            ex += x[k];
-        }
-        __syncthreads();
-        if (tid == 0) s_carry += all;
-        __syncthreads();
     }
-    if (tid == 0) v[n] = s_carry;
+    if (tid == 0) v[n] = carry;
 }
 
 // compare-exchange network over u64 keys in global memory by ONE WAVE (its own stores are visible to its later loads behind
@@ -516,11 +557,24 @@ __device__ __forceinline__ void db_wsync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
 }
+// rank[t] += the number of words of buf[0 .. 4 ceil(n / 4)) below key[t], t < NS
+template <int NS>
+__device__ __forceinline__ void db_rank(const u64 *buf, const int n, const u64 (&key)[DB_RANK_CAP / 64],
+                                        uint32_t (&rank)[DB_RANK_CAP / 64]) {
+    for (int j = 0; j < n; j += 4) {
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        const u64x2 a = *reinterpret_cast<const u64x2 *>(buf + j), b = *reinterpret_cast<const u64x2 *>(buf + j + 2);
+#pragma unroll
+        for (int t = 0; t < NS; ++t)
+            rank[t] += (uint32_t)(a[0] < key[t]) + (uint32_t)(a[1] < key[t]) + (uint32_t)(b[0] < key[t]) +
+                       (uint32_t)(b[1] < key[t]);
+    }
+}
 __global__ __launch_bounds__(64 * DB_WPB) void db_sort_kernel(int N, int nb, const uint32_t *__restrict__ start,
-                                                              u64 *__restrict__ pairs, const int32_t *__restrict__ nth,
-                                                              uint32_t *__restrict__ order, uint32_t *__restrict__ bucket_of,
-                                                              uint32_t *__restrict__ off_in, uint32_t *__restrict__ bucket_sum) {
-    __shared__ u64 s_buf[DB_WPB][DB_CAP];
+                                                              const uint4 *__restrict__ recs, u64 *__restrict__ pairs,
+                                                              DepthSrc dsrc, DbGeom geom, uint32_t *__restrict__ order,
+                                                              uint4 *__restrict__ einfo, uint32_t *__restrict__ bucket_sum) {
+    __shared__ __attribute__((aligned(16))) u64 s_buf[DB_WPB][DB_CAP];
     __shared__ uint32_t s_hist[DB_WPB][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * DB_WPB + wave;
@@ -533,40 +587,56 @@ __global__ __launch_bounds__(64 * DB_WPB) void db_sort_kernel(int N, int nb, con
         if (lane == 0) bucket_sum[b] = 0u;
         return;
     }
-    uint32_t gid[DB_ITEMS];       // the ids of positions 64 r + lane of the sorted run (runs <= DB_CAP)
+    // ids, tile counts and tile boxes of positions 64 r + lane of the sorted run (runs <= DB_CAP)
+    uint32_t gid[DB_ITEMS], cntv[DB_ITEMS], boxv[DB_ITEMS];
+    bool carried = false;         // counts / boxes came with the records (else: looked up by id below)
     if (n <= DB_RANK_CAP) {
+        carried = true;
         // every key's place = the number of keys below it (the words are distinct: they end in the id).  Key j comes to all
         // lanes by v_readlane, no LDS, no dependent chain: ~n^2 / 64 compare-and-add per lane (mean run: 128 entries)
         constexpr int RS = DB_RANK_CAP / 64;
         u64 key[RS];
-        uint32_t rank[RS];
+        uint32_t rank[RS], pc[RS], pb[RS];
 #pragma unroll
         for (int t = 0; t < RS; ++t) {
-            key[t] = (64 * t + lane < n) ? pairs[s0 + 64 * t + lane] : ~0ull;
+            const bool in = 64 * t + lane < n;
+            const uint4 rc = in ? recs[s0 + 64 * t + lane] : make_uint4(~0u, ~0u, 0u, 0u);
+            key[t] = ((u64)rc.x << 32) | rc.y;
+            pc[t] = rc.z;
+            pb[t] = rc.w;
             rank[t] = 0u;
         }
         const int nslots = (n + 63) >> 6;
-#pragma unroll
-        for (int sl = 0; sl < RS; ++sl) {
-            if (sl < nslots) {                                           // (wave-uniform)
-                const uint32_t lo = (uint32_t)key[sl], hi = (uint32_t)(key[sl] >> 32);
-                const int cnt = min(64, n - 64 * sl);
-                for (int l = 0; l < cnt; ++l) {
-                    const u64 kj = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)hi, l) << 32) |
-                                   (uint32_t)__builtin_amdgcn_readlane((int)lo, l);
-#pragma unroll
-                    for (int t = 0; t < RS; ++t)
-                        if (t < nslots) rank[t] += (kj < key[t]) ? 1u : 0u;
-                }
-            }
-        }
-        uint32_t *ids = reinterpret_cast<uint32_t *>(buf);
+        // the words go to LDS once (positions >= n hold the largest word: below nothing) and come back as wave-uniform
+        // broadcast reads, four per step; a lane compares them with the 1..4 words it owns — no branch inside the loop
 #pragma unroll
         for (int t = 0; t < RS; ++t)
-            if (64 * t + lane < n) ids[rank[t]] = (uint32_t)key[t];
+            if (t < nslots) buf[64 * t + lane] = key[t];
+        db_wsync();
+        {
+            if (nslots == 1) db_rank<1>(buf, n, key, rank);
+            else if (nslots == 2) db_rank<2>(buf, n, key, rank);
+            else if (nslots == 3) db_rank<3>(buf, n, key, rank);
+            else db_rank<4>(buf, n, key, rank);
+        }
+        db_wsync();
+        // id, count and box go to their places through LDS ([256] words each) and come back in order
+        uint32_t *xw = reinterpret_cast<uint32_t *>(buf);
+#pragma unroll
+        for (int t = 0; t < RS; ++t)
+            if (64 * t + lane < n) {
+                xw[rank[t]] = (uint32_t)key[t];
+                xw[DB_RANK_CAP + rank[t]] = pc[t];
+                xw[2 * DB_RANK_CAP + rank[t]] = pb[t];
+            }
         db_wsync();
 #pragma unroll
-        for (int r = 0; r < DB_ITEMS; ++r) gid[r] = (r < RS && 64 * r + lane < n) ? ids[64 * r + lane] : 0u;
+        for (int r = 0; r < DB_ITEMS; ++r) {
+            const bool in = r < RS && 64 * r + lane < n;
+            gid[r] = in ? xw[64 * r + lane] : 0u;
+            cntv[r] = in ? xw[DB_RANK_CAP + 64 * r + lane] : 0u;
+            boxv[r] = in ? xw[2 * DB_RANK_CAP + 64 * r + lane] : 0u;
+        }
     } else if (n <= DB_CAP) {
         // stable LSD byte passes in LDS (round 4's per-tile sort, profiles/r04_counting_sort_binning_experiment.patch)
         // (validity of a slot is recomputed from a laundered n - lane wherever it is needed: as loop invariants the lane
@@ -576,7 +646,10 @@ __global__ __launch_bounds__(64 * DB_WPB) void db_sort_kernel(int N, int nb, con
         {
             DB_LIM(nv);
 #pragma unroll
-            for (int r = 0; r < DB_ITEMS; ++r) key[r] = (64 * r < nv) ? pairs[s0 + 64 * r + lane] : ~0ull;
+            for (int r = 0; r < DB_ITEMS; ++r) {
+                const uint4 rc = (64 * r < nv) ? recs[s0 + 64 * r + lane] : make_uint4(~0u, ~0u, 0u, 0u);
+                key[r] = ((u64)rc.x << 32) | rc.y;
+            }
         }
         // one stable pass on bits [shift, shift + 8); nothing moves if the digit is the same for every key
         auto pass = [&](const int shift) {
@@ -676,10 +749,15 @@ __global__ __launch_bounds__(64 * DB_WPB) void db_sort_kernel(int N, int nb, con
 #undef DB_LIM
 #pragma unroll
         for (int r = 0; r < DB_ITEMS; ++r) gid[r] = (uint32_t)key[r];
-    } else {
-        db_bitonic64(pairs + s0, n);     // (rare: more than 512 Gaussians in 1 / nb of the depth range)
+    } else {                             // (rare: more than 512 Gaussians in 1 / nb of the depth range)
+        for (int i = lane; i < n; i += 64) {
+            const uint4 rc = recs[s0 + i];
+            pairs[s0 + i] = ((u64)rc.x << 32) | rc.y;
+        }
+        db_wsync();
+        db_bitonic64(pairs + s0, n);
     }
-    // output: ids in order, the bucket of every position, the exclusive scan of num_tiles_hit inside the bucket
+    // output: ids in order; per position {offset inside the bucket (exclusive scan of the counts), bucket, box, count}
     uint32_t carry = 0;
     for (int c0 = 0; c0 < n; c0 += DB_CAP) {
         if (n > DB_CAP) {
@@ -692,7 +770,13 @@ __global__ __launch_bounds__(64 * DB_WPB) void db_sort_kernel(int N, int nb, con
             if (c0 + 64 * r < n) {                                        // (wave-uniform)
                 const bool valid = p < n;
                 const uint32_t g = min(gid[r], (uint32_t)(N - 1));
-                const uint32_t c = valid ? (uint32_t)nth[g] : 0u;
+                uint32_t c = cntv[r], bx = boxv[r];
+                if (!carried) {                                           // (wave-uniform)
+                    c = 0u;
+                    bx = 1u << 20;
+                    if (valid) db_box(geom, dsrc, (int)g, c, bx);
+                }
+                if (!valid) c = 0u;
                 uint32_t incl = c;
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
@@ -701,8 +785,7 @@ __global__ __launch_bounds__(64 * DB_WPB) void db_sort_kernel(int N, int nb, con
                 }
                 if (valid) {
                     order[s0 + p] = g;
-                    bucket_of[s0 + p] = (uint32_t)b;
-                    off_in[s0 + p] = carry + incl - c;
+                    einfo[s0 + p] = make_uint4(carry + incl - c, (uint32_t)b, bx, c);
                 }
                 carry += __shfl(incl, 63, 64);
             }
@@ -720,17 +803,13 @@ __global__ __launch_bounds__(64 * DB_WPB) void db_sort_kernel(int N, int nb, con
 // lane j of an iteration finds its source Gaussian by binary search over the 64 start offsets — so
 // every store instruction writes 64 consecutive entries.  (The first version looped per Gaussian over
 // its own tiles: 64 short runs per instruction and as many iterations as the largest box of the wave.)
-// offsets[r]: the Gaussian's offset inside its bucket; bucket_of[r] / bucket_base: its bucket and that bucket's offset
-// (db_sort_kernel / db_scan_kernel); only the first *visible positions of the order carry them
+// einfo[r] = {offset inside the bucket, bucket, tile box, tile count} of the r-th Gaussian of the depth order
+// (db_sort_kernel), bucket_base: the buckets' offsets (db_scan_kernel); only the first *visible positions carry them
 __global__ __launch_bounds__(256) void emit_kernel(int N, const uint32_t *__restrict__ order,
-                                                   const uint32_t *__restrict__ offsets,
-                                                   const uint32_t *__restrict__ bucket_of,
+                                                   const uint4 *__restrict__ einfo,
                                                    const uint32_t *__restrict__ bucket_base,
-                                                   const uint32_t *__restrict__ visible,
-                                                   const float *__restrict__ xys,
-                                                   const int32_t *__restrict__ radii, int tiles_x,
-                                                   int tiles_y, int64_t I,
-                                                   const int64_t *__restrict__ I_dev,
+                                                   const uint32_t *__restrict__ visible, int tiles_x,
+                                                   int64_t I, const int64_t *__restrict__ I_dev,
                                                    uint32_t *__restrict__ tkeys,
                                                    uint32_t *__restrict__ tvals) {
     __shared__ uint32_t s_rel[4][64];
@@ -742,16 +821,12 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, const uint32_t *__rest
     int x0 = 0, y0 = 0, bw = 1;
     if (r < N && (uint32_t)r < *visible) {
         g = min(order[r], (uint32_t)(N - 1));
-        off = offsets[r] + bucket_base[bucket_of[r]];
-        const int rad = radii[g];
-        if (rad > 0) {
-            int x1, y1;
-            gg_tile_bbox(xys[2 * (size_t)g], xys[2 * (size_t)g + 1], (float)rad, tiles_x, tiles_y, x0, y0,
-                         x1, y1);
-            bw = x1 - x0;
-            cnt = (uint32_t)(bw * (y1 - y0));
-            if (bw <= 0) { bw = 1; cnt = 0; }
-        }
+        const uint4 e = einfo[r];
+        off = e.x + bucket_base[e.y];
+        x0 = (int)(e.z & 1023u);
+        y0 = (int)((e.z >> 10) & 1023u);
+        bw = max(1, (int)(e.z >> 20));
+        cnt = e.w;
     }
     // offsets[] is the exclusive scan of the counts in this order, so the wave's range starts at lane
     // 0's offset and the relative starts are an exclusive scan of cnt over the lanes
@@ -816,15 +891,15 @@ static int radix_nblocks(int64_t n) {
 
 struct BinWs {
     uint32_t *order;                          // N: Gaussian ids in depth order (the visible ones first)
-    uint32_t *offsets;                        // N: offset of a Gaussian's entries inside its bucket
+    uint4 *einfo;                             // N: {offset inside the bucket, bucket, tile box, tile count} in that order
     uint32_t *G;                              // 256 * max nblocks
     uint32_t *totals;                         // 256
     uint32_t *tkeyA, *tkeyB, *tvalTmp;        // I each
     // depth order by buckets (db_*)
-    u64 *pairs;                               // N: (depth bits << 32 | id), grouped by bucket
-    uint32_t *bucket_of;                      // N
+    uint4 *recs;                              // N: {depth bits, id, tile count, tile box}, grouped by bucket
+    u64 *pairs;                               // N: scratch of the runs too long for LDS (depth bits << 32 | id)
     uint32_t *dbG;                            // DB_BLOCKS x (buckets + 1)
-    uint32_t *dbStart;                        // buckets + 2: bucket totals -> starts; [buckets] = visible count, [buckets + 1] = N
+    uint32_t *dbStart;                        // buckets + 2: bucket totals -> starts; [buckets] = the visible count
     uint32_t *dbBase;                         // buckets + 1: bucket sums of num_tiles_hit -> offsets
     uint32_t *dbmm;                           // 2 x 256: partial min / max of the depth bits
     size_t bytes;
@@ -839,7 +914,7 @@ static BinWs bin_ws_layout(void *ws, int N, int64_t I) {
     };
     size_t n = (size_t)(N > 0 ? N : 1), i = (size_t)(I > 0 ? I : 1);
     w.order = take(4 * n);
-    w.offsets = take(4 * n);
+    w.einfo = (uint4 *)take(16 * n);
     int nb = max(radix_nblocks(N), radix_nblocks(I));
     w.G = take(4 * 256 * (size_t)(nb + 1));
     w.totals = take(4 * 256);
@@ -847,8 +922,8 @@ static BinWs bin_ws_layout(void *ws, int N, int64_t I) {
     w.tkeyB = take(4 * i);
     w.tvalTmp = take(4 * i);
     const size_t nbk = (size_t)db_buckets(N);
+    w.recs = (uint4 *)take(16 * n);
     w.pairs = (u64 *)take(8 * n);
-    w.bucket_of = take(4 * n);
     w.dbG = take(4 * DB_BLOCKS * (nbk + 1));
     w.dbStart = take(4 * (nbk + 2));
     w.dbBase = take(4 * (nbk + 1));
@@ -885,6 +960,7 @@ static int bin_sort_impl(int N, int64_t I, const int64_t *I_dev, const float *xy
                          void *ws, size_t ws_bytes, gg_stream_t stream) {
     GG_REQUIRE(N >= 0 && I >= 0, "negative size");
     GG_REQUIRE(tiles_x > 0 && tiles_y > 0, "empty tile grid");
+    GG_REQUIRE(tiles_x <= DB_BOX_MAX && tiles_y <= DB_BOX_MAX, "tile grid beyond 1023 x 1023 (images beyond 16 368 pixels a side)");
     GG_REQUIRE(I < (int64_t)1 << 31, "num_intersects must fit int32 (tile_bins are int32)");
     GG_REQUIRE(tile_bins != nullptr, "null tile_bins");
     hipStream_t s = (hipStream_t)stream;
@@ -911,14 +987,15 @@ static int bin_sort_impl(int N, int64_t I, const int64_t *I_dev, const float *xy
     }
     uint32_t *order = w.order;
     hipLaunchKernelGGL(db_range_kernel, dim3(256), dim3(256), 0, s, N, dsrc, w.dbmm);
-    hipLaunchKernelGGL(db_walk_kernel<false>, dim3(DB_BLOCKS), dim3(DB_THREADS), walk_lds, s, N, nbk, dsrc, w.dbmm, w.dbG,
-                       (const uint32_t *)nullptr, (u64 *)nullptr);
+    const DbGeom geom{xys, tiles_x, tiles_y};
+    hipLaunchKernelGGL(db_walk_kernel<false>, dim3(DB_BLOCKS), dim3(DB_THREADS), walk_lds, s, N, nbk, dsrc, geom, w.dbmm,
+                       w.dbG, (const uint32_t *)nullptr, (uint4 *)nullptr);
     hipLaunchKernelGGL(db_prefix_kernel, dim3((nbk + 1 + 255) / 256), dim3(256), 0, s, nbk, w.dbG, w.dbStart);
-    hipLaunchKernelGGL(db_scan_kernel, dim3(1), dim3(1024), 0, s, nbk + 1, w.dbStart);
-    hipLaunchKernelGGL(db_walk_kernel<true>, dim3(DB_BLOCKS), dim3(DB_THREADS), walk_lds, s, N, nbk, dsrc, w.dbmm, w.dbG,
-                       (const uint32_t *)w.dbStart, w.pairs);
-    hipLaunchKernelGGL(db_sort_kernel, dim3((nbk + DB_WPB - 1) / DB_WPB), dim3(64 * DB_WPB), 0, s, N, nbk, (const uint32_t *)w.dbStart, w.pairs,
-                       num_tiles_hit, order, w.bucket_of, w.offsets, w.dbBase);
+    hipLaunchKernelGGL(db_scan_kernel, dim3(1), dim3(1024), 0, s, nbk, w.dbStart);   // (-> [nbk] = the visible count)
+    hipLaunchKernelGGL(db_walk_kernel<true>, dim3(DB_BLOCKS), dim3(DB_THREADS), walk_lds, s, N, nbk, dsrc, geom, w.dbmm,
+                       w.dbG, (const uint32_t *)w.dbStart, w.recs);
+    hipLaunchKernelGGL(db_sort_kernel, dim3((nbk + DB_WPB - 1) / DB_WPB), dim3(64 * DB_WPB), 0, s, N, nbk,
+                       (const uint32_t *)w.dbStart, (const uint4 *)w.recs, w.pairs, dsrc, geom, order, w.einfo, w.dbBase);
     hipLaunchKernelGGL(db_scan_kernel, dim3(1), dim3(1024), 0, s, nbk, w.dbBase);
     // 3./4. emit + sort by tile id; ping-pong so the last pass lands in gaussian_ids_sorted
     int tile_bits = 1;
@@ -936,8 +1013,8 @@ static int bin_sort_impl(int N, int64_t I, const int64_t *I_dev, const float *xy
         (void)gg_fill_async(vcur, 0, sizeof(uint32_t) * (size_t)I, s);
     }
     hipLaunchKernelGGL(emit_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, (const uint32_t *)order,
-                       (const uint32_t *)w.offsets, (const uint32_t *)w.bucket_of, (const uint32_t *)w.dbBase,
-                       (const uint32_t *)(w.dbStart + nbk), xys, radii, tiles_x, tiles_y, I, I_dev, kcur, vcur);
+                       (const uint4 *)w.einfo, (const uint32_t *)w.dbBase, (const uint32_t *)(w.dbStart + nbk), tiles_x, I,
+                       I_dev, kcur, vcur);
     // the tile id's bits are split evenly over the passes (13 bits: 7 + 6, not 8 + 5): a pass ranks its keys with one
     // ballot per digit bit, and the scatter kernels are bound by that ranking
     const int per_pass = (tile_bits + passes - 1) / passes;

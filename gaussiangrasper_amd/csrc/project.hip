@@ -669,8 +669,10 @@ extern "C" int gg_shade_tail_bwd_split(int N, const float *v_tail, int v_tail_st
     GG_REQUIRE(v_tail_stride >= 7, "v_tail rows hold 7 values");
     if (N == 0) return GG_OK;
     GG_REQUIRE(v_tail && clamp_mask && v_rgb && v_depths && v_normals, "null pointer");
+    gg_prof_begin(GG_K_TAIL_SPLIT, (hipStream_t)stream);
     hipLaunchKernelGGL(tail_split_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, v_tail,
                        v_tail_stride, clamp_mask, v_rgb, v_depths, v_normals);
+    gg_prof_end(GG_K_TAIL_SPLIT, (hipStream_t)stream);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
@@ -1042,10 +1044,12 @@ extern "C" int gg_view_bwd(int N, const float *rec, int rec_stride, const uint8_
     GG_REQUIRE((((uintptr_t)quats_raw | (uintptr_t)quats_n | (uintptr_t)v_quats) & 15) == 0,
                "quaternion arrays must be 16-byte aligned");
     GG_REQUIRE((rec_stride & 3) != 0 || ((uintptr_t)rec & 15) == 0, "records of a multiple of 4 floats must be 16-byte aligned");
+    gg_prof_begin(GG_K_VIEW_BWD, (hipStream_t)stream);
     hipLaunchKernelGGL(view_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, rec, rec_stride,
                        clamp_mask, means, scales, glob_scale, (const float4 *)quats_raw, (const float4 *)quats_n, opac, axis, viewmat,
                        projmat, fx, fy, img_height, img_width, radii, conics, v_rgb, v_means, v_log_scales,
                        (float4 *)v_quats, v_opacities);
+    gg_prof_end(GG_K_VIEW_BWD, (hipStream_t)stream);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
@@ -1059,9 +1063,11 @@ extern "C" int gg_activate_fwd(int N, const float *means, const float *log_scale
     GG_REQUIRE(means && log_scales && quats && opacities && cam_pos && scales && quats_n && opac && viewdirs &&
                    normals && axis, "null pointer");
     GG_REQUIRE((((uintptr_t)quats | (uintptr_t)quats_n) & 15) == 0, "quats / quats_n must be 16-byte aligned");
+    gg_prof_begin(GG_K_ACTIVATE_FWD, (hipStream_t)stream);
     hipLaunchKernelGGL(activate_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, means,
                        log_scales, (const float4 *)quats, opacities, cam_pos, scales, (float4 *)quats_n, opac,
                        viewdirs, normals, axis);
+    gg_prof_end(GG_K_ACTIVATE_FWD, (hipStream_t)stream);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
@@ -1087,9 +1093,11 @@ extern "C" int gg_activate_bwd_ex(int N, const float *quats, const float *scales
                    v_quats && v_opacities, "null pointer");
     GG_REQUIRE((((uintptr_t)quats | (uintptr_t)v_quats_n | (uintptr_t)v_quats) & 15) == 0,
                "quaternion arrays must be 16-byte aligned");
+    gg_prof_begin(GG_K_ACTIVATE_BWD, (hipStream_t)stream);
     hipLaunchKernelGGL(activate_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N,
                        (const float4 *)quats, scales, opac, axis, v_scales, (const float4 *)v_quats_n, v_opac,
                        v_normals, v_log_scales, (float4 *)v_quats, v_opacities, v_opac_stride, accumulate);
+    gg_prof_end(GG_K_ACTIVATE_BWD, (hipStream_t)stream);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }

@@ -14,9 +14,21 @@ from typing import List
 import torch
 
 
+_last_runs = None      # (key, mask kept alive, result): get_loss_dict asks for pairs and for points on the SAME mask
+
+
 def _label_runs(mask: torch.Tensor):
     """labels > -1 (ascending), and per label the flat indices of its pixels in row-major order (`torch.where` order)"""
-    mask = mask.detach()
+    global _last_runs
+    key = (mask.data_ptr(), mask._version, tuple(mask.shape), mask.dtype)
+    if _last_runs is not None and _last_runs[0] == key:
+        return _last_runs[2]
+    out = _label_runs_of(mask.detach())
+    _last_runs = (key, mask, out)
+    return out
+
+
+def _label_runs_of(mask: torch.Tensor):
     flat = mask.reshape(-1)
     labels, counts = torch.unique(flat, return_counts=True)
     order = torch.argsort(flat, stable=True)

@@ -486,6 +486,11 @@ int gg_adam_step(int num_groups, const gg_adam_group_t *groups, int zero_grad, g
 #define GG_K_COMPACT 26
 #define GG_K_DENSIFY 27
 #define GG_K_ADAM 28
+#define GG_K_VIEW_BWD 29      /* gg_view_bwd: the per-Gaussian backward of a view in one kernel */
+#define GG_K_ACTIVATE_FWD 30
+#define GG_K_ACTIVATE_BWD 31
+#define GG_K_COUNT 18         /* gg_count_intersects */
+#define GG_K_TAIL_SPLIT 19    /* gg_shade_tail_bwd_split */
 #define GG_PROF_NUM_KERNELS 32
 int gg_prof_enable(int on);
 int gg_prof_reset(void);

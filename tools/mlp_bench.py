@@ -19,8 +19,12 @@ PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA, dense
 HBM_PEAK_GBS = 8000.0
 mlp_mod.EXACT_ORDER = "--exact" in sys.argv
 dev = "cuda:0"
-lib = _lib.load()
+if "--lib" in sys.argv:                      # A/B: another build of the library
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
+lib = _lib.load(build_if_missing=False) if "--lib" in sys.argv else _lib.load()
 h, w, cin, cout = 1200, 1600, 32, 512
+if "--config5" in sys.argv:                  # BASELINE config 5's fea_up: 128 -> 128 -> 512 at 1920x1080
+    h, w, cin = 1080, 1920, 128
 rows = h * w
 flops = 2.0 * rows * (cin * 128 + 128 * cout)
 torch.manual_seed(0)
@@ -55,8 +59,8 @@ O.mlp_fwd(img.reshape(-1, cin)[:sample].cpu().numpy(), *[p.detach().cpu().numpy(
           (m.layers[0].weight, m.layers[0].bias, m.layers[2].weight, m.layers[2].bias)])
 cpu_s = time.perf_counter() - t0
 print(json.dumps({
-    "kernel": "mlp_fwd_kernel<32>" if mlp_mod.EXACT_ORDER else "mlp_fwd_f16_kernel<32>",
-    "workload": f"{w}x{h} pixels, 32->128->512 fp32, {flops / 1e9:.1f} GFLOP, "
+    "kernel": f"mlp_fwd_kernel<{cin}>" if mlp_mod.EXACT_ORDER else f"mlp_fwd_f16_kernel<{cin}>",
+    "workload": f"{w}x{h} pixels, {cin}->128->512 fp32, {flops / 1e9:.1f} GFLOP, "
     f"{rows * cout * 4 / 1e9:.2f} GB written",
     "ms": ours_ms,
     "roofline": ({"bound": "mfma", "achieved": flops / ours_ms / 1e9, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--skip-torch", action="store_true", help="only the fused variant (clean kernel profiles)")
     ap.add_argument("--lib", default=None, help="A/B: another build of the library")
+    ap.add_argument("--gc", default="default", choices=["default", "freeze", "off"],
+                    help="Python's cyclic collector during the timed steps: as it is, after gc.freeze() (everything "
+                         "alive after the warm-up moved out of the collector's way), or disabled")
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--height", type=int, default=1200)
     ap.add_argument("--width", type=int, default=1600)
@@ -120,9 +123,17 @@ def main():
                 o.step()
 
     def timed(fused, opts):
+        import gc
         for _ in range(a.warmup):
             iteration(fused, opts)
         torch.cuda.synchronize()
+        gc.enable()
+        gc.unfreeze()
+        if a.gc == "freeze":
+            gc.collect()
+            gc.freeze()
+        elif a.gc == "off":
+            gc.disable()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             iteration(fused, opts)
@@ -136,7 +147,7 @@ def main():
         "workload": "%d Gaussians, %dx%d, %d views per optimizer step: model(camera) + model.get_loss_dict(outputs, batch) "
                     "of the plugin's class (main / depth / normal / feature / up losses + regularisers) + backward, one "
                     "Adam step over 6 Gaussian groups + fea_up" % (a.points, w, h, a.views),
-        "steps": a.steps, "views_per_step": a.views,
+        "steps": a.steps, "views_per_step": a.views, "python_gc": a.gc,
         "fused_losses_and_adam": {"ms_per_step": round(1e3 * t_fused, 2), "views_per_s": round(a.views / t_fused, 1),
                                   "sampling": "gaussiangrasper_amd.sampling (device generator; GG_DEVICE_SAMPLING=1)"},
         "fused_losses_and_adam_reference_sampling": {

@@ -37,6 +37,9 @@ SIGNATURES = {
     "gg_last_error": (C.c_char_p, []),
     "gg_project_fwd": (_I, [_I, _P, _P, _F, _P, _P, _P, _F, _F, _F, _F, _I, _I, _I, _I, _F,
                             _P, _P, _P, _P, _P, _P, _P]),
+    "gg_project_count_workspace": (_SZ, [_I]),
+    "gg_project_fwd_count": (_I, [_I, _P, _P, _F, _P, _P, _P, _F, _F, _F, _F, _I, _I, _I, _I, _F,
+                                  _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gg_project_bwd": (_I, [_I, _P, _P, _F, _P, _P, _P, _F, _F, _F, _F, _I, _I, _P, _P, _P, _P, _P,
                             _P, _P, _P, _P]),
     "gg_project_bwd_ex": (_I, [_I, _P, _P, _F, _P, _P, _P, _F, _F, _F, _F, _I, _I, _P, _P, _P, _I, _P, _P, _I,

@@ -47,9 +47,16 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     const float *__restrict__ projmat, float fx, float fy, float cx, float cy, int img_h,
     int img_w, int tiles_x, int tiles_y, float clip_thresh, float *__restrict__ cov3d,
     float *__restrict__ xys, float *__restrict__ depths, int32_t *__restrict__ radii,
-    float *__restrict__ conics, int32_t *__restrict__ num_tiles_hit) {
+    float *__restrict__ conics, int32_t *__restrict__ num_tiles_hit,
+    unsigned *__restrict__ count_ws = nullptr) {
+    // count_ws != nullptr (gg_project_fwd_count): every workgroup leaves the sum of its num_tiles_hit in count_ws[block]
+    // and a one-workgroup kernel adds them up (r04: instead of count_kernel's pass over num_tiles_hit + an 8-byte fill,
+    // 18 us per view.  A ticket with the LAST workgroup adding up was tried first: 3 907 returning atomics on one word
+    // made the projection 0.20 ms instead of 0.02)
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    if (i >= N && count_ws == nullptr) return;
+    const bool live = i < N;
+    if (!live) i = N - 1;          // (a padding thread of the last workgroup: computes, stores nothing, counts nothing)
     float V[12], P[16];
 #pragma unroll
     for (int k = 0; k < 12; ++k) V[k] = viewmat[k];  // uniform -> scalar loads
@@ -136,15 +143,39 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
             }
         }
     }
+    if (live) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) cov3d[6 * (size_t)i + k] = o_c3[k];
-    xys[2 * (size_t)i] = o_x;
-    xys[2 * (size_t)i + 1] = o_y;
-    depths[i] = o_d;
-    radii[i] = o_r;
+        for (int k = 0; k < 6; ++k) cov3d[6 * (size_t)i + k] = o_c3[k];
+        xys[2 * (size_t)i] = o_x;
+        xys[2 * (size_t)i + 1] = o_y;
+        depths[i] = o_d;
+        radii[i] = o_r;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) conics[3 * (size_t)i + k] = o_con[k];
-    num_tiles_hit[i] = o_n;
+        for (int k = 0; k < 3; ++k) conics[3 * (size_t)i + k] = o_con[k];
+        num_tiles_hit[i] = o_n;
+    }
+    if (count_ws == nullptr) return;
+    __shared__ unsigned s_part[4];
+    unsigned mine = live ? (unsigned)o_n : 0u;
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) count_ws[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+// one workgroup: the partial sums of project_fwd_kernel's workgroups -> *count_out
+__global__ __launch_bounds__(1024) void count_finish_kernel(int nparts, const unsigned *__restrict__ parts,
+                                                            unsigned long long *__restrict__ count_out) {
+    __shared__ unsigned long long s_tot[16];
+    unsigned long long acc = 0;
+    for (int b = threadIdx.x; b < nparts; b += 1024) acc += parts[b];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) s_tot[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < 16; ++w) t += s_tot[w];
+        *count_out = t;
+    }
 }
 
 // the backward of one visible Gaussian: cotangents (v_xy, v_depth, v_conic) -> vm += d/d mean, vs = d/d scale,
@@ -498,6 +529,48 @@ extern "C" int gg_project_fwd(int N, const float *means3d, const float *scales, 
                        projmat, fx, fy, cx, cy, img_height, img_width, tiles_x, tiles_y,
                        clip_thresh, cov3d, xys, depths, radii, conics, num_tiles_hit);
     gg_prof_end(GG_K_PROJECT_FWD, (hipStream_t)stream);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+extern "C" size_t gg_project_count_workspace(int N) { return sizeof(unsigned) * (size_t)(N > 0 ? (N + 255) / 256 : 1); }
+extern "C" int gg_project_fwd_count(int N, const float *means3d, const float *scales, float glob_scale,
+                                    const float *quats, const float *viewmat, const float *projmat,
+                                    float fx, float fy, float cx, float cy, int img_height,
+                                    int img_width, int tiles_x, int tiles_y, float clip_thresh,
+                                    float *cov3d, float *xys, float *depths, int32_t *radii,
+                                    float *conics, int32_t *num_tiles_hit, int64_t *num_intersects_out,
+                                    void *count_ws, size_t count_ws_bytes, gg_stream_t stream) {
+    GG_REQUIRE(N >= 0, "num_points < 0");
+    GG_REQUIRE(img_height > 0 && img_width > 0, "empty image");
+    GG_REQUIRE(tiles_x == (img_width + GG_BLOCK - 1) / GG_BLOCK &&
+                   tiles_y == (img_height + GG_BLOCK - 1) / GG_BLOCK,
+               "tile_bounds must be ceil(W/16), ceil(H/16)");
+    GG_REQUIRE(num_intersects_out != nullptr, "null num_intersects_out");
+    if (N == 0) {
+        if (gg_fill_async(num_intersects_out, 0, sizeof(int64_t), (hipStream_t)stream) != hipSuccess) {
+            gg_set_error("gg_project_fwd_count: memset failed");
+            return GG_ERR_LAUNCH;
+        }
+        return GG_OK;
+    }
+    GG_REQUIRE(means3d && scales && quats && viewmat && projmat && cov3d && xys && depths &&
+                   radii && conics && num_tiles_hit,
+               "null pointer");
+    if (count_ws == nullptr || count_ws_bytes < gg_project_count_workspace(N) || ((uintptr_t)count_ws & 3)) {
+        gg_set_error("gg_project_fwd_count: count workspace of gg_project_count_workspace() bytes expected");
+        return GG_ERR_WORKSPACE;
+    }
+    gg_prof_begin(GG_K_PROJECT_FWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(project_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, N, means3d, scales, glob_scale, quats, viewmat,
+                       projmat, fx, fy, cx, cy, img_height, img_width, tiles_x, tiles_y,
+                       clip_thresh, cov3d, xys, depths, radii, conics, num_tiles_hit, (unsigned *)count_ws);
+    gg_prof_end(GG_K_PROJECT_FWD, (hipStream_t)stream);
+    gg_prof_begin(GG_K_COUNT, (hipStream_t)stream);
+    hipLaunchKernelGGL(count_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (N + 255) / 256,
+                       (const unsigned *)count_ws, (unsigned long long *)num_intersects_out);
+    gg_prof_end(GG_K_COUNT, (hipStream_t)stream);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }

@@ -140,7 +140,8 @@ _pin_ring = {}          # device index -> (pinned int64[_PIN_SLOTS], next slot)
 _pending_counts = {}    # (data_ptr, version) of num_tiles_hit -> (event, pinned view, keep-alive)
 
 
-def _start_count(num_tiles_hit: Tensor) -> None:
+def _start_count(num_tiles_hit: Tensor, total: Optional[Tensor] = None) -> None:
+    """total: the count already on its way (gg_project_fwd_count left it there); None: count with a launch of its own"""
     dev = num_tiles_hit.device
     lib = _lib.load()
     ring, nxt = _pin_ring.get(dev.index, (None, 0))
@@ -148,9 +149,10 @@ def _start_count(num_tiles_hit: Tensor) -> None:
         ring = torch.empty(_PIN_SLOTS, dtype=torch.int64).pin_memory()
     slot = ring[nxt:nxt + 1]
     _pin_ring[dev.index] = (ring, (nxt + 1) % _PIN_SLOTS)
-    total = torch.empty(1, dtype=torch.int64, device=dev)
-    _lib.check(lib.gg_count_intersects(num_tiles_hit.shape[0], _ptr(num_tiles_hit), _ptr(total), None, 0,
-                                       _stream(dev)), "gg_count_intersects")
+    if total is None:
+        total = torch.empty(1, dtype=torch.int64, device=dev)
+        _lib.check(lib.gg_count_intersects(num_tiles_hit.shape[0], _ptr(num_tiles_hit), _ptr(total), None, 0,
+                                           _stream(dev)), "gg_count_intersects")
     slot.copy_(total, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
@@ -212,17 +214,20 @@ class ProjectGaussians(Function):
         radii = torch.empty(n, dtype=torch.int32, device=dev)
         conics = torch.empty(n, 3, dtype=torch.float32, device=dev)
         num_tiles_hit = torch.empty(n, dtype=torch.int32, device=dev)
-        _lib.check(lib.gg_project_fwd(
+        # the projection also leaves sum(num_tiles_hit) on the device (one launch instead of projection + count + fill)
+        total = torch.empty(1, dtype=torch.int64, device=dev)
+        cws = torch.empty(max(lib.gg_project_count_workspace(n) // 4, 1), dtype=torch.int32, device=dev)
+        _lib.check(lib.gg_project_fwd_count(
             n, _ptr(means3d), _ptr(scales), float(glob_scale), _ptr(quats), _ptr(viewmat),
             _ptr(projmat), float(fx), float(fy), float(cx), float(cy), int(img_height),
             int(img_width), int(tile_bounds[0]), int(tile_bounds[1]), float(clip_thresh),
-            _ptr(cov3d), _ptr(xys), _ptr(depths), _ptr(radii), _ptr(conics), _ptr(num_tiles_hit),
-            _stream(dev)), "gg_project_fwd")
+            _ptr(cov3d), _ptr(xys), _ptr(depths), _ptr(radii), _ptr(conics), _ptr(num_tiles_hit), _ptr(total),
+            _ptr(cws), cws.numel() * 4, _stream(dev)), "gg_project_fwd_count")
         ctx.scalars = (float(glob_scale), float(fx), float(fy), float(cx), float(cy),
                        int(img_height), int(img_width))
         ctx.save_for_backward(means3d, scales, quats, viewmat, projmat, radii, conics)
         ctx.mark_non_differentiable(radii, num_tiles_hit)
-        _start_count(num_tiles_hit)
+        _start_count(num_tiles_hit, total)
         return xys, depths, radii, conics, num_tiles_hit, cov3d
 
     @staticmethod

@@ -56,6 +56,18 @@ int gg_project_fwd(int num_points, const float *means3d, const float *scales, fl
                    int tiles_y, float clip_thresh, float *cov3d, float *xys, float *depths,
                    int32_t *radii, float *conics, int32_t *num_tiles_hit, gg_stream_t stream);
 
+/* gg_project_fwd that also leaves sum(num_tiles_hit) in *num_intersects_out (device, int64) — what gg_count_intersects
+ * computes with a launch of its own (reference: `torch.cumsum(num_tiles_hit)[-1].item()` inside every rasterize call).
+ * count_ws: gg_project_count_workspace(num_points) bytes of scratch, 4-byte aligned (per-workgroup partial sums, added
+ * up by a one-workgroup launch behind the projection). */
+size_t gg_project_count_workspace(int num_points);
+int gg_project_fwd_count(int num_points, const float *means3d, const float *scales, float glob_scale,
+                         const float *quats, const float *viewmat, const float *projmat, float fx, float fy,
+                         float cx, float cy, int img_height, int img_width, int tiles_x, int tiles_y,
+                         float clip_thresh, float *cov3d, float *xys, float *depths, int32_t *radii, float *conics,
+                         int32_t *num_tiles_hit, int64_t *num_intersects_out, void *count_ws, size_t count_ws_bytes,
+                         gg_stream_t stream);
+
 /* Replaces gsplat `_C.project_gaussians_backward` (ProjectGaussians.backward).  v_conic uses
  * gsplat's symmetric-matrix convention (v_conic[:,1] is half of dL/d conic.y).  Outputs fully
  * written (zeros where radii<=0). */

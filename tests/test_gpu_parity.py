@@ -1543,3 +1543,31 @@ def test_shade_tail_and_split_segments_edge_cases():
     assert torch.equal(normal, bg[4:].expand(h, w, 3)) and not f_im.any()
     (rgb.sum() + normal.sum()).backward()
     assert not feat.grad.any() and not tail.grad.any()
+
+
+@pytest.mark.parametrize("n", [1, 255, 256, 257, 10_000, 333_333])
+def test_projection_leaves_the_intersection_count(n):
+    """gg_project_fwd_count (round 4): the projection leaves sum(num_tiles_hit) on the device — partial sums per
+    workgroup, added up by a one-workgroup launch — instead of a pass over num_tiles_hit and a fill.  Equal to the sum of
+    the tile counts for ragged sizes, on repeated launches and for launches on two streams at once."""
+    from gaussiangrasper_amd.scene import make_scene as mk
+    sc = mk(n, feature_dim=8, config_index=2).to(DEV)
+    views = ring_cameras(3, 240, 320, device=DEV)
+
+    def project(v):
+        return P.ProjectGaussians.apply(sc.means.detach(), sc.scales.detach().exp() * 3.0, 1, sc.quats.detach(),
+                                        v.viewmat[:3], v.projmat, v.fx, v.fy, v.cx, v.cy, 240, 320, v.tile_bounds)
+    for rep in range(4):
+        out = project(views[rep % 3])
+        nth = out[4]
+        got = P._take_count(nth)
+        assert got == int(nth.long().sum()), (n, rep)
+    s1, s2 = torch.cuda.Stream(device=DEV), torch.cuda.Stream(device=DEV)
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(6):
+        with torch.cuda.stream(s1 if rep % 2 == 0 else s2):
+            outs.append(project(views[rep % 3]))
+    torch.cuda.synchronize()
+    for o in outs:
+        assert P._take_count(o[4]) == int(o[4].long().sum())

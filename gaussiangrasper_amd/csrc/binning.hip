@@ -296,14 +296,19 @@ struct DbRange {
     uint32_t kmin;
     u64 mul;   // bucket = ((bits - kmin) * mul) >> 32
 };
-// (every workgroup reduces the 256 partial pairs itself: 2 KB from L2)
-__device__ __forceinline__ DbRange db_range_of(const uint32_t *__restrict__ mm, int nb, uint32_t *s_mm /*[2]*/) {
+// partial minima / maxima of the visible depth bits: db_range_kernel's 256 pairs, or the per-workgroup ones the caller's
+// projection left behind (gg_view_fwd -> gg_bin_sort_dev_ex); every workgroup reduces them itself (a few KB from L2)
+struct DbParts {
+    const uint32_t *lo, *hi;
+    int n;
+};
+__device__ __forceinline__ DbRange db_range_of(const DbParts mm, int nb, uint32_t *s_mm /*[2]*/) {
     const int tid = threadIdx.x;
     if (tid < 64) {
         uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-        for (int i = tid; i < 256; i += 64) {
-            lo = min(lo, mm[2 * i]);
-            hi = max(hi, mm[2 * i + 1]);
+        for (int i = tid; i < mm.n; i += 64) {
+            lo = min(lo, mm.lo[i]);
+            hi = max(hi, mm.hi[i]);
         }
         for (int off = 32; off > 0; off >>= 1) {
             lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
@@ -342,8 +347,8 @@ __global__ __launch_bounds__(256) void db_range_kernel(int N, DepthSrc dsrc, uin
     if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        mm[2 * blockIdx.x] = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
-        mm[2 * blockIdx.x + 1] = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+        mm[blockIdx.x] = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
+        mm[gridDim.x + blockIdx.x] = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
     }
 }
 // What travels with a Gaussian through the bucket sort: {depth bits, id, tiles hit, tile box}.  The box — x0 | y0 << 10 |
@@ -372,7 +377,7 @@ __device__ __forceinline__ void db_box(const DbGeom g, const DepthSrc d, int i, 
 // SCATTER false: G[block][bucket] = the block's count; true: G holds the block's first position in each bucket
 template <bool SCATTER>
 __global__ __launch_bounds__(DB_THREADS) void db_walk_kernel(int N, int nb, DepthSrc dsrc, DbGeom geom,
-                                                             const uint32_t *__restrict__ mm, uint32_t *__restrict__ G,
+                                                             const DbParts mm, uint32_t *__restrict__ G,
                                                              const uint32_t *__restrict__ start, uint4 *__restrict__ recs) {
     extern __shared__ uint32_t s_hist[];   // nb + 1 counters (SCATTER: cursors), then the range
     uint32_t *s_mm = s_hist + nb + 1;
@@ -901,7 +906,7 @@ struct BinWs {
     uint32_t *dbG;                            // DB_BLOCKS x (buckets + 1)
     uint32_t *dbStart;                        // buckets + 2: bucket totals -> starts; [buckets] = the visible count
     uint32_t *dbBase;                         // buckets + 1: bucket sums of num_tiles_hit -> offsets
-    uint32_t *dbmm;                           // 2 x 256: partial min / max of the depth bits
+    uint32_t *dbmm;                           // 256 + 256: partial minima | maxima of the depth bits
     size_t bytes;
 };
 static BinWs bin_ws_layout(void *ws, int N, int64_t I) {
@@ -957,7 +962,8 @@ static void radix_pass(int64_t n, const int64_t *n_dev, const uint32_t *kin, con
 static int bin_sort_impl(int N, int64_t I, const int64_t *I_dev, const float *xys, const float *depths,
                          const int32_t *radii, const int32_t *num_tiles_hit, int tiles_x, int tiles_y,
                          int32_t *gaussian_ids_sorted, int32_t *tile_bins, int32_t *isect_tile_sorted,
-                         void *ws, size_t ws_bytes, gg_stream_t stream) {
+                         void *ws, size_t ws_bytes, gg_stream_t stream, const uint32_t *range_lo = nullptr,
+                         const uint32_t *range_hi = nullptr, int range_parts = 0) {
     GG_REQUIRE(N >= 0 && I >= 0, "negative size");
     GG_REQUIRE(tiles_x > 0 && tiles_y > 0, "empty tile grid");
     GG_REQUIRE(tiles_x <= DB_BOX_MAX && tiles_y <= DB_BOX_MAX, "tile grid beyond 1023 x 1023 (images beyond 16 368 pixels a side)");
@@ -986,13 +992,17 @@ static int bin_sort_impl(int N, int64_t I, const int64_t *I_dev, const float *xy
         (void)hipFuncSetAttribute((const void *)db_walk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds);
     }
     uint32_t *order = w.order;
-    hipLaunchKernelGGL(db_range_kernel, dim3(256), dim3(256), 0, s, N, dsrc, w.dbmm);
+    DbParts mm{w.dbmm, w.dbmm + 256, 256};
+    if (range_lo && range_hi && range_parts > 0)      // the caller's projection left the partial minima / maxima behind
+        mm = DbParts{range_lo, range_hi, range_parts};
+    else
+        hipLaunchKernelGGL(db_range_kernel, dim3(256), dim3(256), 0, s, N, dsrc, w.dbmm);
     const DbGeom geom{xys, tiles_x, tiles_y};
-    hipLaunchKernelGGL(db_walk_kernel<false>, dim3(DB_BLOCKS), dim3(DB_THREADS), walk_lds, s, N, nbk, dsrc, geom, w.dbmm,
+    hipLaunchKernelGGL(db_walk_kernel<false>, dim3(DB_BLOCKS), dim3(DB_THREADS), walk_lds, s, N, nbk, dsrc, geom, mm,
                        w.dbG, (const uint32_t *)nullptr, (uint4 *)nullptr);
     hipLaunchKernelGGL(db_prefix_kernel, dim3((nbk + 1 + 255) / 256), dim3(256), 0, s, nbk, w.dbG, w.dbStart);
     hipLaunchKernelGGL(db_scan_kernel, dim3(1), dim3(1024), 0, s, nbk, w.dbStart);   // (-> [nbk] = the visible count)
-    hipLaunchKernelGGL(db_walk_kernel<true>, dim3(DB_BLOCKS), dim3(DB_THREADS), walk_lds, s, N, nbk, dsrc, geom, w.dbmm,
+    hipLaunchKernelGGL(db_walk_kernel<true>, dim3(DB_BLOCKS), dim3(DB_THREADS), walk_lds, s, N, nbk, dsrc, geom, mm,
                        w.dbG, (const uint32_t *)w.dbStart, w.recs);
     hipLaunchKernelGGL(db_sort_kernel, dim3((nbk + DB_WPB - 1) / DB_WPB), dim3(64 * DB_WPB), 0, s, N, nbk,
                        (const uint32_t *)w.dbStart, (const uint4 *)w.recs, w.pairs, dsrc, geom, order, w.einfo, w.dbBase);
@@ -1065,6 +1075,23 @@ extern "C" int gg_bin_sort_dev(int N, int64_t capacity, const int64_t *num_inter
     GG_REQUIRE(capacity >= 1, "capacity < 1");
     return bin_sort_impl(N, capacity, num_intersects_dev, xys, depths, radii, num_tiles_hit, tiles_x,
                          tiles_y, gaussian_ids_sorted, tile_bins, isect_tile_sorted, ws, ws_bytes, stream);
+}
+
+// gg_bin_sort_dev with the partial minima / maxima of the visible depth bits handed over (gg_view_fwd's `parts`: one
+// pair per 256 Gaussians) — the depth buckets' range pass over depths and radii is not run
+extern "C" int gg_bin_sort_dev_ex(int N, int64_t capacity, const int64_t *num_intersects_dev,
+                                  const float *xys, const float *depths, const int32_t *radii,
+                                  const int32_t *num_tiles_hit, int tiles_x, int tiles_y,
+                                  int32_t *gaussian_ids_sorted, int32_t *tile_bins,
+                                  int32_t *isect_tile_sorted, void *ws, size_t ws_bytes,
+                                  const uint32_t *depth_bits_min, const uint32_t *depth_bits_max, int range_parts,
+                                  gg_stream_t stream) {
+    GG_REQUIRE(num_intersects_dev != nullptr, "null num_intersects_dev");
+    GG_REQUIRE(capacity >= 1, "capacity < 1");
+    GG_REQUIRE(range_parts == 0 || (depth_bits_min && depth_bits_max && range_parts > 0), "range parts without arrays");
+    return bin_sort_impl(N, capacity, num_intersects_dev, xys, depths, radii, num_tiles_hit, tiles_x,
+                         tiles_y, gaussian_ids_sorted, tile_bins, isect_tile_sorted, ws, ws_bytes, stream,
+                         depth_bits_min, depth_bits_max, range_parts);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -101,6 +101,7 @@ extern "C" const char *gg_prof_name(int id) {
         case GG_K_DENSIFY: return "densify_rows_kernel";
         case GG_K_ADAM: return "adam_kernel";
         case GG_K_VIEW_BWD: return "view_bwd_kernel";
+        case GG_K_VIEW_FWD: return "view_fwd_kernel";
         case GG_K_ACTIVATE_FWD: return "activate_fwd_kernel";
         case GG_K_ACTIVATE_BWD: return "activate_bwd_kernel";
         case GG_K_COUNT: return "count_kernel";

@@ -41,43 +41,19 @@ __device__ __forceinline__ void quat_to_R(const float4 q, float *R, float *qn, f
     qn[3] = z;
 }
 
-__global__ __launch_bounds__(256) void project_fwd_kernel(
-    int N, const float *__restrict__ means, const float *__restrict__ scales, float glob_scale,
-    const float *__restrict__ quats, const float *__restrict__ viewmat,
-    const float *__restrict__ projmat, float fx, float fy, float cx, float cy, int img_h,
-    int img_w, int tiles_x, int tiles_y, float clip_thresh, float *__restrict__ cov3d,
-    float *__restrict__ xys, float *__restrict__ depths, int32_t *__restrict__ radii,
-    float *__restrict__ conics, int32_t *__restrict__ num_tiles_hit,
-    unsigned *__restrict__ count_ws = nullptr) {
-    // count_ws != nullptr (gg_project_fwd_count): every workgroup leaves the sum of its num_tiles_hit in count_ws[block]
-    // and a one-workgroup kernel adds them up (r04: instead of count_kernel's pass over num_tiles_hit + an 8-byte fill,
-    // 18 us per view.  A ticket with the LAST workgroup adding up was tried first: 3 907 returning atomics on one word
-    // made the projection 0.20 ms instead of 0.02)
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N && count_ws == nullptr) return;
-    const bool live = i < N;
-    if (!live) i = N - 1;          // (a padding thread of the last workgroup: computes, stores nothing, counts nothing)
-    float V[12], P[16];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) V[k] = viewmat[k];  // uniform -> scalar loads
-#pragma unroll
-    for (int k = 0; k < 16; ++k) P[k] = projmat[k];
-
-    float o_c3[6] = {0, 0, 0, 0, 0, 0};
-    float o_con[3] = {0, 0, 0};
-    float o_x = 0, o_y = 0, o_d = 0;
-    int o_r = 0, o_n = 0;
-
-    float px = means[3 * i], py = means[3 * i + 1], pz = means[3 * i + 2];
+// projection of one Gaussian (mean p, normalised-or-not quaternion q, scales s already times glob_scale): shared by
+// project_fwd_kernel and view_fwd_kernel (one operation sequence, one result)
+__device__ __forceinline__ void project_fwd_point(
+    const float px, const float py, const float pz, const float4 q, const float s0, const float s1, const float s2,
+    const float (&V)[12], const float (&P)[16], const float fx, const float fy, const float cx, const float cy,
+    const int img_h, const int img_w, const int tiles_x, const int tiles_y, const float clip_thresh, float (&o_c3)[6],
+    float (&o_con)[3], float &o_x, float &o_y, float &o_d, int &o_r, int &o_n) {
     float tx = ((V[0] * px + V[1] * py) + V[2] * pz) + V[3];
     float ty = ((V[4] * px + V[5] * py) + V[6] * pz) + V[7];
     float tz = ((V[8] * px + V[9] * py) + V[10] * pz) + V[11];
     if (tz > clip_thresh) {
         float R[9], qn[4], inv;
-        float4 q = reinterpret_cast<const float4 *>(quats)[i];
         quat_to_R(q, R, qn, inv);
-        float s0 = glob_scale * scales[3 * i], s1 = glob_scale * scales[3 * i + 1],
-              s2 = glob_scale * scales[3 * i + 2];
         float M[9] = {R[0] * s0, R[1] * s1, R[2] * s2, R[3] * s0, R[4] * s1,
                       R[5] * s2, R[6] * s0, R[7] * s1, R[8] * s2};
         float c3[6];
@@ -143,6 +119,38 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
             }
         }
     }
+}
+__global__ __launch_bounds__(256) void project_fwd_kernel(
+    int N, const float *__restrict__ means, const float *__restrict__ scales, float glob_scale,
+    const float *__restrict__ quats, const float *__restrict__ viewmat,
+    const float *__restrict__ projmat, float fx, float fy, float cx, float cy, int img_h,
+    int img_w, int tiles_x, int tiles_y, float clip_thresh, float *__restrict__ cov3d,
+    float *__restrict__ xys, float *__restrict__ depths, int32_t *__restrict__ radii,
+    float *__restrict__ conics, int32_t *__restrict__ num_tiles_hit,
+    unsigned *__restrict__ count_ws = nullptr) {
+    // count_ws != nullptr (gg_project_fwd_count): every workgroup leaves the sum of its num_tiles_hit in count_ws[block]
+    // and a one-workgroup kernel adds them up (r04: instead of count_kernel's pass over num_tiles_hit + an 8-byte fill,
+    // 18 us per view.  A ticket with the LAST workgroup adding up was tried first: 3 907 returning atomics on one word
+    // made the projection 0.20 ms instead of 0.02)
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N && count_ws == nullptr) return;
+    const bool live = i < N;
+    if (!live) i = N - 1;          // (a padding thread of the last workgroup: computes, stores nothing, counts nothing)
+    float V[12], P[16];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) V[k] = viewmat[k];  // uniform -> scalar loads
+#pragma unroll
+    for (int k = 0; k < 16; ++k) P[k] = projmat[k];
+
+    float o_c3[6] = {0, 0, 0, 0, 0, 0};
+    float o_con[3] = {0, 0, 0};
+    float o_x = 0, o_y = 0, o_d = 0;
+    int o_r = 0, o_n = 0;
+
+    const float px = means[3 * i], py = means[3 * i + 1], pz = means[3 * i + 2];
+    project_fwd_point(px, py, pz, reinterpret_cast<const float4 *>(quats)[i], glob_scale * scales[3 * i],
+                      glob_scale * scales[3 * i + 1], glob_scale * scales[3 * i + 2], V, P, fx, fy, cx, cy, img_h, img_w,
+                      tiles_x, tiles_y, clip_thresh, o_c3, o_con, o_x, o_y, o_d, o_r, o_n);
     if (live) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) cov3d[6 * (size_t)i + k] = o_c3[k];
@@ -988,6 +996,140 @@ __global__ __launch_bounds__(256) void activate_fwd_kernel(
         viewdirs[3 * (size_t)i + k] = d[k] / dn;
         normals[3 * (size_t)i + k] = col[k];
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// activate_fwd_kernel + project_fwd_kernel in one pass over the Gaussians (round 4, ops.ViewGeometry): the activated
+// scales and the normalised quaternion go from the activation to the projection in registers (they are still written:
+// the backward reads them), cov3d is not written at all (nothing of the plugin route reads it), and every workgroup
+// leaves three partial results behind — the sum of its num_tiles_hit (count_finish_kernel adds them up) and the smallest
+// and largest depth bits of its visible Gaussians (what gg_bin_sort's depth buckets need: db_range_kernel's pass saved).
+// The per-Gaussian arithmetic is the two kernels': same operation sequence, same bits.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void view_fwd_kernel(
+    int N, const float *__restrict__ means, const float *__restrict__ log_scales, const float4 *__restrict__ quats,
+    const float *__restrict__ opacities, const float *__restrict__ cam_pos, const float *__restrict__ viewmat,
+    const float *__restrict__ projmat, float fx, float fy, float cx, float cy, int img_h, int img_w, int tiles_x,
+    int tiles_y, float clip_thresh, float *__restrict__ scales, float4 *__restrict__ quats_n, float *__restrict__ opac,
+    float *__restrict__ viewdirs, float *__restrict__ normals, int32_t *__restrict__ axis, float *__restrict__ xys,
+    float *__restrict__ depths, int32_t *__restrict__ radii, float *__restrict__ conics,
+    int32_t *__restrict__ num_tiles_hit, unsigned *__restrict__ parts /* [3][workgroups]: sum, min bits, max bits */) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < N;
+    if (!live) i = N - 1;          // (a padding thread of the last workgroup: computes, stores and counts nothing)
+    float V[12], P[16];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) V[k] = viewmat[k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) P[k] = projmat[k];
+    // ---- activations (activate_fwd_kernel)
+    float e[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) e[k] = expf(log_scales[3 * (size_t)i + k]);
+    int ax = 0;                                   // first minimum, as torch.min(dim) reports it
+    if (e[1] < e[ax]) ax = 1;
+    if (e[2] < e[ax]) ax = 2;
+    const float4 q = quats[i];
+    const float n = sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
+    const float4 qn = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);           // :703 (no eps, as the reference)
+    float w, x, y, z;
+    quat_normalise(q, w, x, y, z);                                                 // F.normalize inside quat_to_rotmat
+    float col[3];
+    if (ax == 0) { col[0] = 1.0f - 2.0f * (y * y + z * z); col[1] = 2.0f * (x * y + w * z); col[2] = 2.0f * (x * z - w * y); }
+    else if (ax == 1) { col[0] = 2.0f * (x * y - w * z); col[1] = 1.0f - 2.0f * (x * x + z * z); col[2] = 2.0f * (y * z + w * x); }
+    else { col[0] = 2.0f * (x * z + w * y); col[1] = 2.0f * (y * z - w * x); col[2] = 1.0f - 2.0f * (x * x + y * y); }
+    const float op = 1.0f / (1.0f + expf(-opacities[i]));
+    const float px = means[3 * (size_t)i], py = means[3 * (size_t)i + 1], pz = means[3 * (size_t)i + 2];
+    float d[3] = {px - cam_pos[0], py - cam_pos[1], pz - cam_pos[2]};
+    float dn = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dn += d[k] * d[k];
+    dn = sqrtf(dn);
+    // ---- projection (project_fwd_kernel with glob_scale 1)
+    float o_c3[6] = {0, 0, 0, 0, 0, 0}, o_con[3] = {0, 0, 0};
+    float o_x = 0, o_y = 0, o_d = 0;
+    int o_r = 0, o_n = 0;
+    project_fwd_point(px, py, pz, qn, 1.0f * e[0], 1.0f * e[1], 1.0f * e[2], V, P, fx, fy, cx, cy, img_h, img_w, tiles_x,
+                      tiles_y, clip_thresh, o_c3, o_con, o_x, o_y, o_d, o_r, o_n);
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            scales[3 * (size_t)i + k] = e[k];
+            viewdirs[3 * (size_t)i + k] = d[k] / dn;
+            normals[3 * (size_t)i + k] = col[k];
+            conics[3 * (size_t)i + k] = o_con[k];
+        }
+        axis[i] = ax;
+        quats_n[i] = qn;
+        opac[i] = op;
+        xys[2 * (size_t)i] = o_x;
+        xys[2 * (size_t)i + 1] = o_y;
+        depths[i] = o_d;
+        radii[i] = o_r;
+        num_tiles_hit[i] = o_n;
+    }
+    // ---- the workgroup's partial results
+    __shared__ unsigned s_sum[4], s_lo[4], s_hi[4];
+    const bool vis = live && o_r > 0;
+    unsigned mine = live ? (unsigned)o_n : 0u;
+    unsigned lo = vis ? __builtin_bit_cast(unsigned, o_d) : 0xFFFFFFFFu, hi = vis ? __builtin_bit_cast(unsigned, o_d) : 0u;
+    for (int off = 32; off > 0; off >>= 1) {
+        mine += __shfl_down(mine, off, 64);
+        lo = min(lo, (unsigned)__shfl_down((int)lo, off, 64));
+        hi = max(hi, (unsigned)__shfl_down((int)hi, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_sum[threadIdx.x >> 6] = mine;
+        s_lo[threadIdx.x >> 6] = lo;
+        s_hi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        parts[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        parts[gridDim.x + blockIdx.x] = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
+        parts[2 * gridDim.x + blockIdx.x] = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+    }
+}
+extern "C" size_t gg_view_fwd_workspace(int N) { return sizeof(unsigned) * 3 * (size_t)(N > 0 ? (N + 255) / 256 : 1); }
+extern "C" int gg_view_fwd(int N, const float *means, const float *log_scales, const float *quats, const float *opacities,
+                           const float *cam_pos, const float *viewmat, const float *projmat, float fx, float fy, float cx,
+                           float cy, int img_height, int img_width, int tiles_x, int tiles_y, float clip_thresh,
+                           float *scales, float *quats_n, float *opac, float *viewdirs, float *normals, int32_t *axis,
+                           float *xys, float *depths, int32_t *radii, float *conics, int32_t *num_tiles_hit,
+                           int64_t *num_intersects_out, void *parts, size_t parts_bytes, gg_stream_t stream) {
+    GG_REQUIRE(N >= 0, "num_points < 0");
+    GG_REQUIRE(img_height > 0 && img_width > 0, "empty image");
+    GG_REQUIRE(tiles_x == (img_width + GG_BLOCK - 1) / GG_BLOCK && tiles_y == (img_height + GG_BLOCK - 1) / GG_BLOCK,
+               "tile_bounds must be ceil(W/16), ceil(H/16)");
+    GG_REQUIRE(num_intersects_out != nullptr, "null num_intersects_out");
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) {
+        if (gg_fill_async(num_intersects_out, 0, sizeof(int64_t), s) != hipSuccess) {
+            gg_set_error("gg_view_fwd: memset failed");
+            return GG_ERR_LAUNCH;
+        }
+        return GG_OK;
+    }
+    GG_REQUIRE(means && log_scales && quats && opacities && cam_pos && viewmat && projmat && scales && quats_n && opac &&
+                   viewdirs && normals && axis && xys && depths && radii && conics && num_tiles_hit, "null pointer");
+    GG_REQUIRE((((uintptr_t)quats | (uintptr_t)quats_n) & 15) == 0, "quats / quats_n must be 16-byte aligned");
+    if (parts == nullptr || parts_bytes < gg_view_fwd_workspace(N) || ((uintptr_t)parts & 3)) {
+        gg_set_error("gg_view_fwd: partial-result array of gg_view_fwd_workspace() bytes expected");
+        return GG_ERR_WORKSPACE;
+    }
+    const int blocks = (N + 255) / 256;
+    gg_prof_begin(GG_K_VIEW_FWD, s);
+    hipLaunchKernelGGL(view_fwd_kernel, dim3(blocks), dim3(256), 0, s, N, means, log_scales, (const float4 *)quats,
+                       opacities, cam_pos, viewmat, projmat, fx, fy, cx, cy, img_height, img_width, tiles_x, tiles_y,
+                       clip_thresh, scales, (float4 *)quats_n, opac, viewdirs, normals, axis, xys, depths, radii, conics,
+                       num_tiles_hit, (unsigned *)parts);
+    gg_prof_end(GG_K_VIEW_FWD, s);
+    gg_prof_begin(GG_K_COUNT, s);
+    hipLaunchKernelGGL(count_finish_kernel, dim3(1), dim3(1024), 0, s, blocks, (const unsigned *)parts,
+                       (unsigned long long *)num_intersects_out);
+    gg_prof_end(GG_K_COUNT, s);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
 }
 
 // the backward of one Gaussian's activations: (v_scales, v_quats_n, v_opac, v_normals) -> gradients of the log

@@ -140,8 +140,9 @@ _pin_ring = {}          # device index -> (pinned int64[_PIN_SLOTS], next slot)
 _pending_counts = {}    # (data_ptr, version) of num_tiles_hit -> (event, pinned view, keep-alive)
 
 
-def _start_count(num_tiles_hit: Tensor, total: Optional[Tensor] = None) -> None:
-    """total: the count already on its way (gg_project_fwd_count left it there); None: count with a launch of its own"""
+def _start_count(num_tiles_hit: Tensor, total: Optional[Tensor] = None, depth_parts=None) -> None:
+    """total: the count already on its way (gg_project_fwd_count / gg_view_fwd left it there); None: count with a launch of
+    its own.  depth_parts: (min bits, max bits, number of pairs) gg_view_fwd left behind, for gg_bin_sort_dev_ex"""
     dev = num_tiles_hit.device
     lib = _lib.load()
     ring, nxt = _pin_ring.get(dev.index, (None, 0))
@@ -158,7 +159,7 @@ def _start_count(num_tiles_hit: Tensor, total: Optional[Tensor] = None) -> None:
     ev.record(torch.cuda.current_stream(dev))
     if len(_pending_counts) > 8:      # views whose count was never consumed
         _pending_counts.clear()
-    _pending_counts[(num_tiles_hit.data_ptr(), num_tiles_hit._version)] = (ev, slot, num_tiles_hit, total)
+    _pending_counts[(num_tiles_hit.data_ptr(), num_tiles_hit._version)] = (ev, slot, num_tiles_hit, total, depth_parts)
 
 
 def _pending(num_tiles_hit: Tensor):
@@ -173,7 +174,7 @@ def _take_count(num_tiles_hit: Tensor):
     if hit is None:
         return None
     _pending_counts.pop((num_tiles_hit.data_ptr(), num_tiles_hit._version), None)
-    ev, slot, _, _ = hit
+    ev, slot = hit[0], hit[1]
     ev.synchronize()
     return int(slot.item())
 
@@ -499,9 +500,12 @@ def bin_and_sort_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, num_tiles
         total_dev = pending[3]
         ids = torch.empty(cap, dtype=torch.int32, device=dev)
         ws = _workspace(lib.gg_bin_sort_workspace(n, cap), dev)
-        _lib.check(lib.gg_bin_sort_dev(n, cap, _ptr(total_dev), _ptr(xys_c), _ptr(depths_c), _ptr(radii_c),
-                                       _ptr(nth_c), tiles_x, tiles_y, _ptr(ids), _ptr(tile_bins),
-                                       None, _ptr(ws), ws.numel(), _stream(dev)), "gg_bin_sort_dev")
+        parts = pending[4]                # (min bits, max bits, pairs) from the projection, or None
+        _lib.check(lib.gg_bin_sort_dev_ex(n, cap, _ptr(total_dev), _ptr(xys_c), _ptr(depths_c), _ptr(radii_c),
+                                          _ptr(nth_c), tiles_x, tiles_y, _ptr(ids), _ptr(tile_bins),
+                                          None, _ptr(ws), ws.numel(), _ptr(parts[0]) if parts else None,
+                                          _ptr(parts[1]) if parts else None, parts[2] if parts else 0, _stream(dev)),
+                   "gg_bin_sort_dev_ex")
 
         def redo(b: Binning) -> bool:
             count = _take_count(num_tiles_hit)
@@ -825,10 +829,9 @@ class ViewGeometry(Function):
                 img_height, img_width, tile_bounds, degrees_to_use):
         ctx.set_materialize_grads(False)
         a, p, t = _PartCtx(), _PartCtx(), _PartCtx()
-        scales_e, quats_n, opac, viewdirs, normals = ActivateGaussians.forward(a, means, log_scales, quats, opacities,
-                                                                              cam_pos)
-        xys, depths, radii, conics, num_tiles_hit, _cov3d = ProjectGaussians.forward(
-            p, means, scales_e, 1, quats_n, viewmat, full_proj, fx, fy, cx, cy, img_height, img_width, tile_bounds)
+        scales_e, quats_n, opac, viewdirs, normals, xys, depths, radii, conics, num_tiles_hit = \
+            ViewGeometry._activate_and_project(a, p, means, log_scales, quats, opacities, cam_pos, viewmat, full_proj,
+                                               fx, fy, cx, cy, img_height, img_width, tile_bounds)
         tail = ShadeTail.forward(t, degrees_to_use, viewdirs, colors_all, depths, normals)
         ctx.parts = (a, p, t)
         ctx.counts = tuple(len(c.saved_tensors) for c in ctx.parts)
@@ -837,6 +840,49 @@ class ViewGeometry(Function):
             c.saved_tensors = ()
         ctx.mark_non_differentiable(radii, num_tiles_hit)
         return xys, depths, radii, conics, num_tiles_hit, opac, tail, normals
+
+    @staticmethod
+    def _activate_and_project(a, p, means, log_scales, quats, opacities, cam_pos, viewmat, full_proj, fx, fy, cx, cy,
+                              img_height, img_width, tile_bounds):
+        """ActivateGaussians.forward + ProjectGaussians.forward (glob_scale 1, default clip) as ONE kernel, gg_view_fwd,
+        which also leaves the intersection count and the depth range's partial results behind; `a` / `p` are filled as
+        the two forwards fill their ctx (the backwards read them)."""
+        dev = _require_hip(means, log_scales, quats, opacities, cam_pos, viewmat, full_proj)
+        n = means.shape[0]
+        if means.ndim != 2 or means.shape[1] != 3:
+            raise ValueError("means3d must have dimensions (N, 3)")
+        if tuple(log_scales.shape) != (n, 3) or tuple(quats.shape) != (n, 4) or opacities.numel() != n:
+            raise ValueError("expected means (N,3), scales (N,3), quats (N,4), opacities (N,1)")
+        if viewmat.numel() < 12 or full_proj.numel() != 16:
+            raise ValueError("viewmat must hold >= 12 and projmat exactly 16 elements")
+        a.sinks = [_sink_for(t_) if (t_.dtype == torch.float32 and t_.is_contiguous()) else None
+                   for t_ in (log_scales, quats, opacities)]
+        a.sinks = a.sinks if all(k is not None for k in a.sinks) else None
+        p.sink = _sink_for(means) if (means.dtype == torch.float32 and means.is_contiguous()) else None
+        m, s_, q, o = _f32(means), _f32(log_scales), _f32(quats), _f32(opacities)
+        c, vm, pm = _f32(cam_pos).reshape(-1), _f32(viewmat), _f32(full_proj)
+        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        i32 = lambda *shape: torch.empty(*shape, dtype=torch.int32, device=dev)
+        scales_e, quats_n, opac, viewdirs, normals = f(n, 3), f(n, 4), f(n, 1), f(n, 3), f(n, 3)
+        xys, depths, conics = f(n, 2), f(n), f(n, 3)
+        axis, radii, num_tiles_hit = i32(n), i32(n), i32(n)
+        lib = _lib.load()
+        blocks = max((n + 255) // 256, 1)
+        parts = i32(3 * blocks)
+        total = torch.empty(1, dtype=torch.int64, device=dev)
+        _lib.check(lib.gg_view_fwd(
+            n, _ptr(m), _ptr(s_), _ptr(q), _ptr(o), _ptr(c), _ptr(vm), _ptr(pm), float(fx), float(fy), float(cx),
+            float(cy), int(img_height), int(img_width), int(tile_bounds[0]), int(tile_bounds[1]), CLIP_THRESH_DEFAULT,
+            _ptr(scales_e), _ptr(quats_n), _ptr(opac), _ptr(viewdirs), _ptr(normals), _ptr(axis), _ptr(xys),
+            _ptr(depths), _ptr(radii), _ptr(conics), _ptr(num_tiles_hit), _ptr(total), _ptr(parts), parts.numel() * 4,
+            _stream(dev)), "gg_view_fwd")
+        a.save_for_backward(q, scales_e, opac, axis)
+        a.opacity_shape = tuple(opacities.shape)
+        p.scalars = (1.0, float(fx), float(fy), float(cx), float(cy), int(img_height), int(img_width))
+        p.save_for_backward(m, scales_e, quats_n, vm, pm, radii, conics)
+        _start_count(num_tiles_hit, total, (parts[blocks:2 * blocks], parts[2 * blocks:], blocks) if n > 0 else None)
+        return (scales_e, quats_n, opac.reshape(a.opacity_shape), viewdirs, normals, xys, depths, radii, conics,
+                num_tiles_hit)
 
     @staticmethod
     def backward(ctx, v_xys, v_depths, v_radii, v_conics, v_nth, v_opac, v_tail, v_normals):

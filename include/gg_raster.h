@@ -144,6 +144,20 @@ int gg_view_bwd(int num_points, const float *rec, int rec_stride, const uint8_t 
                 int img_width, const int32_t *radii, const float *conics, float *v_rgb, float *v_means,
                 float *v_log_scales, float *v_quats, float *v_opacities, gg_stream_t stream);
 
+/* gg_activate_fwd + gg_project_fwd (glob_scale 1) + the intersection count in one pass over the Gaussians (round 4,
+ * ops.ViewGeometry).  Outputs are those two entries' (bit for bit: shared device code) except that cov3d is not produced.
+ * *num_intersects_out (device, int64) receives sum(num_tiles_hit).  `parts`: gg_view_fwd_workspace(num_points) bytes,
+ * 4-byte aligned; on return it holds per workgroup of 256 Gaussians [sum of num_tiles_hit | smallest | largest depth bits
+ * of its visible Gaussians] (three arrays of ceil(num_points / 256) words) — gg_bin_sort_dev_ex takes the last two
+ * instead of running its own pass over depths and radii. */
+size_t gg_view_fwd_workspace(int num_points);
+int gg_view_fwd(int num_points, const float *means, const float *log_scales, const float *quats, const float *opacities,
+                const float *cam_pos, const float *viewmat, const float *projmat, float fx, float fy, float cx, float cy,
+                int img_height, int img_width, int tiles_x, int tiles_y, float clip_thresh, float *scales, float *quats_n,
+                float *opac, float *viewdirs, float *normals, int32_t *axis, float *xys, float *depths, int32_t *radii,
+                float *conics, int32_t *num_tiles_hit, int64_t *num_intersects_out, void *parts, size_t parts_bytes,
+                gg_stream_t stream);
+
 /* ---- quat_to_rotmat ------------------------------------------------------------------------
  * Replace gsplat `_torch_impl.quat_to_rotmat` (differentiable torch code there: ~35 elementwise
  * launches forward, ~70 backward; reference call sites gaussian_splatting.py:516,614 — the
@@ -213,6 +227,14 @@ int gg_bin_sort_dev(int num_points, int64_t capacity, const int64_t *num_interse
                     const int32_t *num_tiles_hit, int tiles_x, int tiles_y,
                     int32_t *gaussian_ids_sorted, int32_t *tile_bins, int32_t *isect_tile_sorted,
                     void *ws, size_t ws_bytes, gg_stream_t stream);
+/* gg_bin_sort_dev_ex: the same, with the partial minima / maxima of the visible Gaussians' depth bits handed over
+ * (range_parts pairs, e.g. gg_view_fwd's `parts` arrays 1 and 2): the depth buckets' own pass over depths / radii is not
+ * run.  range_parts 0: gg_bin_sort_dev. */
+int gg_bin_sort_dev_ex(int num_points, int64_t capacity, const int64_t *num_intersects_dev, const float *xys,
+                       const float *depths, const int32_t *radii, const int32_t *num_tiles_hit, int tiles_x, int tiles_y,
+                       int32_t *gaussian_ids_sorted, int32_t *tile_bins, int32_t *isect_tile_sorted, void *ws,
+                       size_t ws_bytes, const uint32_t *depth_bits_min, const uint32_t *depth_bits_max, int range_parts,
+                       gg_stream_t stream);
 
 /* ---- alpha blending ----------------------------------------------------------------------
  * gg_blend_fwd replaces gsplat `_C.rasterize_forward` (C=3) and `_C.nd_rasterize_forward`
@@ -503,6 +525,8 @@ int gg_adam_step(int num_groups, const gg_adam_group_t *groups, int zero_grad, g
 #define GG_K_ACTIVATE_BWD 31
 #define GG_K_COUNT 18         /* gg_count_intersects */
 #define GG_K_TAIL_SPLIT 19    /* gg_shade_tail_bwd_split */
+#define GG_K_VIEW_FWD 32      /* gg_view_fwd: activations + projection of a view in one kernel */
+#define GG_K_IDS 40           /* ids are below this */
 #define GG_PROF_NUM_KERNELS 32
 int gg_prof_enable(int on);
 int gg_prof_reset(void);

@@ -18,7 +18,7 @@ from gaussiangrasper_amd.scene import make_scene  # noqa: E402
 
 def prof(lib):
     out = {}
-    for kid in range(32):
+    for kid in range(40):
         n, ms = ctypes.c_int(0), ctypes.c_double(0.0)
         lib.gg_prof_get(kid, ctypes.byref(n), ctypes.byref(ms))
         if n.value:

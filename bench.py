@@ -96,6 +96,8 @@ def parse(argv=None):
                          "ends with reduced gradients, as the reference's DDP step would) or rs_ag = reduce-scatter, "
                          "fused Adam on this rank's shard, all-gather of the parameters (dist.ShardedAdamStep; the "
                          "timed step then INCLUDES the optimizer step)")
+    ap.add_argument("--keep-gc", action="store_true",
+                    help="do not gc.freeze() after the warm-up (see freeze_gc)")
     ap.add_argument("--pipe-priority", default="0,0",
                     help="measurement: HIP stream priorities of the two view-pipeline streams (-1 = high)")
     ap.add_argument("--no-view-pipeline", action="store_true",
@@ -114,6 +116,8 @@ def parse(argv=None):
     ap.add_argument("--share-gpu", action="store_true",
                     help="test hook: every rank uses cuda:0 (a one-GPU box rehearsing N ranks; gloo backend)")
     a = ap.parse_args(argv)
+    if a.keep_gc:
+        os.environ["GG_BENCH_KEEP_GC"] = "1"
     d4 = dict(points=1_000_000, height=1200, width=1600, feature_dim=32)
     d5 = dict(points=5_000_000, height=1080, width=1920, feature_dim=128)
     for k, v in (d4 if a.config == 4 else d5).items():
@@ -249,6 +253,20 @@ def parse_rccl_log(path):
     except OSError:
         return None
     return keep or None
+
+
+def freeze_gc():
+    """Python's cyclic collector walks every tracked object of the process on a full collection — ~60 ms with torch
+    loaded, once per ~50-70 views at ~1 000 container allocations per view — and the GPU drains meanwhile (the host is at
+    most one view ahead of it: the intersection count is read back per view).  Measured on `--config 5`: 157 views/s
+    with the collector as it comes, 203 with it off.  After the warm-up everything alive is moved to the permanent
+    generation (`gc.freeze()`): later collections only walk what the timed steps allocate.  `--keep-gc` leaves the
+    collector untouched."""
+    import gc
+    if os.environ.get("GG_BENCH_KEEP_GC") == "1":
+        return
+    gc.collect()
+    gc.freeze()
 
 
 def read_kernel_times(lib):
@@ -508,6 +526,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
         fn = make_step(fused)
         for _ in range(warmup):
             one_step(fn)
+        freeze_gc()
         t = timed(fn, args.steps)
         grads = bucket.gathered().detach().cpu().clone() if (args.dump_grads and rank == 0) else None
         kern, t_prof = {}, None
@@ -573,6 +592,8 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> int:
                                   if plugin_first else "shim route: the reference's 4 rasterize calls per view",
                                   args.views_per_step),
                    "route": args.route, "deterministic_backward": bool(args.deterministic),
+                   "python_gc": "as it comes" if os.environ.get("GG_BENCH_KEEP_GC") == "1" else
+                                "gc.freeze() after the warm-up (bench.freeze_gc)",
                    "view_pipeline": ("backward of view k beside forward of view k + 1 on two streams"
                                      if pipe_streams_box[0] is not None else "off"),
                    "num_gaussians": args.points, "image": [args.height, args.width],
@@ -695,6 +716,7 @@ def render_only_result(args, rank, world, dev, ops, lib, barrier, max_over_ranks
         for _ in range(args.warmup):
             for v in my_views:
                 render(v)
+        freeze_gc()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -730,6 +752,8 @@ def render_only_result(args, rank, world, dev, ops, lib, barrier, max_over_ranks
                                   else "shim route: the reference's 4 rasterize calls",
                                   args.feature_dim, args.views_per_step),
                    "route": "plugin" if fused else "shim",
+                   "python_gc": "as it comes" if os.environ.get("GG_BENCH_KEEP_GC") == "1" else
+                                "gc.freeze() after the warm-up (bench.freeze_gc)",
                    "num_gaussians": args.points, "image": [args.height, args.width],
                    "feature_dim": args.feature_dim, "views_per_step_per_gpu": args.views_per_step,
                    "n_visible": n_vis, "num_intersects": n_isect,

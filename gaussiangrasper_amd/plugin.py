@@ -333,11 +333,22 @@ def make_fused_model_class(base, ops=_ops, background_override=lambda: None, fus
             # training camera with its dataset index (full_images_datamanager.py:375-377, `metadata["cam_idx"]`)
             # and intrinsics are per-dataset constants (camera optimisation, if on, moves poses only), so each
             # (index, downscale) is read back once.  Cameras without the stamp, and eval mode (where train and eval
-            # datasets share index values), are read every time.
+            # datasets share index values), are read once per set of camera TENSORS (address + version).
             cache = self.__dict__.setdefault("_gg_camera_scalars", {})
             scal = cache.get(key) if key is not None else None
             if scal is None:
-                scal = _camera_scalars(camera)
+                # (unstamped / eval cameras: the SAME tensors at the same versions hold the same values — a render loop
+                #  that keeps its camera objects, as the viewer and bench.py --config 5 do, is read back once per object)
+                tkey = tuple((t.data_ptr(), t._version, str(t.device)) for t in
+                             (camera.fx, camera.fy, camera.cx, camera.cy, camera.width, camera.height))
+                tcache = self.__dict__.setdefault("_gg_camera_scalars_by_tensor", {})
+                hit = tcache.get(tkey)
+                if hit is None:
+                    if len(tcache) >= 256:
+                        tcache.clear()
+                    hit = tcache[tkey] = (_camera_scalars(camera), (camera.fx, camera.fy, camera.cx, camera.cy,
+                                                                  camera.width, camera.height))   # (refs: addresses stay theirs)
+                scal = hit[0]
                 if key is not None:
                     cache[key] = scal
             fx, fy, cx, cy, ax, ay, W, H = scal

@@ -9,11 +9,14 @@ import torch  # noqa: E402
 from gaussiangrasper_amd import _lib, ops  # noqa: E402
 from gaussiangrasper_amd.camera import ring_cameras  # noqa: E402
 from gaussiangrasper_amd.scene import make_scene  # noqa: E402
-if len(sys.argv) > 1:
-    _lib.LIB_PATH = os.path.abspath(sys.argv[1])
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+if args:
+    _lib.LIB_PATH = os.path.abspath(args[0])
 dev = "cuda:0"
 h, w, n = 1200, 1600, 1_000_000
-sc = make_scene(n, config_index=3).to(dev)
+if "--config5" in sys.argv:            # BASELINE config 5: 5 M Gaussians at 1920x1080
+    h, w, n = 1080, 1920, 5_000_000
+sc = make_scene(n, config_index=5 if "--config5" in sys.argv else 3).to(dev)
 v = ring_cameras(8, h, w, device=dev)[0]
 with torch.no_grad():
     xys, depths, radii, conics, nth, _ = ops.ProjectGaussians.apply(

@@ -67,7 +67,9 @@ SIGNATURES = {
     "gg_bin_sort_dev": (_I, [_I, _I64, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
     "gg_bin_sort_dev_ex": (_I, [_I, _I64, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _SZ, _P, _P, _I, _P]),
     "gg_view_fwd_workspace": (_SZ, [_I]),
-    "gg_view_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _I, _I, _I, _F] + [_P] * 11 + [_P, _P, _SZ, _P]),
+    "gg_view_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _I, _I, _I, _F] + [_P] * 11 +
+                    [_P, _P, _SZ, _P, _SZ, _P]),
+    "gg_blend_fwd_pair_packed": (_I, [_I, _I, _I, _I, _I] + [_P] * 11 + [_SZ, _I, _P]),
     "gg_blend_workspace": (_SZ, [_I]),
     "gg_blend_fwd": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gg_blend_fwd_pair": (_I, [_I, _I, _I, _I, _I] + [_P] * 14 + [_SZ, _P]),

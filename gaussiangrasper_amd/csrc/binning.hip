@@ -36,7 +36,10 @@ __device__ __forceinline__ int64_t dev_count(int64_t n, const int64_t *__restric
 #define RS_WAVES (RS_THREADS / GG_WAVE)
 // keys per thread: 16 for large inputs; 4 when that would leave fewer than ~4 workgroups per CU
 // (the N = 1 M depth sort: 245 workgroups of 16 keys/thread ran latency-bound at 32 us per pass)
-static inline int rs_items(int64_t n) { return n >= (int64_t)4096 * 1024 ? 16 : 4; }
+#ifndef GG_RS_BIG
+#define GG_RS_BIG 16
+#endif
+static inline int rs_items(int64_t n) { return n >= (int64_t)4096 * 1024 ? GG_RS_BIG : 4; }
 
 // ---------------------------------------------------------------------------------------------
 // sum(num_tiles_hit) -> device int64
@@ -944,15 +947,15 @@ static void radix_pass(int64_t n, const int64_t *n_dev, const uint32_t *kin, con
                        uint32_t *kout, uint32_t *vout, int shift, uint32_t mask, BinWs &w, hipStream_t s,
                        DepthSrc dsrc = DepthSrc{nullptr, nullptr}) {
     int nb = radix_nblocks(n);
-    if (rs_items(n) == 16)
-        hipLaunchKernelGGL(radix_hist_kernel<16>, dim3(nb), dim3(RS_THREADS), 0, s, n, n_dev, kin, shift,
+    if (rs_items(n) != 4)
+        hipLaunchKernelGGL(radix_hist_kernel<GG_RS_BIG>, dim3(nb), dim3(RS_THREADS), 0, s, n, n_dev, kin, shift,
                            mask, nb, w.G, dsrc);
     else
         hipLaunchKernelGGL(radix_hist_kernel<4>, dim3(nb), dim3(RS_THREADS), 0, s, n, n_dev, kin, shift,
                            mask, nb, w.G, dsrc);
     hipLaunchKernelGGL(radix_colscan_kernel, dim3(256), dim3(256), 0, s, nb, w.G, w.totals);
-    if (rs_items(n) == 16)
-        hipLaunchKernelGGL(radix_scatter_kernel<16>, dim3(nb), dim3(RS_THREADS), 0, s, n, n_dev, kin, vin,
+    if (rs_items(n) != 4)
+        hipLaunchKernelGGL(radix_scatter_kernel<GG_RS_BIG>, dim3(nb), dim3(RS_THREADS), 0, s, n, n_dev, kin, vin,
                            kout, vout, shift, mask, nb, w.G, w.totals, dsrc);
     else
         hipLaunchKernelGGL(radix_scatter_kernel<4>, dim3(nb), dim3(RS_THREADS), 0, s, n, n_dev, kin, vin,

@@ -14,24 +14,8 @@ __global__ __launch_bounds__(256) void blend_prep_kernel(int N, const float *__r
                                                          GRec *__restrict__ rec) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    GRec r;
-    r.x = xys[2 * (size_t)i];
-    r.y = xys[2 * (size_t)i + 1];
-    r.opac = opacity[i];
-    r.ca = conics[3 * (size_t)i];
-    r.cb = conics[3 * (size_t)i + 1];
-    r.cc = conics[3 * (size_t)i + 2];
-    r.pad = 0.0f;
-    // alpha = opac*exp(-sigma) >= 1/255  <=>  sigma <= ln(255*opac).  Margins absorb the fp32
-    // rounding of sigma (rel ~5e-7), of gg_expf (2 ulp) and of the fast log (1e-6).
-    float t = __logf(255.0f * r.opac);
-    t = t + 0.002f * fabsf(t) + 0.002f;
-    if (!(r.opac > 0.0f)) t = -1.0f;                   // alpha <= 0 < 1/255 always
-    if (r.opac != r.opac) t = __builtin_inff();         // NaN opacity: never cull (NaN propagates)
-    r.thr = t;
-    float4 *dst = reinterpret_cast<float4 *>(rec + i);
-    dst[0] = make_float4(r.x, r.y, r.opac, r.thr);
-    dst[1] = make_float4(r.ca, r.cb, r.cc, r.pad);
+    grec_pack(xys[2 * (size_t)i], xys[2 * (size_t)i + 1], opacity[i], conics[3 * (size_t)i], conics[3 * (size_t)i + 1],
+              conics[3 * (size_t)i + 2], rec + i);
 }
 
 extern "C" size_t gg_blend_workspace(int num_points) {
@@ -183,21 +167,21 @@ static int blend_fwd_pair_impl(int C, int C2, int N, int img_h, int img_w, const
                                  const float *colors, const float *colors2, const float *opacity,
                                  const float *background, const float *background2, float *out_img,
                                  float *out_img2, float *final_Ts, int32_t *final_idx, void *ws,
-                                 size_t ws_bytes, gg_stream_t stream, bool fast) {
+                                 size_t ws_bytes, gg_stream_t stream, bool fast, bool records_ready = false) {
     GG_REQUIRE(C >= 32, "the first colour array needs >= 32 channels (its first chunk carries the second array)");
     GG_REQUIRE(C2 >= 1 && C2 <= 8, "the second colour array has 1..8 channels");
     GG_REQUIRE(N >= 0, "num_points < 0");
     GG_REQUIRE(img_h > 0 && img_w > 0, "empty image");
     GG_REQUIRE(tile_bins && background && background2 && out_img && out_img2 && final_Ts && final_idx,
                "null pointer");
-    GG_REQUIRE(N == 0 || (ids && xys && conics && colors && colors2 && opacity), "null pointer");
+    GG_REQUIRE(N == 0 || (ids && colors && colors2 && (records_ready || (xys && conics && opacity))), "null pointer");
     if (ws == nullptr || ws_bytes < gg_blend_workspace(N)) {
         gg_set_error("gg_blend_fwd_pair: workspace too small");
         return GG_ERR_WORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
     GRec *rec = (GRec *)ws;
-    if (N > 0) {
+    if (N > 0 && !records_ready) {
         gg_prof_begin(GG_K_BLEND_PREP, s);
         hipLaunchKernelGGL(blend_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, xys, conics,
                            opacity, rec);
@@ -247,6 +231,18 @@ extern "C" int gg_blend_fwd_pair_fast(int C, int C2, int N, int img_h, int img_w
                                       size_t ws_bytes, gg_stream_t stream) {
     return blend_fwd_pair_impl(C, C2, N, img_h, img_w, ids, tile_bins, xys, conics, colors, colors2, opacity, background,
                                background2, out_img, out_img2, final_Ts, final_idx, ws, ws_bytes, stream, true);
+}
+
+// gg_blend_fwd_pair / gg_blend_fwd_pair_fast on a workspace that ALREADY holds the packed records of these Gaussians
+// (gg_view_fwd's `records` output, or an earlier forward over the same xys / conics / opacity): no packing pass
+extern "C" int gg_blend_fwd_pair_packed(int C, int C2, int N, int img_h, int img_w, const int32_t *ids,
+                                        const int32_t *tile_bins, const float *colors, const float *colors2,
+                                        const float *background, const float *background2, float *out_img,
+                                        float *out_img2, float *final_Ts, int32_t *final_idx, void *ws,
+                                        size_t ws_bytes, int fast, gg_stream_t stream) {
+    return blend_fwd_pair_impl(C, C2, N, img_h, img_w, ids, tile_bins, nullptr, nullptr, colors, colors2, nullptr,
+                               background, background2, out_img, out_img2, final_Ts, final_idx, ws, ws_bytes, stream,
+                               fast != 0, true);
 }
 
 // ---------------------------------------------------------------------------------------------

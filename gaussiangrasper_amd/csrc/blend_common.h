@@ -21,6 +21,18 @@ struct __attribute__((aligned(16))) GRec {
     float ca, cb, cc, pad;
 };
 
+// pack one Gaussian's record (shared by blend_prep_kernel and view_fwd_kernel: the same bits)
+__device__ __forceinline__ void grec_pack(float x, float y, float opac, float ca, float cb, float cc, GRec *__restrict__ dst) {
+    // alpha = opac*exp(-sigma) >= 1/255  <=>  sigma <= ln(255*opac).  Margins absorb the fp32
+    // rounding of sigma (rel ~5e-7), of gg_expf (2 ulp) and of the fast log (1e-6).
+    float t = __logf(255.0f * opac);
+    t = t + 0.002f * fabsf(t) + 0.002f;
+    if (!(opac > 0.0f)) t = -1.0f;                   // alpha <= 0 < 1/255 always
+    if (opac != opac) t = __builtin_inff();           // NaN opacity: never cull (NaN propagates)
+    float4 *d4 = reinterpret_cast<float4 *>(dst);
+    d4[0] = make_float4(x, y, opac, t);
+    d4[1] = make_float4(ca, cb, cc, 0.0f);
+}
 
 // Tile of a workgroup.  Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD
 // b & 7), each with its own L2.  XCD x takes the strips s = x, x+8, x+16, ... of GG_STRIP consecutive

@@ -9,7 +9,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 
-#include "gg_common.h"
+#include "blend_common.h"
 
 // ---- error plumbing (one thread-local message, SURVEY §8b "gg_last_error") ------------------
 static thread_local char g_err[512] = "";
@@ -1013,7 +1013,8 @@ __global__ __launch_bounds__(256) void view_fwd_kernel(
     int tiles_y, float clip_thresh, float *__restrict__ scales, float4 *__restrict__ quats_n, float *__restrict__ opac,
     float *__restrict__ viewdirs, float *__restrict__ normals, int32_t *__restrict__ axis, float *__restrict__ xys,
     float *__restrict__ depths, int32_t *__restrict__ radii, float *__restrict__ conics,
-    int32_t *__restrict__ num_tiles_hit, unsigned *__restrict__ parts /* [3][workgroups]: sum, min bits, max bits */) {
+    int32_t *__restrict__ num_tiles_hit, unsigned *__restrict__ parts /* [3][workgroups]: sum, min bits, max bits */,
+    GRec *__restrict__ records /* nullable: the blend kernels' packed records (blend_prep_kernel's pass saved) */) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < N;
     if (!live) i = N - 1;          // (a padding thread of the last workgroup: computes, stores and counts nothing)
@@ -1067,6 +1068,7 @@ __global__ __launch_bounds__(256) void view_fwd_kernel(
         depths[i] = o_d;
         radii[i] = o_r;
         num_tiles_hit[i] = o_n;
+        if (records) grec_pack(o_x, o_y, op, o_con[0], o_con[1], o_con[2], records + i);
     }
     // ---- the workgroup's partial results
     __shared__ unsigned s_sum[4], s_lo[4], s_hi[4];
@@ -1096,12 +1098,15 @@ extern "C" int gg_view_fwd(int N, const float *means, const float *log_scales, c
                            float cy, int img_height, int img_width, int tiles_x, int tiles_y, float clip_thresh,
                            float *scales, float *quats_n, float *opac, float *viewdirs, float *normals, int32_t *axis,
                            float *xys, float *depths, int32_t *radii, float *conics, int32_t *num_tiles_hit,
-                           int64_t *num_intersects_out, void *parts, size_t parts_bytes, gg_stream_t stream) {
+                           int64_t *num_intersects_out, void *parts, size_t parts_bytes, void *records,
+                           size_t records_bytes, gg_stream_t stream) {
     GG_REQUIRE(N >= 0, "num_points < 0");
     GG_REQUIRE(img_height > 0 && img_width > 0, "empty image");
     GG_REQUIRE(tiles_x == (img_width + GG_BLOCK - 1) / GG_BLOCK && tiles_y == (img_height + GG_BLOCK - 1) / GG_BLOCK,
                "tile_bounds must be ceil(W/16), ceil(H/16)");
     GG_REQUIRE(num_intersects_out != nullptr, "null num_intersects_out");
+    GG_REQUIRE(records == nullptr || (records_bytes >= sizeof(GRec) * (size_t)(N > 0 ? N : 1) && ((uintptr_t)records & 15) == 0),
+               "records: gg_blend_workspace(num_points) bytes, 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     if (N == 0) {
         if (gg_fill_async(num_intersects_out, 0, sizeof(int64_t), s) != hipSuccess) {
@@ -1122,7 +1127,7 @@ extern "C" int gg_view_fwd(int N, const float *means, const float *log_scales, c
     hipLaunchKernelGGL(view_fwd_kernel, dim3(blocks), dim3(256), 0, s, N, means, log_scales, (const float4 *)quats,
                        opacities, cam_pos, viewmat, projmat, fx, fy, cx, cy, img_height, img_width, tiles_x, tiles_y,
                        clip_thresh, scales, (float4 *)quats_n, opac, viewdirs, normals, axis, xys, depths, radii, conics,
-                       num_tiles_hit, (unsigned *)parts);
+                       num_tiles_hit, (unsigned *)parts, (GRec *)records);
     gg_prof_end(GG_K_VIEW_FWD, s);
     gg_prof_begin(GG_K_COUNT, s);
     hipLaunchKernelGGL(count_finish_kernel, dim3(1), dim3(1024), 0, s, blocks, (const unsigned *)parts,

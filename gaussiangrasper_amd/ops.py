@@ -815,7 +815,10 @@ def _is_record_view(t: Optional[Tensor], base: int, offset: int, width: int, str
 class ViewGeometry(Function):
     """apply(means, log_scales, quats, opacities, colors_all, cam_pos, viewmat, full_proj, fx, fy, cx, cy,
              img_height, img_width, tile_bounds, degrees_to_use)
-       -> (xys, depths, radii, conics, num_tiles_hit, opac, tail (N, 7), normals)
+       -> (xys, depths, radii, conics, num_tiles_hit, opac, tail (N, 7), normals, packed)
+
+    `packed`: a blend workspace already holding these Gaussians' packed records (pass it to rasterize_segments(...,
+    packed=...): the forward then skips its packing pass).
 
     ActivateGaussians -> ProjectGaussians -> ShadeTail (reference :699-731, :742, :605-619) as one node: the forward is
     those three operators' forwards, the backward — when every parameter has a gradient buffer (register_grad_sink) and
@@ -829,7 +832,7 @@ class ViewGeometry(Function):
                 img_height, img_width, tile_bounds, degrees_to_use):
         ctx.set_materialize_grads(False)
         a, p, t = _PartCtx(), _PartCtx(), _PartCtx()
-        scales_e, quats_n, opac, viewdirs, normals, xys, depths, radii, conics, num_tiles_hit = \
+        scales_e, quats_n, opac, viewdirs, normals, xys, depths, radii, conics, num_tiles_hit, packed = \
             ViewGeometry._activate_and_project(a, p, means, log_scales, quats, opacities, cam_pos, viewmat, full_proj,
                                                fx, fy, cx, cy, img_height, img_width, tile_bounds)
         tail = ShadeTail.forward(t, degrees_to_use, viewdirs, colors_all, depths, normals)
@@ -838,8 +841,8 @@ class ViewGeometry(Function):
         ctx.save_for_backward(*a.saved_tensors, *p.saved_tensors, *t.saved_tensors)
         for c in ctx.parts:
             c.saved_tensors = ()
-        ctx.mark_non_differentiable(radii, num_tiles_hit)
-        return xys, depths, radii, conics, num_tiles_hit, opac, tail, normals
+        ctx.mark_non_differentiable(radii, num_tiles_hit, packed)
+        return xys, depths, radii, conics, num_tiles_hit, opac, tail, normals, packed
 
     @staticmethod
     def _activate_and_project(a, p, means, log_scales, quats, opacities, cam_pos, viewmat, full_proj, fx, fy, cx, cy,
@@ -870,22 +873,23 @@ class ViewGeometry(Function):
         blocks = max((n + 255) // 256, 1)
         parts = i32(3 * blocks)
         total = torch.empty(1, dtype=torch.int64, device=dev)
+        packed = _workspace(lib.gg_blend_workspace(n), dev)          # the blend operators' workspace, records packed here
         _lib.check(lib.gg_view_fwd(
             n, _ptr(m), _ptr(s_), _ptr(q), _ptr(o), _ptr(c), _ptr(vm), _ptr(pm), float(fx), float(fy), float(cx),
             float(cy), int(img_height), int(img_width), int(tile_bounds[0]), int(tile_bounds[1]), CLIP_THRESH_DEFAULT,
             _ptr(scales_e), _ptr(quats_n), _ptr(opac), _ptr(viewdirs), _ptr(normals), _ptr(axis), _ptr(xys),
             _ptr(depths), _ptr(radii), _ptr(conics), _ptr(num_tiles_hit), _ptr(total), _ptr(parts), parts.numel() * 4,
-            _stream(dev)), "gg_view_fwd")
+            _ptr(packed), packed.numel(), _stream(dev)), "gg_view_fwd")
         a.save_for_backward(q, scales_e, opac, axis)
         a.opacity_shape = tuple(opacities.shape)
         p.scalars = (1.0, float(fx), float(fy), float(cx), float(cy), int(img_height), int(img_width))
         p.save_for_backward(m, scales_e, quats_n, vm, pm, radii, conics)
         _start_count(num_tiles_hit, total, (parts[blocks:2 * blocks], parts[2 * blocks:], blocks) if n > 0 else None)
         return (scales_e, quats_n, opac.reshape(a.opacity_shape), viewdirs, normals, xys, depths, radii, conics,
-                num_tiles_hit)
+                num_tiles_hit, packed)
 
     @staticmethod
-    def backward(ctx, v_xys, v_depths, v_radii, v_conics, v_nth, v_opac, v_tail, v_normals):
+    def backward(ctx, v_xys, v_depths, v_radii, v_conics, v_nth, v_opac, v_tail, v_normals, v_packed=None):
         a, p, t = ctx.parts
         saved, k = ctx.saved_tensors, 0
         for c, cnt in zip(ctx.parts, ctx.counts):
@@ -974,7 +978,16 @@ class RasterizeSegments(Function):
                      for c in cols]
         bins = bin_and_sort_gaussians(xys, depths, radii, num_tiles_hit, img_height, img_width, speculative=True)
         lib = _lib.load()
-        ws = _workspace(lib.gg_blend_workspace(n), dev)
+        # splits may come as (splits, packed): `packed` = a blend workspace that already holds these Gaussians' records
+        # (ViewGeometry's last output): the pair forward then skips its packing pass
+        packed = None
+        if isinstance(splits, tuple) and len(splits) == 2 and (splits[1] is None or isinstance(splits[1], Tensor)) \
+                and isinstance(splits[0], tuple):
+            splits, packed = splits
+        if packed is not None and (packed.dtype != torch.uint8 or packed.numel() < lib.gg_blend_workspace(n)
+                                   or packed.device != dev):
+            raise ValueError("packed: a uint8 blend workspace of gg_blend_workspace(N) bytes on the operands' device")
+        ws = packed if packed is not None else _workspace(lib.gg_blend_workspace(n), dev)
         final_Ts = torch.empty(img_height, img_width, dtype=torch.float32, device=dev)
         final_idx = torch.empty(img_height, img_width, dtype=torch.int32, device=dev)
         outs = [torch.empty(img_height, img_width, c.shape[1], dtype=torch.float32, device=dev) for c in cols_c]
@@ -984,7 +997,14 @@ class RasterizeSegments(Function):
             # a >= 32-channel array carries a <= 8-channel one through its first forward walk
             wide = next((i for i, c in enumerate(cols_c) if c.shape[1] >= 32), None)
             small = next((i for i, c in enumerate(cols_c) if c.shape[1] <= 8), None) if wide is not None else None
-            if small is not None:
+            if small is not None and packed is not None:
+                _lib.check(lib.gg_blend_fwd_pair_packed(
+                    cols_c[wide].shape[1], cols_c[small].shape[1], n, img_height, img_width,
+                    _ptr(bins.gaussian_ids_sorted), _ptr(bins.tile_bins), _ptr(cols_c[wide]), _ptr(cols_c[small]),
+                    _ptr(bgs_c[wide]), _ptr(bgs_c[small]), _ptr(outs[wide]), _ptr(outs[small]), _ptr(final_Ts),
+                    _ptr(final_idx), _ptr(ws), ws.numel(), 0 if (EXACT_FORWARD or _DETERMINISTIC) else 1,
+                    _stream(dev)), "gg_blend_fwd_pair_packed")
+            elif small is not None:
                 pair_fwd = lib.gg_blend_fwd_pair if (EXACT_FORWARD or _DETERMINISTIC) else lib.gg_blend_fwd_pair_fast
                 _lib.check(pair_fwd(
                     cols_c[wide].shape[1], cols_c[small].shape[1], n, img_height, img_width,
@@ -1129,7 +1149,8 @@ class RasterizeSegments(Function):
         return (v_xy, None, None, v_conic, None, v_opacity.reshape(ctx.opacity_shape), None, None, None, *seg_grads)
 
 
-def rasterize_segments(xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, segments):
+def rasterize_segments(xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, segments,
+                       packed: Optional[Tensor] = None):
     """segments: sequence of (colors (N, C_k), background (C_k,)[, split sizes]) -> list of images (H, W, C_k);
     a segment given with split sizes (e.g. [3, 1, 3] for rgb | depth | normal) comes back as that many images
     (views of one buffer, channel-sliced), and their cotangents go to the backward kernel without a concatenation."""
@@ -1138,8 +1159,9 @@ def rasterize_segments(xys, depths, radii, conics, num_tiles_hit, opacity, img_h
         flat += [seg[0], seg[1]]
         if len(seg) > 2 and seg[2] is not None:
             splits[i] = tuple(int(x) for x in seg[2])
+    spec = tuple(sorted(splits.items()))
     return list(RasterizeSegments.apply(xys, depths, radii, conics, num_tiles_hit, opacity, img_height,
-                                        img_width, tuple(sorted(splits.items())), *flat))
+                                        img_width, (spec, packed) if packed is not None else spec, *flat))
 
 
 # ------------------------------------------------------------------------------------------------

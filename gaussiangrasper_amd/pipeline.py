@@ -106,7 +106,8 @@ def _tail_background(dev) -> torch.Tensor:
     return _CONSTANTS[key]
 
 
-def fused_images(ops, xys, depths, radii, conics, num_tiles_hit, opac, h, w, feature, rgbs, normals, tail=None):
+def fused_images(ops, xys, depths, radii, conics, num_tiles_hit, opac, h, w, feature, rgbs, normals, tail=None,
+                 packed=None):
     """feature (D) | rgb (3) | depth (1, background 10) | normal (3) images from one binning.
     With `ops.rasterize_segments` (the product) the feature array and the 7-channel rgb|depth|normal array
     are two segments of ONE operator: no (N, D+7) concatenation, aligned feature rows, one set of
@@ -118,9 +119,10 @@ def fused_images(ops, xys, depths, radii, conics, num_tiles_hit, opac, h, w, fea
         if tail is None:
             tail = torch.cat([rgbs, depths[:, None], normals], dim=1)
         bg_tail = _tail_background(dev)
+        kw = {"packed": packed} if packed is not None else {}
         feat_im, rgb, depth, normal = ops.rasterize_segments(
             xys, depths, radii, conics, num_tiles_hit, opac, h, w,
-            [(feature, _zeros(d, dev)), (tail, bg_tail, (3, 1, 3))])
+            [(feature, _zeros(d, dev)), (tail, bg_tail, (3, 1, 3))], **kw)
         return feat_im, rgb, depth, normal
     colors = torch.cat([feature, rgbs, depths[:, None], normals], dim=1)
     background = torch.zeros(d + 7, device=dev)

@@ -48,13 +48,14 @@ def fused_view(model, means, log_scales, quats, opacities, colors_all, feature, 
         if full_proj is None:
             full_proj = projmat @ viewmat                                # :707
         model._gg_last_view = (viewmat, full_proj)
-        model.xys, depths, model.radii, conics, num_tiles_hit, opac, tail, model.normals = ops.ViewGeometry.apply(
+        model.xys, depths, model.radii, conics, num_tiles_hit, opac, tail, model.normals, packed = ops.ViewGeometry.apply(
             means, log_scales, quats, opacities, colors_all, cam_pos.reshape(-1)[:3], viewmat[:3, :], full_proj,
             fx, fy, cx, cy, H, W, tile_bounds, sh_degree_to_use)
         if model.training:
             model.xys.retain_grad()                                    # :724-725
         feat_im, rgb, depth_im, normal_im = fused_images(ops, model.xys, depths, model.radii, conics, num_tiles_hit,
-                                                         opac, H, W, feature, None, model.normals, tail=tail)
+                                                         opac, H, W, feature, None, model.normals, tail=tail,
+                                                         packed=packed)
         count = ops.last_num_intersects(model.radii)     # None: the lists binned last are not this call's
         if count == 0 or (count is None and (model.radii).sum() == 0):   # :714, answered after the render (see below)
             return None

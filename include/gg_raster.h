@@ -149,14 +149,16 @@ int gg_view_bwd(int num_points, const float *rec, int rec_stride, const uint8_t 
  * *num_intersects_out (device, int64) receives sum(num_tiles_hit).  `parts`: gg_view_fwd_workspace(num_points) bytes,
  * 4-byte aligned; on return it holds per workgroup of 256 Gaussians [sum of num_tiles_hit | smallest | largest depth bits
  * of its visible Gaussians] (three arrays of ceil(num_points / 256) words) — gg_bin_sort_dev_ex takes the last two
- * instead of running its own pass over depths and radii. */
+ * instead of running its own pass over depths and radii.  `records` (nullable): gg_blend_workspace(num_points) bytes,
+ * 16-byte aligned — filled with the blend kernels' packed per-Gaussian records (xy, opacity, cull threshold, conic), i.e.
+ * a blend workspace that gg_blend_fwd_pair_packed takes as it is. */
 size_t gg_view_fwd_workspace(int num_points);
 int gg_view_fwd(int num_points, const float *means, const float *log_scales, const float *quats, const float *opacities,
                 const float *cam_pos, const float *viewmat, const float *projmat, float fx, float fy, float cx, float cy,
                 int img_height, int img_width, int tiles_x, int tiles_y, float clip_thresh, float *scales, float *quats_n,
                 float *opac, float *viewdirs, float *normals, int32_t *axis, float *xys, float *depths, int32_t *radii,
                 float *conics, int32_t *num_tiles_hit, int64_t *num_intersects_out, void *parts, size_t parts_bytes,
-                gg_stream_t stream);
+                void *records, size_t records_bytes, gg_stream_t stream);
 
 /* ---- quat_to_rotmat ------------------------------------------------------------------------
  * Replace gsplat `_torch_impl.quat_to_rotmat` (differentiable torch code there: ~35 elementwise
@@ -276,6 +278,15 @@ int gg_blend_fwd_pair_fast(int channels, int channels2, int num_points, int img_
                            const float *opacity, const float *background, const float *background2,
                            float *out_img, float *out_img2, float *final_Ts, int32_t *final_idx, void *ws,
                            size_t ws_bytes, gg_stream_t stream);
+/* gg_blend_fwd_pair (fast == 0) / gg_blend_fwd_pair_fast (fast != 0) on a workspace that already holds the packed
+ * records of these Gaussians — gg_view_fwd's `records`, or the workspace of an earlier forward over the same xys /
+ * conics / opacity: the packing pass over the Gaussians is not run.  The backward entries take that workspace as
+ * always. */
+int gg_blend_fwd_pair_packed(int channels, int channels2, int num_points, int img_height, int img_width,
+                             const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *colors,
+                             const float *colors2, const float *background, const float *background2, float *out_img,
+                             float *out_img2, float *final_Ts, int32_t *final_idx, void *ws, size_t ws_bytes, int fast,
+                             gg_stream_t stream);
 
 /* gg_blend_bwd replaces gsplat `_C.rasterize_backward` / `_C.nd_rasterize_backward`.
  * v_xy (N,2), v_conic (N,3), v_colors (N,C), v_opacity (N,) are fully written.

@@ -401,7 +401,7 @@ def test_view_geometry_one_kernel_backward_equals_the_three_operator_chain(deter
                 P.clear_bin_cache()
                 cam = v.cam_pos.to(dev).reshape(-1)[:3]
                 if route == "node":
-                    xys, depths, radii, conics, nth, opac, tail, normals = P.ViewGeometry.apply(
+                    xys, depths, radii, conics, nth, opac, tail, normals, packed = P.ViewGeometry.apply(
                         sc.means, sc.scales, sc.quats, sc.opacities, sc.colors_all, cam, v.viewmat[:3, :], v.projmat,
                         v.fx, v.fy, v.cx, v.cy, h, w, v.tile_bounds, 4)
                 else:
@@ -411,7 +411,8 @@ def test_view_geometry_one_kernel_backward_equals_the_three_operator_chain(deter
                         sc.means, scales_e, 1, quats_n, v.viewmat[:3, :], v.projmat, v.fx, v.fy, v.cx, v.cy, h, w,
                         v.tile_bounds)
                     tail = P.ShadeTail.apply(4, viewdirs, sc.colors_all, depths, normals)
-                out = fused_images(P, xys, depths, radii, conics, nth, opac, h, w, sc.feature, None, normals, tail=tail)
+                out = fused_images(P, xys, depths, radii, conics, nth, opac, h, w, sc.feature, None, normals, tail=tail,
+                                   packed=packed if route == "node" else None)
                 g = torch.Generator(device="cpu").manual_seed(5 + k)
                 cots = [torch.randn(o.shape, generator=g).to(dev) for o in out]
                 torch.autograd.backward(list(out), cots)

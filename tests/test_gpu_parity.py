@@ -195,7 +195,9 @@ def test_binning_long_tile_lists(oracle, n, h, w, rmax):
     """Few tiles, many Gaussians each: lists of 2 k ... 200 k entries with most keys tied on depth (four distinct depth
     values: ties must come out in ascending Gaussian id).  The C-ABI call also asks for the sorted tile ids.
     (Written for round 4's counting-sort experiment, profiles/r04_counting_sort_binning_experiment.patch, whose per-tile
-    sorts had size classes; kept: the radix path has no other test with lists this long.)"""
+    sorts had size classes; kept: with four distinct depths the depth BUCKETS hold 7 k - 50 k Gaussians each, so this is
+    also the test of the bucket sort's long-run path — the compare-exchange network in global memory — and of its
+    id-byte passes for equal depths.)"""
     from gaussiangrasper_amd import _lib
     xys, depths, radii, nth, tb = _tie_inputs(n, h, w, rmax, seed=9)
     ref = oracle.bin_and_sort(xys, depths, radii, nth, tb)

@@ -1573,3 +1573,49 @@ def test_projection_leaves_the_intersection_count(n):
     torch.cuda.synchronize()
     for o in outs:
         assert P._take_count(o[4]) == int(o[4].long().sum())
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_binning_random_shapes_against_the_oracle(oracle, seed):
+    """Round 4's bucket depth sort on shapes its other tests do not reach: random counts (1 .. 150 k, incl. fewer
+    Gaussians than buckets), image sizes with ragged tile edges, depth laws (uniform, log-uniform over six decades, a tight
+    cluster plus outliers — almost everything in ONE bucket —, a handful of distinct values), radius laws incl. mostly
+    culled and nothing visible.  Lists and tile ranges bit-identical to the oracle's 64-bit sort."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 2, 63, 64, 65, 300, 5000, 40_000, 150_000]))
+    h, w = int(rng.integers(17, 400)), int(rng.integers(17, 400))
+    tx, ty = (w + 15) // 16, (h + 15) // 16
+    law = seed % 4
+    if law == 0:
+        depths = rng.uniform(0.02, 50.0, n)
+    elif law == 1:
+        depths = 10.0 ** rng.uniform(-1.5, 4.5, n)
+    elif law == 2:
+        depths = rng.normal(3.0, 1e-4, n)
+        depths[rng.random(n) < 0.01] = rng.uniform(0.05, 900.0)
+    else:
+        depths = rng.choice(np.array([0.5, 0.5000001, 7.0, 123.0]), n)
+    depths = np.abs(depths).astype(np.float32) + np.float32(0.011)
+    xys = np.stack([rng.uniform(-20, w + 20, n), rng.uniform(-20, h + 20, n)], axis=1).astype(np.float32)
+    rmax = int(rng.choice([2, 12, 60]))
+    radii = rng.integers(0, rmax, n).astype(np.int32)
+    if seed % 5 == 0:
+        radii[rng.random(n) < 0.9] = 0                      # mostly culled
+    if seed == 7:
+        radii[:] = 0                                        # nothing visible
+    f = np.float32
+    cx, cy, r = xys[:, 0] / f(16), xys[:, 1] / f(16), radii.astype(np.float32) / f(16)
+    x0 = np.clip(cx - r, 0, tx).astype(np.int32)
+    x1 = np.clip((cx + r) + f(1), 0, tx).astype(np.int32)
+    y0 = np.clip(cy - r, 0, ty).astype(np.int32)
+    y1 = np.clip((cy + r) + f(1), 0, ty).astype(np.int32)
+    nth = ((x1 - x0) * (y1 - y0)).astype(np.int32)
+    nth[radii <= 0] = 0
+    radii[nth == 0] = 0
+    ref = oracle.bin_and_sort(xys, depths, radii, nth, (tx, ty, 1))
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    b = P.bin_and_sort_gaussians(t(xys), t(depths), t(radii), t(nth), h, w, use_cache=False)
+    assert b.num_intersects == ref["num_intersects"] == int(nth.sum())
+    assert_bitexact(_np(b.tile_bins), ref["tile_bins"], "tile_bins")
+    if b.num_intersects:
+        assert_bitexact(_np(b.gaussian_ids_sorted), ref["gaussian_ids_sorted"], "gaussian_ids_sorted")

@@ -357,6 +357,9 @@ __global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(long P, int out_dim, 
 //     after them — one barrier per slice.
 // ---------------------------------------------------------------------------------------------
 #define MLPF_THREADS 512
+#ifndef MLPF_NPB
+#define MLPF_NPB 4   // 16-pixel blocks per wave and iteration (2: measured below)
+#endif
 #ifndef MLPF_ABL
 #define MLPF_ABL 0   // measurement builds: 1 no output stores, 2 no layer-2 MFMAs, 3 no stores and layer 2's A operands read once
 #endif
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(MLPF_THREADS) void mlp_fwd_f16_kernel(long P, int o
     // With two blocks the LDS ran at its 128 B/clk: 0.91 ms of compute against 0.60 with the A operands read once
     // (output stores off, 32 -> 128 -> 512 at 1600x1200); four blocks halve that traffic.  Layer 1 runs on two blocks
     // at a time (its B operands: 64 registers at 128 inputs).
-    constexpr int NPB = 4;
+    constexpr int NPB = MLPF_NPB;
     constexpr int PIX_PER_WG = (MLPF_THREADS / 64) * 16 * NPB;      // 512
     const long nblocks = (P + PIX_PER_WG - 1) / PIX_PER_WG;
     for (long blkid = blockIdx.x; blkid < nblocks; blkid += gridDim.x) {   // (every wave runs every barrier)
@@ -647,7 +650,7 @@ extern "C" int gg_mlp_fwd_fast(int64_t num_rows, int in_dim, int hidden_dim, int
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
-    const long nblocks = (num_rows + 511) / 512;      // 512 pixels per workgroup iteration (mlp_fwd_f16_kernel: NPB)
+    const long nblocks = (num_rows + 128 * MLPF_NPB - 1) / (128 * MLPF_NPB);      // pixels per workgroup iteration (mlp_fwd_f16_kernel: NPB)
     const int grid = (int)(nblocks < cus ? nblocks : cus);
     const size_t lds_bytes = sizeof(uint4) * 2 * MLPF_SLICE_Q + sizeof(float) * (size_t)(2 * MLP_HID + 2 * out_dim);
     hipError_t e = hipSuccess;

@@ -381,7 +381,10 @@ __device__ __forceinline__ void db_box(const DbGeom g, const DepthSrc d, int i, 
 template <bool SCATTER>
 __global__ __launch_bounds__(DB_THREADS) void db_walk_kernel(int N, int nb, DepthSrc dsrc, DbGeom geom,
                                                              const DbParts mm, uint32_t *__restrict__ G,
-                                                             const uint32_t *__restrict__ start, uint4 *__restrict__ recs) {
+                                                             const uint32_t *__restrict__ start, uint4 *__restrict__ recs,
+                                                             int32_t *__restrict__ zero = nullptr, int nzero = 0) {
+    // (the counting walk is the chain's first kernel with threads to spare: it zeroes the tile ranges for tile_bins_kernel)
+    for (int i = blockIdx.x * DB_THREADS + threadIdx.x; i < nzero; i += DB_BLOCKS * DB_THREADS) zero[i] = 0;
     extern __shared__ uint32_t s_hist[];   // nb + 1 counters (SCATTER: cursors), then the range
     uint32_t *s_mm = s_hist + nb + 1;
     const DbRange r = db_range_of(mm, nb, s_mm);
@@ -974,11 +977,13 @@ static int bin_sort_impl(int N, int64_t I, const int64_t *I_dev, const float *xy
     GG_REQUIRE(tile_bins != nullptr, "null tile_bins");
     hipStream_t s = (hipStream_t)stream;
     const int T = tiles_x * tiles_y;
-    if (gg_fill_async(tile_bins, 0, sizeof(int32_t) * 2 * (size_t)T, s) != hipSuccess) {
-        gg_set_error("gg_bin_sort: memset failed");
-        return GG_ERR_LAUNCH;
+    if (N == 0 || I == 0) {       // (otherwise the first kernel below zeroes the ranges: no launch of its own)
+        if (gg_fill_async(tile_bins, 0, sizeof(int32_t) * 2 * (size_t)T, s) != hipSuccess) {
+            gg_set_error("gg_bin_sort: memset failed");
+            return GG_ERR_LAUNCH;
+        }
+        return GG_OK;
     }
-    if (N == 0 || I == 0) return GG_OK;
     GG_REQUIRE(xys && depths && radii && num_tiles_hit && gaussian_ids_sorted, "null pointer");
     BinWs w = bin_ws_layout(ws, N, I);
     if (ws == nullptr || ws_bytes < w.bytes) {
@@ -1002,11 +1007,11 @@ static int bin_sort_impl(int N, int64_t I, const int64_t *I_dev, const float *xy
         hipLaunchKernelGGL(db_range_kernel, dim3(256), dim3(256), 0, s, N, dsrc, w.dbmm);
     const DbGeom geom{xys, tiles_x, tiles_y};
     hipLaunchKernelGGL(db_walk_kernel<false>, dim3(DB_BLOCKS), dim3(DB_THREADS), walk_lds, s, N, nbk, dsrc, geom, mm,
-                       w.dbG, (const uint32_t *)nullptr, (uint4 *)nullptr);
+                       w.dbG, (const uint32_t *)nullptr, (uint4 *)nullptr, tile_bins, 2 * T);
     hipLaunchKernelGGL(db_prefix_kernel, dim3((nbk + 1 + 255) / 256), dim3(256), 0, s, nbk, w.dbG, w.dbStart);
     hipLaunchKernelGGL(db_scan_kernel, dim3(1), dim3(1024), 0, s, nbk, w.dbStart);   // (-> [nbk] = the visible count)
     hipLaunchKernelGGL(db_walk_kernel<true>, dim3(DB_BLOCKS), dim3(DB_THREADS), walk_lds, s, N, nbk, dsrc, geom, mm,
-                       w.dbG, (const uint32_t *)w.dbStart, w.recs);
+                       w.dbG, (const uint32_t *)w.dbStart, w.recs, (int32_t *)nullptr, 0);
     hipLaunchKernelGGL(db_sort_kernel, dim3((nbk + DB_WPB - 1) / DB_WPB), dim3(64 * DB_WPB), 0, s, N, nbk,
                        (const uint32_t *)w.dbStart, (const uint4 *)w.recs, w.pairs, dsrc, geom, order, w.einfo, w.dbBase);
     hipLaunchKernelGGL(db_scan_kernel, dim3(1), dim3(1024), 0, s, nbk, w.dbBase);

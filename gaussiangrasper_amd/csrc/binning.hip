@@ -39,6 +39,9 @@ __device__ __forceinline__ int64_t dev_count(int64_t n, const int64_t *__restric
 #ifndef GG_RS_BIG
 #define GG_RS_BIG 16
 #endif
+#ifndef GG_RS_ATOMIC_RANK
+#define GG_RS_ATOMIC_RANK 1
+#endif
 static inline int rs_items(int64_t n) { return n >= (int64_t)4096 * 1024 ? GG_RS_BIG : 4; }
 
 // ---------------------------------------------------------------------------------------------
@@ -179,7 +182,9 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
 
     const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)wave * (GG_WAVE * RS_ITEMS);
     uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+#if !GG_RS_ATOMIC_RANK
     volatile uint32_t *wh = whist[wave];
+#endif
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
@@ -204,11 +209,22 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         }
         uint32_t cnt = (uint32_t)__popcll(peers);
         uint32_t before = (uint32_t)__popcll(peers & lt_mask);
+#if GG_RS_ATOMIC_RANK
+        // the group's first lane takes the digit's running count with ONE returning LDS add and hands it to the group
+        // through the lane crossbar; the adds of the 16 rounds are independent instructions in program order (a wave's
+        // LDS operations execute in order), so their latencies overlap — the read / write / barrier / read of the first
+        // version was three dependent LDS round trips per key
+        uint32_t old = 0u;
+        if (valid && before == 0) old = atomicAdd(&whist[wave][d], cnt);
+        old = __shfl(old, (int)__builtin_ctzll(peers | (1ull << 63)), 64);
+        rank[it] = old + before;
+#else
         if (valid && before == 0) wh[d] = wh[d] + cnt;  // group leader (lowest lane)
         __builtin_amdgcn_wave_barrier();
         uint32_t after = valid ? wh[d] : 0u;
         rank[it] = after - cnt + before;
         __builtin_amdgcn_wave_barrier();
+#endif
     }
     __syncthreads();
     // Per digit: offsets of the waves inside the block's run of that digit, the block's count, and —

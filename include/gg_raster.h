@@ -207,7 +207,10 @@ int gg_count_intersects(int num_points, const int32_t *num_tiles_hit,
  *                               exactly the order of the reference's sorted int64 keys
  *                               (tile_id << 32 | depth bits);
  *   tile_bins (tiles_x*tiles_y, 2) — [start,end) of each tile in that list, (0,0) if empty;
- *   isect_tile_sorted (I,) optional (may be NULL) — the tile id of every sorted entry. */
+ *   isect_tile_sorted (I,) optional (may be NULL) — the tile id of every sorted entry.
+ * Tile grids up to 1023 x 1023 (images up to 16 368 pixels a side): a Gaussian's tile box travels through the depth
+ * sort in one 32-bit word (round 4); larger grids are rejected with GG_ERR_INVALID_ARG.  Workspace: ~44 bytes per Gaussian
+ * + 12 bytes per list entry. */
 size_t gg_bin_sort_workspace(int num_points, int64_t num_intersects);
 int gg_bin_sort(int num_points, int64_t num_intersects, const float *xys, const float *depths,
                 const int32_t *radii, const int32_t *num_tiles_hit, int tiles_x, int tiles_y,

@@ -65,6 +65,9 @@ def test_argument_validation_without_a_gpu():
     assert st == -1 and b"tile_bounds" in lib.gg_last_error()
     st = lib.gg_sh_fwd(4, 5, 1, n, n, n, n)
     assert st == -1 and b"num_bases" in lib.gg_last_error()
+    # the depth sort carries a Gaussian's tile box in one 32-bit word: grids beyond 1023 x 1023 are refused, not mis-sorted
+    st = lib.gg_bin_sort(4, 4, n, n, n, n, 1024, 2, n, n, n, n, 0, n)
+    assert st == -1 and b"1023" in lib.gg_last_error()
     st = lib.gg_sh_fwd(4, 4, 2, n, n, n, n)
     assert st == -1 and b"degrees_to_use" in lib.gg_last_error()
     st = lib.gg_blend_fwd(0, 4, 16, 16, n, n, n, n, n, n, n, n, n, n, n, 0, n)

@@ -224,8 +224,9 @@ int gg_bin_sort(int num_points, int64_t num_intersects, const float *xys, const 
  * rare case count > capacity (lists truncated), calls again with a larger capacity.  Removes the one
  * host<->device round trip per view the reference has at this point (`.item()`). */
 /* gg_bin_sort_status: kept for ABI stability.  Up to round 3 the offsets scan waited on other workgroups inside its
- * launch and a wait that gave up was reported here; since round 4 no binning kernel waits on another workgroup (the scan
- * is three plain launches), so there is nothing to report: the call synchronises the stream and returns GG_OK. */
+ * launch and a wait that gave up was reported here; since round 4 no binning kernel waits on another workgroup (the
+ * offsets come out of the depth-bucket kernels), so there is nothing to report: the call synchronises the stream and
+ * returns GG_OK. */
 int gg_bin_sort_status(int num_points, int64_t num_intersects, const void *ws, size_t ws_bytes, gg_stream_t stream);
 int gg_bin_sort_dev(int num_points, int64_t capacity, const int64_t *num_intersects_dev,
                     const float *xys, const float *depths, const int32_t *radii,
